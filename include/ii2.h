@@ -1,0 +1,184 @@
+/*
+ * ii2.h — C ABI of the MI355X posting-list engine (libii2_hip.so).
+ *
+ * Drop-in boundary for the posting-list hot path of lezhnev74/inverted_index_2.  The
+ * reference is a plain Go library with no FFI seam (SURVEY.md §8 b), so the boundary is
+ * drawn *beneath* its exported Go API: the Go methods keep their signatures and bind
+ * these entry points through cgo (stub in INTEGRATION.md).  Each entry point names the
+ * reference code it replaces (file:line into the reference tree).
+ *
+ * Conventions
+ *   - every call returns 0 on success or a negative II2_E* code; ii2_last_error(ctx)
+ *     gives the message (the Go side wraps it with fmt.Errorf("…: %w"), cf. shard.go:160).
+ *   - plain pointers and sizes only.  `where` says whether a caller buffer lives in host
+ *     memory (II2_HOST — what cgo passes) or in this device's HBM (II2_DEVICE).
+ *   - inputs are read-only and never retained after return; outputs are written only on
+ *     success (all-or-nothing per call).
+ *   - a ctx is bound to one GPU and one HIP stream; calls on one ctx are serialised by an
+ *     internal mutex, so a ctx may be shared by goroutines / threads (InvertedIndex.Merge
+ *     fans Shard.Merge over `concurrency` goroutines, inverted_index.go:83-103); use one
+ *     ctx per worker to overlap.
+ *   - doc ids ("values") are uint32 everywhere, as in the reference (file/types.go:11).
+ *   - there is NO CPU fallback: without a usable gfx950 device ii2_ctx_create fails.
+ */
+#ifndef II2_H
+#define II2_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define II2_ABI_VERSION 1
+
+enum { II2_HOST = 0, II2_DEVICE = 1 };
+
+enum {
+    II2_OK = 0,
+    II2_EINVAL = -1,     /* bad argument (NULL, unsorted sizes, too many lists …) */
+    II2_ENOMEM = -2,     /* device or host allocation failed */
+    II2_EHIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
+    II2_ECAPACITY = -4,  /* caller's output buffer is too small (buffer content unspecified) */
+    II2_ERANGE = -5,     /* segment too large for the DV1 format (>= 4 GiB of payload) */
+    II2_ECOMM = -6,      /* RCCL failure / communicator not initialised */
+    II2_ENODEVICE = -7   /* no usable gfx950 GPU — the library has no CPU path */
+};
+
+#define II2_MAX_LISTS 64u   /* lists per intersect / union call, segments per merge */
+#define II2_DV1_BLOCK 256u  /* postings per DV1 block */
+
+typedef struct ii2_ctx ii2_ctx;
+typedef struct ii2_seg ii2_seg;    /* device-resident DV1 segment: n_lists posting lists */
+typedef struct ii2_tomb ii2_tomb;  /* device-resident tombstone bitmap */
+
+/* One entry per DV1 block (+ one sentinel): first doc id of the block and the byte offset
+ * of its payload (the varint gaps of the block's remaining postings). */
+typedef struct { uint32_t first_doc; uint32_t byte_off; } ii2_skip;
+
+typedef struct {
+    uint64_t n_lists;      /* aligned term slots */
+    uint64_t n_postings;
+    uint64_t n_blocks;
+    uint64_t n_bytes;      /* payload bytes */
+} ii2_seg_info;
+
+typedef struct {
+    uint64_t n_in;         /* postings read (sum of input list lengths) */
+    uint64_t n_out;        /* postings written */
+    uint64_t n_terms_out;  /* terms with >= 1 surviving posting (0 => write no segment, shard.go:219-225) */
+    uint64_t n_tiles;      /* workgroup tiles the merge was cut into */
+} ii2_merge_stats;
+
+/* ---- context -------------------------------------------------------------------------- */
+int ii2_abi_version(void);
+/* Binds a context to GPU `device` (hipSetDevice ordinal).  Fails with II2_ENODEVICE when
+ * there is no gfx950 device. */
+int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out);
+void ii2_ctx_destroy(ii2_ctx *ctx);
+const char *ii2_last_error(const ii2_ctx *ctx);     /* ctx may be NULL: last create error */
+int ii2_ctx_sync(ii2_ctx *ctx);                     /* waits for the ctx stream */
+void *ii2_ctx_stream(ii2_ctx *ctx);                 /* the hipStream_t, for event timing */
+
+/* raw device buffers for II2_DEVICE arguments */
+int ii2_dev_alloc(ii2_ctx *ctx, size_t bytes, void **dptr);
+int ii2_dev_free(ii2_ctx *ctx, void *dptr);
+int ii2_copy_h2d(ii2_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int ii2_copy_d2h(ii2_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- segments: the encode / decode steps ----------------------------------------------- */
+/* Encode step.  Replaces Writer.Append -> intcomp.CompressUint32 (file/writer.go:32-59):
+ * builds a device-resident DV1 segment from n_lists lists given CSR-style
+ * (post_off[n_lists+1] into values).  Lists are stored verbatim (any u32 sequence
+ * round-trips, cf. file/writer_test.go:14), but merge / intersect / union require each
+ * list ascending and duplicate-free — what the index itself always produces. */
+int ii2_seg_encode(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *post_off, const uint32_t *values,
+                   int where, ii2_seg **out);
+/* Adopt an already DV1-encoded segment (blk_off[n_lists+1], skip[n_blocks+1], payload[n_bytes]). */
+int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const uint32_t *blk_off,
+                   const ii2_skip *skip, const uint8_t *payload, int where, ii2_seg **out);
+/* Decode step.  Replaces Reader.Next -> intcomp.UncompressUint32 (file/reader.go:79-100):
+ * post_off[n_lists+1] and values[n_postings] are written to caller buffers. */
+int ii2_seg_decode(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *post_off, uint32_t *values, int where);
+/* Copy the DV1 arrays out (any of the three may be NULL). */
+int ii2_seg_export(ii2_ctx *ctx, const ii2_seg *seg, uint32_t *blk_off, ii2_skip *skip, uint8_t *payload);
+int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info);
+void ii2_seg_free(ii2_seg *seg);
+
+/* ---- tombstones ------------------------------------------------------------------------ */
+/* Replaces RemovedLists.Values() + slices.BinarySearch per value (removed_list.go:44-54,
+ * shard.go:165,183): a dense bitmap over [0, max(removed)] built on the device; duplicates
+ * in `removed` are harmless, order is irrelevant. */
+int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n_removed, int where, ii2_tomb **out);
+void ii2_tomb_free(ii2_tomb *tomb);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* Segment merge.  Replaces the body of Shard.Merge's loop (shard.go:163-212) together with
+ * the k-way merging iterator it drains (shard.go:253-278, go-iterators NewMergingIterator
+ * folding equal terms with file.MergeTermValues, file/types.go:14-22): for every aligned
+ * term slot t the union of the k segments' lists, sorted, duplicate-free, minus the
+ * tombstones.  All k segments must have the same n_lists (the host aligns term ids; the
+ * bytes.Compare term ordering of file/types.go:24-26 stays on the host).
+ * Output, device-resident: out_off[n_lists+1] (u64) and out_values (u32, capacity
+ * out_cap >= sum of the inputs' n_postings is always enough).  A term whose
+ * out_off[t+1]==out_off[t] has no survivors and is dropped by the caller (shard.go:192-194). */
+int ii2_merge_segments(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb,
+                       uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap,
+                       ii2_merge_stats *stats);
+/* Same, then the encode step on the merged lists: returns a new DV1 segment (what
+ * w.Append writes, shard.go:207).  *out is NULL when no term survives. */
+int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb,
+                              ii2_seg **out, ii2_merge_stats *stats);
+
+/* Multi-term intersection (build-defined operator, absent in the reference — SURVEY §0 D1):
+ * ascending ids present in every list segs[i]/list_idx[i], minus the tombstones when
+ * tomb != NULL (tomb == NULL is the reference's Read behaviour).
+ * d_out: device buffer, capacity cap >= the shortest list is always enough. */
+int ii2_intersect(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
+                  const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *count);
+/* Enqueue only: the count lands in the device word d_count; no host synchronisation. */
+int ii2_intersect_async(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
+                        const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count);
+
+/* Multi-term union.  Replaces PrefixSearch's append + slices.Sort + slices.Compact
+ * (inverted_index.go:274-292).  cap >= sum of the list lengths is always enough. */
+int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
+              const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *count);
+
+/* ---- host-buffer convenience (what the cgo binding calls) ------------------------------- */
+/* k term-aligned segments, flat: seg_off[k*(n_terms+1)] (per segment, offsets into that
+ * segment's own slice), seg_base[k+1] (where each segment's slice starts in values).
+ * removed: RemovedLists.Values() (any order, duplicates allowed) or NULL. */
+int ii2_merge_host(ii2_ctx *ctx, uint32_t k, uint64_t n_terms, const uint64_t *seg_off,
+                   const uint64_t *seg_base, const uint32_t *values,
+                   const uint32_t *removed, uint64_t n_removed,
+                   uint64_t *out_off, uint32_t *out_values, uint64_t out_cap, ii2_merge_stats *stats);
+/* n lists, flat: list_off[n+1] into values. */
+int ii2_intersect_host(ii2_ctx *ctx, uint32_t n, const uint64_t *list_off, const uint32_t *values,
+                       const uint32_t *removed, uint64_t n_removed,
+                       uint32_t *out, uint64_t cap, uint64_t *count);
+int ii2_union_host(ii2_ctx *ctx, uint32_t n, const uint64_t *list_off, const uint32_t *values,
+                   const uint32_t *removed, uint64_t n_removed,
+                   uint32_t *out, uint64_t cap, uint64_t *count);
+
+/* ---- multi-GPU: concatenate per-shard results in rank order ----------------------------- */
+/* Replaces InvertedIndex.Read's shard-order concatenation (inverted_index.go:330-339) when
+ * the term space (or the doc-id space) is sharded over the GPUs of one node.  One process
+ * per GPU; rank 0 calls ii2_comm_unique_id and hands the 128 bytes to the others. */
+#define II2_UNIQUE_ID_BYTES 128
+int ii2_comm_unique_id(void *id_out);
+int ii2_comm_init(ii2_ctx *ctx, int world, int rank, const void *unique_id);
+/* Every rank contributes d_local[n_local]; every rank receives all contributions in rank
+ * order in d_out (capacity cap, in values) and the per-rank counts in counts_host[world]. */
+int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local,
+                   uint32_t *d_out, uint64_t cap, uint64_t *counts_host);
+
+/* ---- diagnostics ------------------------------------------------------------------------ */
+/* Runs the device self-checks (wave scan, block decode against a scalar decode). 0 = pass. */
+int ii2_selftest(ii2_ctx *ctx);
+/* Tuning knobs, by name ("intersect.lookback", "merge.cap", …); unknown names are II2_EINVAL. */
+int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,559 @@
+// api.cpp — the C ABI of libii2_hip.so (include/ii2.h): contexts, segments, tombstones,
+// intersect / union / merge entry points and the host-buffer convenience calls.
+// There is deliberately no CPU implementation behind any entry point.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "internal.h"
+
+using namespace ii2;
+
+static thread_local std::string g_create_err;
+
+#define HIP_TRY(ctx, expr)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+            return II2_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+static int fail(ii2_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// temp device allocation freed at scope exit (cold paths only: encode / import / host calls)
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// Workspace: reserve the total up front, then carve.
+static int ws_reserve(ii2_ctx *ctx, size_t bytes) {
+    ctx->ws_used = 0;
+    if (bytes <= ctx->ws_cap) return II2_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    ctx->ws = nullptr;
+    ctx->ws_cap = 0;
+    size_t want = align_up(bytes + bytes / 4, 1 << 20);
+    if (hipMalloc((void **)&ctx->ws, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "workspace allocation failed");
+    ctx->ws_cap = want;
+    return II2_OK;
+}
+template <class T> static T *ws_take(ii2_ctx *ctx, size_t count) {
+    size_t bytes = align_up(count * sizeof(T));
+    T *p = (T *)(ctx->ws + ctx->ws_used);
+    ctx->ws_used += bytes;
+    return p;
+}
+
+static int desc_reserve(ii2_ctx *ctx, size_t n) {
+    if (n <= ctx->desc_cap) return II2_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->desc) (void)hipFree(ctx->desc);
+    ctx->desc = nullptr;
+    ctx->desc_cap = 0;
+    size_t want = align_up(n + n / 2, 4096);
+    if (hipMalloc((void **)&ctx->desc, want * sizeof(unsigned long long)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "descriptor allocation failed");
+    HIP_TRY(ctx, hipMemsetAsync(ctx->desc, 0, want * sizeof(unsigned long long), ctx->stream));
+    ctx->desc_cap = want;
+    return II2_OK;
+}
+static uint32_t next_epoch(ii2_ctx *ctx) {
+    ctx->epoch = (ctx->epoch + 1) & 0x3FFFFFu;
+    if (ctx->epoch == 0) {     // wrapped: forget every old descriptor
+        (void)hipMemsetAsync(ctx->desc, 0, ctx->desc_cap * sizeof(unsigned long long), ctx->stream);
+        ctx->epoch = 1;
+    }
+    return ctx->epoch;
+}
+
+extern "C" {
+
+int ii2_abi_version(void) { return II2_ABI_VERSION; }
+
+int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
+    (void)flags;
+    if (!out) return II2_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_create_err = "no HIP device visible (libii2_hip has no CPU path)";
+        return II2_ENODEVICE;
+    }
+    if (device < 0 || device >= n) { g_create_err = "device ordinal out of range"; return II2_EINVAL; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { g_create_err = "hipGetDeviceProperties failed"; return II2_EHIP; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return II2_ENODEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) { g_create_err = "hipSetDevice failed"; return II2_EHIP; }
+    ii2_ctx *ctx = new (std::nothrow) ii2_ctx();
+    if (!ctx) return II2_ENOMEM;
+    ctx->device = device;
+    ctx->cu_count = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_mail, 64 * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_mail, 64 * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess ||
+        hipMemset(ctx->d_ticket, 0, 64) != hipSuccess) {
+        g_create_err = "context resource allocation failed";
+        ii2_ctx_destroy(ctx);
+        return II2_EHIP;
+    }
+    *out = ctx;
+    return II2_OK;
+}
+
+void ii2_ctx_destroy(ii2_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ii2_comm_destroy_internal(ctx);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->desc) (void)hipFree(ctx->desc);
+    if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
+    if (ctx->d_mail) (void)hipFree(ctx->d_mail);
+    if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *ii2_last_error(const ii2_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int ii2_ctx_sync(ii2_ctx *ctx) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+
+void *ii2_ctx_stream(ii2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int ii2_dev_alloc(ii2_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "hipMalloc failed");
+    return II2_OK;
+}
+int ii2_dev_free(ii2_ctx *ctx, void *dptr) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(dptr));
+    return II2_OK;
+}
+int ii2_copy_h2d(ii2_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+int ii2_copy_d2h(ii2_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+
+}  // extern "C"
+
+// ---- segments -----------------------------------------------------------------------------
+static void seg_release(ii2_seg *s) {
+    if (!s) return;
+    if (s->d_blk_off) (void)hipFree(s->d_blk_off);
+    if (s->d_skip) (void)hipFree(s->d_skip);
+    if (s->d_payload) (void)hipFree(s->d_payload);
+    delete s;
+}
+
+// reads back the driver-choice statistics of single-list segments and the host blk_off mirror
+static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
+    seg->h_blk_off.resize(seg->n_lists + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+
+// encode from device-resident CSR (d_post_off, d_values) — unlocked
+int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values,
+                                uint64_t n_postings, ii2_seg **out) {
+    hipStream_t st = ctx->stream;
+    std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
+    if (!seg) return II2_ENOMEM;
+    seg->ctx = ctx;
+    seg->n_lists = n_lists;
+    seg->n_postings = n_postings;
+    const uint64_t nb_bound = n_postings / II2_DV1_BLOCK + n_lists + 1;
+    if (nb_bound >= (1ull << 31)) return fail(ctx, II2_ERANGE, "too many DV1 blocks for one segment");
+    if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    DevBuf nblk, scan_tmp;
+    const size_t tmpb = scan_temp_bytes((size_t)std::max<uint64_t>(n_lists + 1, nb_bound + 1));
+    if (nblk.alloc((n_lists + 1) * sizeof(uint32_t)) != hipSuccess || scan_tmp.alloc(tmpb) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "encode scratch allocation failed");
+    HIP_TRY(ctx, launch_enc_list_blocks(d_post_off, n_lists, nblk.as<uint32_t>(), st));
+    HIP_TRY(ctx, scan_excl_u32(scan_tmp.p, tmpb, nblk.as<uint32_t>(), seg->d_blk_off, n_lists + 1, st));
+    uint32_t nb32 = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nb32, seg->d_blk_off + n_lists, sizeof nb32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint64_t nb = nb32;
+    seg->n_blocks = nb;
+    DevBuf sizes, boff;
+    if (sizes.alloc((nb + 1) * sizeof(uint32_t)) != hipSuccess || boff.alloc((nb + 1) * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&seg->d_skip, (nb + 1) * sizeof(ii2_skip)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "encode scratch allocation failed");
+    HIP_TRY(ctx, launch_enc_block_sizes(d_post_off, seg->d_blk_off, n_lists, d_values, nb, sizes.as<uint32_t>(), seg->d_skip, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(scan_tmp.p, tmpb, sizes.as<uint32_t>(), boff.as<uint64_t>(), nb + 1, st));
+    uint64_t nbytes = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nbytes, boff.as<uint64_t>() + nb, sizeof nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (nbytes >= 0xFFFFFFF0ull) return fail(ctx, II2_ERANGE, "segment payload exceeds the 4 GiB DV1 limit; split the segment");
+    seg->n_bytes = nbytes;
+    if (hipMalloc((void **)&seg->d_payload, nbytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + nbytes, 0, 16, st));
+    HIP_TRY(ctx, launch_enc_write(d_post_off, seg->d_blk_off, n_lists, d_values, nb, boff.as<uint64_t>(), seg->d_skip,
+                                  seg->d_payload, n_postings, st));
+    int rc = seg_finish(ctx, seg.get());
+    if (rc) return rc;
+    *out = seg.release();
+    return II2_OK;
+}
+
+// decode into device buffers — unlocked.  d_post_off may be null.
+int ii2_seg_decode_dev_unlocked(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *d_post_off, uint32_t *d_values) {
+    hipStream_t st = ctx->stream;
+    const uint64_t nb = seg->n_blocks;
+    DevBuf counts, bpo, scan_tmp;
+    const size_t tmpb = scan_temp_bytes((size_t)nb + 1);
+    if (counts.alloc((nb + 1) * sizeof(uint32_t)) != hipSuccess || bpo.alloc((nb + 1) * sizeof(uint64_t)) != hipSuccess ||
+        scan_tmp.alloc(tmpb) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "decode scratch allocation failed");
+    HIP_TRY(ctx, launch_dec_block_counts(seg->d_skip, seg->d_payload, nb, counts.as<uint32_t>(), st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(scan_tmp.p, tmpb, counts.as<uint32_t>(), bpo.as<uint64_t>(), nb + 1, st));
+    if (d_values) HIP_TRY(ctx, launch_dec_write(seg->d_skip, seg->d_payload, nb, bpo.as<uint64_t>(), d_values, st));
+    if (d_post_off) HIP_TRY(ctx, launch_gather_post_off(seg->d_blk_off, bpo.as<uint64_t>(), seg->n_lists, d_post_off, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return II2_OK;
+}
+
+extern "C" {
+
+int ii2_seg_encode(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *post_off, const uint32_t *values, int where, ii2_seg **out) {
+    if (!ctx || !post_off || !out || (where != II2_HOST && where != II2_DEVICE)) return fail(ctx, II2_EINVAL, "ii2_seg_encode: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    if (where == II2_DEVICE) {
+        uint64_t n = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n, post_off + n_lists, sizeof n, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return ii2_seg_encode_dev_unlocked(ctx, n_lists, post_off, values, n, out);
+    }
+    const uint64_t n = post_off[n_lists];
+    for (uint64_t l = 0; l < n_lists; l++)
+        if (post_off[l + 1] < post_off[l]) return fail(ctx, II2_EINVAL, "ii2_seg_encode: post_off must be non-decreasing");
+    if (n && !values) return fail(ctx, II2_EINVAL, "ii2_seg_encode: values is NULL");
+    DevBuf dpo, dv;
+    if (dpo.alloc((n_lists + 1) * sizeof(uint64_t)) != hipSuccess || dv.alloc(n * sizeof(uint32_t)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "encode staging allocation failed");
+    HIP_TRY(ctx, hipMemcpyAsync(dpo.p, post_off, (n_lists + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(dv.p, values, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    return ii2_seg_encode_dev_unlocked(ctx, n_lists, dpo.as<uint64_t>(), dv.as<uint32_t>(), n, out);
+}
+
+int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const uint32_t *blk_off, const ii2_skip *skip,
+                   const uint8_t *payload, int where, ii2_seg **out) {
+    if (!ctx || !blk_off || !skip || !out) return fail(ctx, II2_EINVAL, "ii2_seg_import: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    const hipMemcpyKind kind = where == II2_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
+    if (!seg) return II2_ENOMEM;
+    seg->ctx = ctx;
+    seg->n_lists = n_lists;
+    seg->n_postings = n_postings;
+    uint32_t nb = 0;
+    if (where == II2_HOST) nb = blk_off[n_lists];
+    else {
+        HIP_TRY(ctx, hipMemcpyAsync(&nb, blk_off + n_lists, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    seg->n_blocks = nb;
+    ii2_skip last;
+    if (where == II2_HOST) last = skip[nb];
+    else {
+        HIP_TRY(ctx, hipMemcpyAsync(&last, skip + nb, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    seg->n_bytes = last.byte_off;
+    if (seg->n_bytes && !payload) return fail(ctx, II2_EINVAL, "ii2_seg_import: payload is NULL");
+    if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&seg->d_skip, ((uint64_t)nb + 1) * sizeof(ii2_skip)) != hipSuccess ||
+        hipMalloc((void **)&seg->d_payload, seg->n_bytes + 16) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off, blk_off, (n_lists + 1) * sizeof(uint32_t), kind, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(seg->d_skip, skip, ((uint64_t)nb + 1) * sizeof(ii2_skip), kind, ctx->stream));
+    if (seg->n_bytes) HIP_TRY(ctx, hipMemcpyAsync(seg->d_payload, payload, seg->n_bytes, kind, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + seg->n_bytes, 0, 16, ctx->stream));
+    int rc = seg_finish(ctx, seg.get());
+    if (rc) return rc;
+    *out = seg.release();
+    return II2_OK;
+}
+
+int ii2_seg_decode(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *post_off, uint32_t *values, int where) {
+    if (!ctx || !seg) return fail(ctx, II2_EINVAL, "ii2_seg_decode: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (where == II2_DEVICE) return ii2_seg_decode_dev_unlocked(ctx, seg, post_off, values);
+    DevBuf dpo, dv;
+    if (dpo.alloc((seg->n_lists + 1) * sizeof(uint64_t)) != hipSuccess || dv.alloc(seg->n_postings * sizeof(uint32_t)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "decode staging allocation failed");
+    int rc = ii2_seg_decode_dev_unlocked(ctx, seg, dpo.as<uint64_t>(), dv.as<uint32_t>());
+    if (rc) return rc;
+    if (post_off) HIP_TRY(ctx, hipMemcpyAsync(post_off, dpo.p, (seg->n_lists + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (values && seg->n_postings)
+        HIP_TRY(ctx, hipMemcpyAsync(values, dv.p, seg->n_postings * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+
+int ii2_seg_export(ii2_ctx *ctx, const ii2_seg *seg, uint32_t *blk_off, ii2_skip *skip, uint8_t *payload) {
+    if (!ctx || !seg) return fail(ctx, II2_EINVAL, "ii2_seg_export: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (blk_off) HIP_TRY(ctx, hipMemcpyAsync(blk_off, seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (skip) HIP_TRY(ctx, hipMemcpyAsync(skip, seg->d_skip, (seg->n_blocks + 1) * sizeof(ii2_skip), hipMemcpyDeviceToHost, ctx->stream));
+    if (payload && seg->n_bytes) HIP_TRY(ctx, hipMemcpyAsync(payload, seg->d_payload, seg->n_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+
+int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info) {
+    if (!seg || !info) return II2_EINVAL;
+    info->n_lists = seg->n_lists;
+    info->n_postings = seg->n_postings;
+    info->n_blocks = seg->n_blocks;
+    info->n_bytes = seg->n_bytes;
+    return II2_OK;
+}
+
+void ii2_seg_free(ii2_seg *seg) {
+    if (!seg) return;
+    if (seg->ctx) {
+        std::lock_guard<std::mutex> g(seg->ctx->mu);
+        (void)hipStreamSynchronize(seg->ctx->stream);
+        seg_release(seg);
+    } else seg_release(seg);
+}
+
+// ---- tombstones ---------------------------------------------------------------------------
+int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where, ii2_tomb **out) {
+    if (!ctx || !out || (n && !removed)) return fail(ctx, II2_EINVAL, "ii2_tomb_create: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    DevBuf staged;
+    const uint32_t *d_rem = removed;
+    if (where == II2_HOST && n) {
+        if (staged.alloc(n * sizeof(uint32_t)) != hipSuccess) return fail(ctx, II2_ENOMEM, "tombstone staging allocation failed");
+        HIP_TRY(ctx, hipMemcpyAsync(staged.p, removed, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        d_rem = staged.as<uint32_t>();
+    }
+    uint32_t mx = 0;
+    if (n) {
+        uint32_t *d_mx = (uint32_t *)ctx->d_mail;
+        HIP_TRY(ctx, hipMemsetAsync(d_mx, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, launch_max_u32(d_rem, n, d_mx, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&mx, d_mx, sizeof mx, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    ii2_tomb *t = new (std::nothrow) ii2_tomb();
+    if (!t) return II2_ENOMEM;
+    t->ctx = ctx;
+    t->n_words = n ? (uint64_t)(mx >> 5) + 1 : 0;
+    if (hipMalloc((void **)&t->d_words, (t->n_words + 4) * sizeof(uint32_t)) != hipSuccess) {
+        delete t;
+        return fail(ctx, II2_ENOMEM, "tombstone bitmap allocation failed");
+    }
+    hipError_t e = hipMemsetAsync(t->d_words, 0, (t->n_words + 4) * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = launch_tomb_build(d_rem, n, t->d_words, t->n_words, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(t->d_words);
+        delete t;
+        ctx->err = std::string("tombstone build: ") + hipGetErrorString(e);
+        return II2_EHIP;
+    }
+    *out = t;
+    return II2_OK;
+}
+
+void ii2_tomb_free(ii2_tomb *t) {
+    if (!t) return;
+    if (t->ctx) {
+        std::lock_guard<std::mutex> g(t->ctx->mu);
+        (void)hipStreamSynchronize(t->ctx->stream);
+    }
+    if (t->d_words) (void)hipFree(t->d_words);
+    delete t;
+}
+
+}  // extern "C"
+
+// ---- intersect ------------------------------------------------------------------------------
+static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListView *v) {
+    if (!seg || idx >= seg->n_lists) return fail(ctx, II2_EINVAL, "list index out of range");
+    if (seg->ctx != ctx) return fail(ctx, II2_EINVAL, "segment belongs to another context");
+    const uint32_t b0 = seg->h_blk_off[idx], b1 = seg->h_blk_off[idx + 1];
+    v->skip = seg->d_skip + b0;
+    v->payload = seg->d_payload;
+    v->nblk = b1 - b0;
+    v->pad = 0;
+    return II2_OK;
+}
+
+static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
+                              const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count) {
+    if (n == 0 || n > MAX_LISTS || !segs || !d_count) return fail(ctx, II2_EINVAL, "ii2_intersect: bad argument");
+    hipStream_t st = ctx->stream;
+    IntersectParams p;
+    std::memset(&p, 0, sizeof p);
+    std::vector<ListView> views(n);
+    bool any_empty = false;
+    for (uint32_t i = 0; i < n; i++) {
+        int rc = make_list_view(ctx, segs[i], list_idx ? list_idx[i] : 0, &views[i]);
+        if (rc) return rc;
+        any_empty |= views[i].nblk == 0;
+    }
+    if (any_empty) {
+        HIP_TRY(ctx, hipMemsetAsync(d_count, 0, sizeof(uint64_t), st));
+        return II2_OK;
+    }
+    if (!d_out) return fail(ctx, II2_EINVAL, "ii2_intersect: output buffer is NULL");
+    std::stable_sort(views.begin(), views.end(), [](const ListView &a, const ListView &b) { return a.nblk < b.nblk; });
+    for (uint32_t i = 0; i < n; i++) p.lists[i] = views[i];
+    p.n_lists = n;
+    const uint32_t nblk0 = views[0].nblk;
+    // tile height: aim the tile's doc span at the LDS byte map; keep >= ~8 tiles per CU
+    uint32_t G = 1;
+    if (ctx->opt_intersect_g > 0) G = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, ISECT_GMAX);
+    else if (nblk0 > 1) {
+        ii2_skip ends[2];
+        HIP_TRY(ctx, hipMemcpyAsync(&ends[0], views[0].skip, sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(&ends[1], views[0].skip + (nblk0 - 1), sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const double per_block = (double)(ends[1].first_doc - ends[0].first_doc) / (double)(nblk0 - 1);
+        const double g = per_block > 0 ? 0.85 * ISECT_SMAX / per_block : ISECT_GMAX;
+        G = g >= ISECT_GMAX ? ISECT_GMAX : g < 1 ? 1u : (uint32_t)g;
+        while (G > 1 && nblk0 / G < 8u * (uint32_t)ctx->cu_count) G >>= 1;
+    }
+    p.G = G;
+    p.n_tiles = (nblk0 + G - 1) / G;
+    p.lookback = ctx->opt_intersect_lookback ? 1u : 0u;
+    size_t need = align_up((size_t)p.n_tiles * 2 * n * sizeof(uint32_t)) + 4096;
+    if (!p.lookback)
+        need += align_up((size_t)p.n_tiles * G * 256 * sizeof(uint32_t)) + align_up((p.n_tiles + 1) * sizeof(uint32_t)) +
+                align_up((p.n_tiles + 1) * sizeof(uint64_t));
+    int rc = ws_reserve(ctx, need);
+    if (rc) return rc;
+    p.ranges = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * 2 * n);
+    uint64_t *d_tile_off = nullptr;
+    if (p.lookback) {
+        rc = desc_reserve(ctx, p.n_tiles);
+        if (rc) return rc;
+        p.desc = ctx->desc;
+        p.epoch = next_epoch(ctx);
+        p.ticket = ctx->d_ticket;
+        p.ticket_base = ctx->ticket_val;
+        ctx->ticket_val += p.n_tiles;
+    } else {
+        p.tmp = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * G * 256);
+        p.tile_count = ws_take<uint32_t>(ctx, p.n_tiles + 1);
+        d_tile_off = ws_take<uint64_t>(ctx, p.n_tiles + 1);
+    }
+    p.tomb = tomb ? tomb->d_words : nullptr;
+    p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+    p.out = d_out;
+    p.out_cap = cap;
+    p.d_count = d_count;
+    HIP_TRY(ctx, launch_intersect(p, d_tile_off, st));
+    return II2_OK;
+}
+
+extern "C" {
+
+int ii2_intersect_async(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
+                        const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return intersect_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, d_count);
+}
+
+int ii2_intersect(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
+                  const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *count) {
+    if (!ctx || !count) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = intersect_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, ctx->d_mail);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count = ctx->h_mail[0];
+    if (*count > cap) return fail(ctx, II2_ECAPACITY, "ii2_intersect: result does not fit the output buffer (content unspecified)");
+    return II2_OK;
+}
+
+int ii2_selftest(ii2_ctx *ctx) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ws_reserve(ctx, SELFTEST_SCRATCH + 4096);
+    if (rc) return rc;
+    uint8_t *scratch = ws_take<uint8_t>(ctx, SELFTEST_SCRATCH);
+    uint32_t *d_fail = (uint32_t *)ctx->d_mail;
+    HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, launch_selftest(d_fail, scratch, ctx->stream));
+    uint32_t f = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&f, d_fail, sizeof f, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (f) {
+        char msg[96];
+        std::snprintf(msg, sizeof msg, "device self-test failed, mask 0x%x (1=scan 2=decode 4=count)", f);
+        ctx->err = msg;
+        return (int)f;
+    }
+    return II2_OK;
+}
+
+int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const std::string k(name);
+    if (k == "intersect.lookback") ctx->opt_intersect_lookback = value;
+    else if (k == "intersect.g") ctx->opt_intersect_g = value;
+    else if (k == "merge.cap") ctx->opt_merge_cap = value;
+    else if (k == "merge.lookback") ctx->opt_merge_lookback = value;
+    else return fail(ctx, II2_EINVAL, "unknown option");
+    return II2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// codec.hip — DV1 encode / decode kernels, tombstone bitmap build, device self-test.
+// Encode replaces Writer.Append -> intcomp.CompressUint32 (reference file/writer.go:32-59),
+// decode replaces Reader.Next -> intcomp.UncompressUint32 (file/reader.go:79-100) — as
+// roles; the byte format is this build's own.
+#include "dv1_device.h"
+#include "internal.h"
+
+namespace ii2 {
+
+// ---- encode ---------------------------------------------------------------------------
+__global__ void k_enc_list_blocks(const uint64_t *__restrict__ post_off, uint64_t n_lists, uint32_t *__restrict__ nblk) {
+    uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > n_lists) return;
+    if (l == n_lists) { nblk[l] = 0; return; }
+    uint64_t n = post_off[l + 1] - post_off[l];
+    nblk[l] = (uint32_t)((n + II2_DV1_BLOCK - 1) / II2_DV1_BLOCK);
+}
+
+// list that owns block b: last l with blk_off[l] <= b
+__device__ __forceinline__ uint64_t owner_list(const uint32_t *__restrict__ blk_off, uint64_t n_lists, uint32_t b) {
+    uint64_t lo = 0, hi = n_lists;      // invariant: blk_off[lo] <= b < blk_off[hi]
+    while (hi - lo > 1) {
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (blk_off[mid] <= b) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// One wave per block: lane i handles postings 4i..4i+3 of the block.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_enc_blocks(const uint64_t *__restrict__ post_off, const uint32_t *__restrict__ blk_off,
+                                                    uint64_t n_lists, const uint32_t *__restrict__ values, uint64_t n_blocks,
+                                                    uint32_t *__restrict__ sizes, const uint64_t *__restrict__ byte_off64,
+                                                    ii2_skip *__restrict__ skip, uint8_t *__restrict__ payload, uint64_t n_postings) {
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int l = lane_id();
+    if (b > n_blocks) return;
+    if (b == n_blocks) {          // sentinel
+        if (l == 0) {
+            if (!WRITE) sizes[b] = 0;
+            else {
+                skip[b].first_doc = n_postings ? values[n_postings - 1] : 0u;
+                skip[b].byte_off = (uint32_t)byte_off64[b];
+            }
+        }
+        return;
+    }
+    const uint64_t li = owner_list(blk_off, n_lists, (uint32_t)b);
+    const uint64_t p0 = post_off[li] + (uint64_t)(b - blk_off[li]) * II2_DV1_BLOCK;
+    const uint64_t pe = post_off[li + 1];
+    const uint32_t cnt = (uint32_t)(pe - p0 < II2_DV1_BLOCK ? pe - p0 : II2_DV1_BLOCK);
+    uint32_t d[4];
+    uint32_t len = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = 4u * (uint32_t)l + (uint32_t)j;
+        d[j] = 0;
+        if (i >= 1 && i < cnt) {
+            d[j] = values[p0 + i] - values[p0 + i - 1];
+            len += varint_len(d[j]);
+        }
+    }
+    const uint32_t incl = wave_incl_scan(len);
+    if (!WRITE) {
+        if (l == 63) sizes[b] = incl;
+        return;
+    }
+    const uint64_t base = byte_off64[b];
+    if (l == 0) {
+        skip[b].first_doc = values[p0];
+        skip[b].byte_off = (uint32_t)base;
+    }
+    uint64_t q = base + (incl - len);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t i = 4u * (uint32_t)l + (uint32_t)j;
+        if (i >= 1 && i < cnt) {
+            uint32_t v = d[j];
+            while (v >= 0x80u) { payload[q++] = (uint8_t)(v | 0x80u); v >>= 7; }
+            payload[q++] = (uint8_t)v;
+        }
+    }
+}
+
+hipError_t launch_enc_list_blocks(const uint64_t *post_off, uint64_t n_lists, uint32_t *nblk, hipStream_t s) {
+    uint64_t n = n_lists + 1;
+    hipLaunchKernelGGL(k_enc_list_blocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, post_off, n_lists, nblk);
+    return hipGetLastError();
+}
+
+hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
+                                  const uint32_t *values, uint64_t n_blocks, uint32_t *sizes, ii2_skip *skip, hipStream_t s) {
+    uint64_t waves = n_blocks + 1;
+    hipLaunchKernelGGL(k_enc_blocks<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, post_off, blk_off, n_lists,
+                       values, n_blocks, sizes, (const uint64_t *)nullptr, skip, (uint8_t *)nullptr, (uint64_t)0);
+    return hipGetLastError();
+}
+
+hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
+                            const uint32_t *values, uint64_t n_blocks, const uint64_t *byte_off64,
+                            ii2_skip *skip, uint8_t *payload, uint64_t n_postings, hipStream_t s) {
+    uint64_t waves = n_blocks + 1;
+    hipLaunchKernelGGL(k_enc_blocks<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, post_off, blk_off, n_lists,
+                       values, n_blocks, (uint32_t *)nullptr, byte_off64, skip, payload, n_postings);
+    return hipGetLastError();
+}
+
+// ---- decode ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dec_block_counts(const ii2_skip *__restrict__ skip, const uint8_t *__restrict__ payload,
+                                                          uint64_t n_blocks, uint32_t *__restrict__ counts) {
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b > n_blocks) return;
+    if (b == n_blocks) { if (lane_id() == 0) counts[b] = 0; return; }
+    const uint32_t q0 = skip[b].byte_off, q1 = skip[b + 1].byte_off;
+    const uint32_t c = count_block_wave(payload, q0, q1);
+    if (lane_id() == 0) counts[b] = c;
+}
+
+__global__ __launch_bounds__(256) void k_dec_write(const ii2_skip *__restrict__ skip, const uint8_t *__restrict__ payload,
+                                                   uint64_t n_blocks, const uint64_t *__restrict__ bpo, uint32_t *__restrict__ values) {
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= n_blocks) return;
+    const uint32_t q0 = skip[b].byte_off, q1 = skip[b + 1].byte_off;
+    uint32_t *out = values + bpo[b];
+    decode_block_wave(payload, q0, q1, skip[b].first_doc, [&](uint32_t ix, uint32_t id) { out[ix] = id; });
+}
+
+__global__ void k_gather_post_off(const uint32_t *__restrict__ blk_off, const uint64_t *__restrict__ bpo, uint64_t n_lists,
+                                  uint64_t *__restrict__ post_off) {
+    uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l <= n_lists) post_off[l] = bpo[blk_off[l]];
+}
+
+hipError_t launch_dec_block_counts(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, uint32_t *counts, hipStream_t s) {
+    uint64_t waves = n_blocks + 1;
+    hipLaunchKernelGGL(k_dec_block_counts, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, skip, payload, n_blocks, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, const uint64_t *bpo,
+                            uint32_t *values, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dec_write, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, s, skip, payload, n_blocks, bpo, values);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, uint64_t n_lists, uint64_t *post_off, hipStream_t s) {
+    uint64_t n = n_lists + 1;
+    hipLaunchKernelGGL(k_gather_post_off, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blk_off, bpo, n_lists, post_off);
+    return hipGetLastError();
+}
+
+// ---- tombstones -----------------------------------------------------------------------
+// RemovedLists.Values() (removed_list.go:44-54) as a dense bitmap: bit v set <=> v removed.
+__global__ void k_tomb_build(const uint32_t *__restrict__ removed, uint64_t n, uint32_t *__restrict__ words, uint64_t n_words) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = removed[i];
+        uint64_t w = v >> 5;
+        if (w < n_words) atomicOr(&words[w], 1u << (v & 31u));
+    }
+}
+
+__global__ void k_max_u32(const uint32_t *__restrict__ v, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        m = v[i] > m ? v[i] : m;
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (lane_id() == 0) atomicMax(out, m);
+}
+
+hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_tomb_build, dim3(g), dim3(256), 0, s, removed, n, words, n_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_max_u32, dim3(g), dim3(256), 0, s, v, n, out);
+    return hipGetLastError();
+}
+
+// ---- self-test ------------------------------------------------------------------------
+// fail bit 0: DPP scan != shuffle scan; bit 1: wave block decode != scalar decode.
+__global__ void k_selftest(uint32_t *fail, uint8_t *gbuf) {
+    const int l = lane_id();
+    uint32_t seed = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1) + blockIdx.x * 7919u;
+    for (int it = 0; it < 8; it++) {
+        seed = seed * 1664525u + 1013904223u;
+        uint32_t x = seed >> (it * 3);
+        if (wave_incl_scan(x) != wave_incl_scan_shfl(x)) atomicOr(fail, 1u);
+    }
+    // a block with mixed varint lengths, encoded by lane 0 into global scratch
+    __shared__ uint32_t ids[4][256];
+    __shared__ uint32_t got[4][256];
+    const int wv = threadIdx.x >> 6;
+    uint8_t *buf = gbuf + (size_t)(blockIdx.x * 4 + wv) * 1408;   // global scratch, 1408 B per wave
+    uint32_t nbytes = 0;
+    if (l == 0) {
+        uint32_t s2 = 12345u + 977u * (uint32_t)(blockIdx.x * 4 + wv);
+        uint32_t cur = 1000u + blockIdx.x;
+        ids[wv][0] = cur;
+        const uint32_t cnt = 256u - (uint32_t)((blockIdx.x * 4 + wv) % 5) * 50u;   // 256,206,156,106,56
+        for (uint32_t i = 1; i < 256; i++) {
+            s2 = s2 * 1664525u + 1013904223u;
+            uint32_t sel = (s2 >> 28) & 7u;
+            uint32_t gap = sel < 4 ? 1u + ((s2 >> 8) & 0x3Fu) : sel < 6 ? 128u + ((s2 >> 8) & 0x3FFFu)
+                         : sel == 6 ? (1u << 14) + ((s2 >> 4) & 0xFFFFFu) : (1u << 21) + ((s2 >> 3) & 0xFFFFFFu);
+            if (blockIdx.x == 0) gap = 1u + (s2 >> 30);            // pure 1-byte block
+            if (blockIdx.x == 1 && i == 200) gap = 0xF0000000u;    // 5-byte varint (wraps; still additive)
+            cur += gap;
+            ids[wv][i] = cur;
+            if (i < cnt) {
+                uint32_t v = gap;
+                while (v >= 0x80u) { buf[nbytes++] = (uint8_t)(v | 0x80u); v >>= 7; }
+                buf[nbytes++] = (uint8_t)v;
+            }
+        }
+        for (int z = 0; z < 8; z++) buf[nbytes + z] = 0xFF;
+        got[wv][0] = cnt;   // stash
+    }
+    __threadfence();
+    __syncthreads();
+    const uint32_t cnt = got[wv][0];
+    nbytes = 0;
+    // recompute nbytes uniformly (lane 0 knows it; broadcast through LDS-free readlane)
+    {
+        uint32_t nb0 = 0;
+        if (l == 0) {
+            for (uint32_t i = 1; i < cnt; i++) nb0 += varint_len(ids[wv][i] - ids[wv][i - 1]);
+        }
+        nbytes = wave_bcast(nb0, 0);
+    }
+    __syncthreads();
+    const uint32_t first = ids[wv][0];
+    for (int i = l; i < 256; i += 64) got[wv][i] = 0xDEADBEEFu;
+    __syncthreads();
+    uint32_t n = decode_block_wave((const uint8_t *)buf, 0u, nbytes, first, [&](uint32_t ix, uint32_t id) {
+        if (ix < 256) got[wv][ix] = id;
+    });
+    __syncthreads();
+    if (n != cnt) atomicOr(fail, 2u);
+    for (uint32_t i = (uint32_t)l; i < cnt; i += 64)
+        if (got[wv][i] != ids[wv][i]) atomicOr(fail, 2u);
+    if (count_block_wave((const uint8_t *)buf, 0u, nbytes) != cnt) atomicOr(fail, 4u);
+}
+
+hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s) {
+    hipLaunchKernelGGL(k_selftest, dim3(64), dim3(256), 0, s, d_fail, d_scratch);
+    return hipGetLastError();
+}
+
+}  // namespace ii2

@@ -1,0 +1,169 @@
+// dv1_device.h — wave64 device helpers for the DV1 block-Δ-varint posting format (gfx950).
+//
+// DV1: a list is cut into blocks of 256 postings.  Block b has a skip entry
+// {first_doc, byte_off}; its payload holds the LEB128 varint gaps of postings 1..cnt-1
+// (posting 0 is first_doc), at payload[skip[b].byte_off .. skip[b+1].byte_off).
+// Only the last block of a list may be short; its count is 1 + (#terminator bytes).
+//
+// Decode is additive: a byte q contributes (b & 0x7f) << 7*k(q), k = number of
+// continuation bytes directly before it, and a posting's id is first_doc plus the
+// inclusive prefix sum of the contributions up to its terminator byte.  So one wave
+// decodes a 256-byte chunk with 4 bytes per lane and one DPP prefix sum — no per-varint
+// serial dependency and no divergence on varint length.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ii2.h"
+
+namespace ii2 {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// Inclusive prefix sum over the 64 lanes of a wave (all lanes must be active).
+// row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 / row_bcast:31 carry the row
+// totals across rows (gfx9 DPP).
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1,3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2,3
+    return x;
+}
+
+// Reference form of the same scan (shuffles); used by the self-test to check the DPP form.
+__device__ __forceinline__ uint32_t wave_incl_scan_shfl(uint32_t x) {
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = (uint32_t)__shfl_up((int)x, d, 64);
+        if (l >= d) x += y;
+    }
+    return x;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(x), 63);
+}
+
+__device__ __forceinline__ uint32_t wave_bcast(uint32_t x, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, lane);
+}
+
+// value of lane-1 (lane 0 receives `first`)
+__device__ __forceinline__ uint32_t wave_shift_up1(uint32_t x, uint32_t first) {
+    uint32_t y = (uint32_t)__shfl_up((int)x, 1, 64);
+    return lane_id() == 0 ? first : y;
+}
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) {
+    uint32_t w;
+    __builtin_memcpy(&w, p, 4);     // gfx950: one global_load_dword, any byte alignment
+    return w;
+}
+
+// Number of terminator bytes (bit7 clear) among the low `nb` bytes of w.
+__device__ __forceinline__ uint32_t count_terminators(uint32_t w, uint32_t nb) {
+    uint32_t valid = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1u);
+    uint32_t term = ~w & 0x80808080u & valid;
+    return (uint32_t)__popc(term);
+}
+
+// Decode one DV1 block with one wave.  emit(idx_in_block, doc_id) is called once per
+// posting, by the lane that owns the posting's terminator byte (lane 0 also owns posting 0).
+// Returns the number of postings in the block (wave-uniform).  All 64 lanes must call.
+template <class Emit>
+__device__ __forceinline__ uint32_t decode_block_wave(const uint8_t *__restrict__ payload, uint32_t q0,
+                                                      uint32_t q1, uint32_t first_doc, Emit emit) {
+    const int l = lane_id();
+    if (l == 0) emit(0u, first_doc);
+    uint32_t carry_id = first_doc;   // running id after the last byte of the previous chunk
+    uint32_t carry_cnt = 1;          // postings emitted so far
+    uint32_t carry_run = 0;          // continuation bytes pending at the chunk boundary
+    for (uint32_t q = q0; q < q1; q += 256) {
+        const uint32_t myq = q + 4u * (uint32_t)l;
+        uint32_t nb = myq < q1 ? (q1 - myq < 4u ? q1 - myq : 4u) : 0u;
+        uint32_t w = nb ? load_u32_unaligned(payload + myq) : 0u;
+        if (nb < 4) w &= nb ? ((1u << (8 * nb)) - 1u) : 0u;
+        const uint32_t cont = w & 0x80808080u;
+        const bool plain = (__ballot(cont != 0) == 0ull) && carry_run == 0;   // wave-uniform
+        uint32_t c0, c1, c2, c3;         // per-byte contributions
+        uint32_t t0, t1, t2, t3;         // per-byte terminator flags (valid bytes only)
+        if (plain) {
+            c0 = w & 0xFFu; c1 = (w >> 8) & 0xFFu; c2 = (w >> 16) & 0xFFu; c3 = w >> 24;
+            t0 = nb > 0; t1 = nb > 1; t2 = nb > 2; t3 = nb > 3;
+        } else {
+            const uint32_t k0b = cont & 0x80u, k1b = cont & 0x8000u, k2b = cont & 0x800000u, k3b = cont & 0x80000000u;
+            // trailing continuation run of this lane's valid bytes
+            uint32_t trail = 0;
+            if (nb == 4) trail = k3b ? (k2b ? (k1b ? (k0b ? 4u : 3u) : 2u) : 1u) : 0u;
+            else if (nb == 3) trail = k2b ? (k1b ? (k0b ? 3u : 2u) : 1u) : 0u;
+            else if (nb == 2) trail = k1b ? (k0b ? 2u : 1u) : 0u;
+            else if (nb == 1) trail = k0b ? 1u : 0u;
+            // run pending before byte 0 of this lane: lane-1's trail; a lane of four
+            // continuation bytes extends the run of the lane before it (varints are <= 5 bytes)
+            uint32_t prev = wave_shift_up1(trail, carry_run);
+            uint32_t prev2 = wave_shift_up1(prev, 0u);
+            uint32_t prev_nb4 = wave_shift_up1(trail == 4u ? 1u : 0u, 0u);
+            uint32_t r0 = prev + (prev_nb4 ? prev2 : 0u);
+            if (r0 > 4u) r0 = 4u;                 // garbage guard: keeps the shift < 32
+            uint32_t r1 = k0b ? r0 + 1u : 0u;
+            uint32_t r2 = k1b ? r1 + 1u : 0u;
+            uint32_t r3 = k2b ? r2 + 1u : 0u;
+            if (r1 > 4u) r1 = 4u;
+            if (r2 > 4u) r2 = 4u;
+            if (r3 > 4u) r3 = 4u;
+            c0 = (w & 0x7Fu) << (7u * r0);
+            c1 = ((w >> 8) & 0x7Fu) << (7u * r1);
+            c2 = ((w >> 16) & 0x7Fu) << (7u * r2);
+            c3 = ((w >> 24) & 0x7Fu) << (7u * r3);
+            t0 = (nb > 0) && !k0b; t1 = (nb > 1) && !k1b; t2 = (nb > 2) && !k2b; t3 = (nb > 3) && !k3b;
+            carry_run = wave_bcast(trail == 4u ? (r0 + 4u > 4u ? 4u : r0 + 4u) : trail, 63);
+        }
+        const uint32_t s = c0 + c1 + c2 + c3;
+        const uint32_t tc = t0 + t1 + t2 + t3;
+        const uint32_t si = wave_incl_scan(s);
+        const uint32_t ti = wave_incl_scan(tc);
+        uint32_t id = carry_id + (si - s);
+        uint32_t ix = carry_cnt + (ti - tc);
+        id += c0; if (t0) { emit(ix, id); ix++; }
+        id += c1; if (t1) { emit(ix, id); ix++; }
+        id += c2; if (t2) { emit(ix, id); ix++; }
+        id += c3; if (t3) { emit(ix, id); ix++; }
+        carry_id += wave_bcast(si, 63);
+        carry_cnt += wave_bcast(ti, 63);
+    }
+    return carry_cnt;
+}
+
+// Posting count of a block without decoding ids (1 + terminators).  Wave-uniform result.
+__device__ __forceinline__ uint32_t count_block_wave(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1) {
+    const int l = lane_id();
+    uint32_t n = 0;
+    for (uint32_t q = q0; q < q1; q += 256) {
+        const uint32_t myq = q + 4u * (uint32_t)l;
+        uint32_t nb = myq < q1 ? (q1 - myq < 4u ? q1 - myq : 4u) : 0u;
+        uint32_t w = nb ? load_u32_unaligned(payload + myq) : 0xFFFFFFFFu;
+        n += count_terminators(w, nb);
+    }
+    return 1u + wave_sum(n);
+}
+
+// first index i in [lo, hi) with skip[i].first_doc > x   (upper bound on first_doc)
+__device__ __forceinline__ uint32_t skip_upper_bound(const ii2_skip *__restrict__ skip, uint32_t lo, uint32_t hi, uint32_t x) {
+    while (lo < hi) {
+        uint32_t mid = lo + ((hi - lo) >> 1);
+        if (skip[mid].first_doc <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ unsigned varint_len(uint32_t v) {
+    return v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u;
+}
+
+}  // namespace ii2

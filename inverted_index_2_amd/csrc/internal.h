@@ -1,0 +1,150 @@
+// internal.h — host-side structures and kernel launcher prototypes of libii2_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ii2.h"
+
+struct ii2_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    // grow-only device scratch, carved per call (no hipMalloc on the steady-state path)
+    uint8_t *ws = nullptr;
+    size_t ws_cap = 0;
+    size_t ws_used = 0;
+    // small pinned host mailbox for counts read back after a call
+    uint64_t *h_mail = nullptr;
+    uint64_t *d_mail = nullptr;
+    uint32_t epoch = 0;   // look-back descriptor generation
+    unsigned long long *desc = nullptr;   // look-back descriptors (only ever hold descriptors)
+    size_t desc_cap = 0;
+    uint32_t *d_ticket = nullptr;         // monotonically increasing tile ticket
+    uint32_t ticket_val = 0;              // host mirror of *d_ticket after the enqueued launches
+    // options
+    int64_t opt_intersect_lookback = 1;
+    int64_t opt_intersect_g = 0;        // 0 = auto
+    int64_t opt_merge_cap = 0;          // 0 = default
+    int64_t opt_merge_lookback = 1;
+    void *comm = nullptr;               // ncclComm_t
+    int world = 1, rank = 0;
+    int cu_count = 256;
+};
+
+struct ii2_seg {
+    ii2_ctx *ctx = nullptr;
+    uint64_t n_lists = 0, n_postings = 0, n_blocks = 0, n_bytes = 0;
+    uint32_t *d_blk_off = nullptr;   // [n_lists+1]
+    ii2_skip *d_skip = nullptr;      // [n_blocks+1]
+    uint8_t *d_payload = nullptr;    // [n_bytes + 16]
+    std::vector<uint32_t> h_blk_off; // host mirror when n_lists is small (<= 4096), else empty
+};
+
+struct ii2_tomb {
+    ii2_ctx *ctx = nullptr;
+    uint32_t *d_words = nullptr;
+    uint64_t n_words = 0;   // bitmap covers doc ids [0, 32*n_words)
+};
+
+void ii2_comm_destroy_internal(ii2_ctx *ctx);
+int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values,
+                                uint64_t n_postings, ii2_seg **out);
+int ii2_seg_decode_dev_unlocked(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *d_post_off, uint32_t *d_values);
+
+namespace ii2 {
+
+// One posting list as the kernels see it: `skip` points at the list's first block entry;
+// skip[nblk] is readable (next list's first block or the sentinel) and bounds the payload.
+struct ListView {
+    const ii2_skip *skip;
+    const uint8_t *payload;
+    uint32_t nblk;
+    uint32_t pad;
+};
+
+struct SegView {
+    const uint32_t *blk_off;
+    const ii2_skip *skip;
+    const uint8_t *payload;
+};
+
+constexpr uint32_t MAX_LISTS = II2_MAX_LISTS;
+
+struct IntersectParams {
+    ListView lists[MAX_LISTS];   // lists[0] is the driver (fewest blocks)
+    uint32_t n_lists;
+    uint32_t G;                  // driver blocks per tile
+    uint32_t n_tiles;
+    uint32_t tomb_nwords;
+    const uint32_t *tomb;        // may be null
+    uint32_t *ranges;            // [n_tiles][n_lists][2]  block range per (tile, list)
+    uint32_t *out;               // final ids
+    uint64_t out_cap;
+    uint32_t *tmp;               // non-lookback: per-tile slots of G*256
+    uint32_t *tile_count;        // non-lookback
+    unsigned long long *desc;    // lookback descriptors [n_tiles]
+    uint32_t *ticket;            // lookback dynamic tile id
+    uint64_t *d_count;           // result count
+    uint32_t epoch;
+    uint32_t lookback;
+    uint32_t ticket_base;        // value of *ticket before this launch
+    uint32_t pad2;
+};
+
+constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
+hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s);
+
+// scans (hipcub) — temp storage comes from the caller
+size_t scan_temp_bytes(size_t n);
+hipError_t scan_excl_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
+hipError_t scan_excl_u32_to_u64(void *tmp, size_t tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t s);
+hipError_t scan_excl_u64(void *tmp, size_t tmp_bytes, const uint64_t *in, uint64_t *out, size_t n, hipStream_t s);
+
+// codec
+hipError_t launch_enc_list_blocks(const uint64_t *post_off, uint64_t n_lists, uint32_t *nblk, hipStream_t s);
+hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
+                                  const uint32_t *values, uint64_t n_blocks, uint32_t *sizes, ii2_skip *skip, hipStream_t s);
+hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
+                            const uint32_t *values, uint64_t n_blocks, const uint64_t *byte_off64,
+                            ii2_skip *skip, uint8_t *payload, uint64_t n_postings, hipStream_t s);
+hipError_t launch_dec_block_counts(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, uint32_t *counts, hipStream_t s);
+hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, const uint64_t *bpo,
+                            uint32_t *values, hipStream_t s);
+hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, uint64_t n_lists, uint64_t *post_off, hipStream_t s);
+hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, hipStream_t s);
+hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
+
+// intersect
+constexpr uint32_t ISECT_GMAX = 8;          // driver blocks per tile (max)
+constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
+hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s);
+
+// merge / union
+struct MergeParams {
+    SegView segs[MAX_LISTS];
+    uint32_t k;
+    uint32_t pad;
+    uint64_t n_terms;
+    const uint32_t *tomb;
+    uint32_t tomb_nwords;
+    uint32_t cap;                 // postings per tile (LDS capacity)
+    // plan
+    const uint32_t *term_tile;    // [n_terms+1] first tile of each term (monotone)
+    const uint32_t *term_ub;      // [n_terms]   upper bound of the term's input postings
+    const uint32_t *large_split;  // [n_tiles]   doc-range splitters of large-term tiles (lo of tile), 0 for small
+    uint32_t n_tiles;
+    uint32_t small_max;
+    // outputs
+    uint32_t *out_counts;         // [n_terms] survivors per term
+    uint32_t *tile_count;         // [n_tiles]
+    uint32_t *tmp;                // parked survivors, tile t at tmp_off[t]
+    const uint64_t *tile_tmp_off; // [n_tiles+1]
+};
+hipError_t launch_merge_plan_ub(const MergeParams &p, uint32_t *term_ub, hipStream_t s);
+
+}  // namespace ii2

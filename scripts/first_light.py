@@ -1,0 +1,32 @@
+"""Quick GPU probe: self-test, C2 intersect timing at full size (HIP events via torch-free path)."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from inverted_index_2_amd import Context, synth
+from oracle import oracle as orc
+
+D = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
+ctx = Context(0)
+ctx.selftest(); print("selftest ok", flush=True)
+t = time.time(); a, b = synth.zipf_list(2, D), synth.zipf_list(3, D); print("gen", a.size, b.size, time.time() - t, flush=True)
+t = time.time(); seg = ctx.encode_lists([a, b]); print("encode", time.time() - t, seg.info.n_bytes, seg.info.n_blocks, flush=True)
+t = time.time(); want = orc.intersect([a, b]); cpu_s = time.time() - t; print("oracle", want.size, cpu_s, flush=True)
+out = ctx.empty(min(a.size, b.size) + 512)
+dcnt = ctx.empty(8, np.uint64)
+for lb in (1, 0):
+    ctx.set_option("intersect.lookback", lb)
+    o, n = ctx.intersect([(seg, 0), (seg, 1)], out=out)
+    got = out.download(n)
+    print("lookback", lb, "count", n, "match", n == want.size and np.array_equal(got, want), flush=True)
+    for g in (0, 2, 4, 8):
+        ctx.set_option("intersect.g", g)
+        ctx.intersect_async([(seg, 0), (seg, 1)], None, out, dcnt); ctx.sync()
+        t = time.time()
+        K = 20
+        for _ in range(K):
+            ctx.intersect_async([(seg, 0), (seg, 1)], None, out, dcnt)
+        ctx.sync()
+        dt = (time.time() - t) / K
+        alg = seg.info.n_bytes + 8 * seg.info.n_blocks + 4 * n
+        print(f"  g={g} {dt*1e6:.1f} us/step  {(a.size+b.size)/dt/1e9:.1f} Gpostings/s  alg {alg/dt/1e12:.3f} TB/s", flush=True)
+    ctx.set_option("intersect.g", 0)

@@ -1,0 +1,86 @@
+"""GPU: DV1 encode / decode kernels against the oracle codec (byte-exact) — through the C ABI."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.gpu_util import ctx, sorted_unique  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_selftest(ctx):
+    ctx.selftest()
+
+
+def _lists(rng):
+    lens = [0, 1, 2, 3, 255, 256, 257, 511, 512, 513, 1000, 0, 5, 70000]
+    gaps_hi = [2, 100, 20000, 3_000_000]
+    out = []
+    for i, n in enumerate(lens):
+        g = rng.integers(1, gaps_hi[i % 4] + 1, n, dtype=np.int64)
+        ids = np.cumsum(g)
+        ids = ids[ids < (1 << 32)]
+        out.append(ids.astype(np.uint32))
+    out.append(np.asarray([0, 0xFFFFFFFF], np.uint32))
+    out.append(np.asarray([0xFFFFFFFF], np.uint32))
+    return out
+
+
+def test_encode_matches_oracle_bytes_and_roundtrips(ctx):
+    rng = np.random.default_rng(11)
+    lists = _lists(rng)
+    po = np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.uint64)
+    flat = np.concatenate(lists)
+    seg = ctx.encode(po, flat)
+    blk, skip, payload = seg.export()
+    oblk, oskip, opayload = orc.dv1_encode(po, flat)
+    assert np.array_equal(blk, oblk)
+    assert np.array_equal(skip["first_doc"][:-1], oskip["first_doc"][:-1])
+    assert np.array_equal(skip["byte_off"], oskip["byte_off"])
+    assert np.array_equal(payload, opayload)
+    po2, vals = seg.decode()
+    assert np.array_equal(po2, po) and np.array_equal(vals, flat)
+
+
+def test_import_oracle_encoded_and_decode(ctx):
+    rng = np.random.default_rng(12)
+    lists = _lists(rng)
+    po = np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.uint64)
+    flat = np.concatenate(lists)
+    oblk, oskip, opayload = orc.dv1_encode(po, flat)
+    seg = ctx.import_dv1(flat.size, oblk, oskip, opayload)
+    po2, vals = seg.decode()
+    assert np.array_equal(po2, po) and np.array_equal(vals, flat)
+
+
+def test_codec_kats_verbatim(ctx, kats):
+    # file/writer_test.go:11-46 — unsorted {10,500,300}, empty, {66,5513} survive write->read verbatim
+    for name, rows in kats["codec"].items():
+        lists = [np.asarray(v, np.uint32) for _, v in rows]
+        seg = ctx.encode_lists(lists)
+        po, vals = seg.decode()
+        for i, l in enumerate(lists):
+            assert np.array_equal(vals[int(po[i]):int(po[i + 1])], l), (name, i)
+
+
+def test_many_tiny_lists(ctx):
+    rng = np.random.default_rng(13)
+    lens = rng.integers(0, 9, 20000)
+    lists = [sorted_unique(rng, int(n), 1 << 20) for n in lens]
+    po = np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.uint64)
+    flat = np.concatenate(lists)
+    seg = ctx.encode(po, flat)
+    po2, vals = seg.decode()
+    assert np.array_equal(po2, po) and np.array_equal(vals, flat)
+    oblk, oskip, opayload = orc.dv1_encode(po, flat)
+    blk, skip, payload = seg.export()
+    assert np.array_equal(blk, oblk) and np.array_equal(payload, opayload)
+
+
+def test_tombstone_bitmap_filters_like_binary_search(ctx):
+    rng = np.random.default_rng(14)
+    a = sorted_unique(rng, 5000, 100000)
+    removed = rng.integers(0, 100000, 3000).astype(np.uint32)     # unsorted, with duplicates
+    seg = ctx.encode_lists([a])
+    out, n = ctx.intersect([(seg, 0)], tomb=ctx.tombstones(removed))
+    assert np.array_equal(out.download(n), orc.filter_removed(a, np.sort(removed)))

@@ -1,0 +1,113 @@
+"""GPU: intersection kernels against the oracle (bit-exact id sequences) — through the C ABI."""
+import numpy as np
+import pytest
+
+from inverted_index_2_amd import synth
+from oracle import oracle as orc
+from tests.gpu_util import ctx, sorted_unique  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, lists, removed=None):
+    seg = ctx.encode_lists(lists)
+    tomb = ctx.tombstones(removed) if removed is not None else None
+    want = orc.intersect(lists, np.sort(removed) if removed is not None else ())
+    for lookback in (1, 0):
+        ctx.set_option("intersect.lookback", lookback)
+        out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
+        got = out.download(n)
+        assert n == want.size, (lookback, n, want.size)
+        assert np.array_equal(got, want), lookback
+    ctx.set_option("intersect.lookback", 1)
+    # split over two segments as well (lists from different segments)
+    if len(lists) >= 2:
+        s0, s1 = ctx.encode_lists(lists[:1]), ctx.encode_lists(lists[1:])
+        out, n = ctx.intersect([(s0, 0)] + [(s1, i) for i in range(len(lists) - 1)], tomb=tomb)
+        assert np.array_equal(out.download(n), want)
+
+
+def test_edge_cases(ctx):
+    e = np.empty(0, np.uint32)
+    _check(ctx, [e, e])
+    _check(ctx, [np.asarray([5], np.uint32), e])
+    _check(ctx, [np.asarray([5], np.uint32), np.asarray([5], np.uint32)])
+    _check(ctx, [np.asarray([5], np.uint32), np.asarray([6], np.uint32)])
+    _check(ctx, [np.asarray([0, 0xFFFFFFFF], np.uint32), np.asarray([0xFFFFFFFF], np.uint32)])
+    _check(ctx, [np.asarray([0, 0xFFFFFFFF], np.uint32), np.asarray([0, 7, 0xFFFFFFFF], np.uint32)])
+    a = np.arange(0, 3000, 2, dtype=np.uint32)
+    b = np.arange(1, 3000, 2, dtype=np.uint32)
+    _check(ctx, [a, b])                       # disjoint, interleaved
+    _check(ctx, [a, a])                       # identical
+    _check(ctx, [a, a[::7].copy()])           # subset
+    _check(ctx, [a, (a + 100000).astype(np.uint32)])   # disjoint ranges
+
+
+@pytest.mark.parametrize("n", [255, 256, 257, 511, 512, 513, 2047, 2048, 2049, 4097])
+def test_block_boundary_lengths(ctx, n):
+    rng = np.random.default_rng(n)
+    a = sorted_unique(rng, n, 4 * n + 10)
+    b = sorted_unique(rng, n + 3, 4 * n + 10)
+    _check(ctx, [a, b])
+    _check(ctx, [a, b], removed=rng.integers(0, 4 * n + 10, n // 3 + 1).astype(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_dense(ctx, seed):
+    rng = np.random.default_rng(100 + seed)
+    U = int(rng.integers(10_000, 400_000))
+    k = int(rng.integers(2, 6))
+    lists = [sorted_unique(rng, int(rng.integers(U // 8, U // 2)), U) for _ in range(k)]
+    _check(ctx, lists)
+    _check(ctx, lists, removed=rng.integers(0, U, U // 50).astype(np.uint32))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_sparse_and_skewed(ctx, seed):
+    # sparse lists (gaps >> 64) leave the byte-map path; skew forces galloping over skip tables
+    rng = np.random.default_rng(200 + seed)
+    U = 1 << 31
+    core = sorted_unique(rng, 300, U)
+    sizes = [500, 5_000, 60_000, 400_000][: 2 + seed % 3]
+    lists = [np.union1d(sorted_unique(rng, s, U), core).astype(np.uint32) for s in sizes]
+    _check(ctx, lists)
+    _check(ctx, lists[::-1], removed=core[::3].copy())
+
+
+def test_dense_vs_sparse_mix(ctx):
+    rng = np.random.default_rng(7)
+    dense = sorted_unique(rng, 900_000, 2_000_000)
+    sparse = sorted_unique(rng, 700, 2_000_000)
+    mid = sorted_unique(rng, 40_000, 2_000_000)
+    _check(ctx, [dense, sparse])
+    _check(ctx, [dense, mid, sparse])
+    _check(ctx, [mid, dense])
+
+
+def test_eight_terms_zipf(ctx):
+    # BASELINE config 5 in miniature: ranks {2,4,...,16384}, common core forced into every list
+    D = 20_000_000
+    rng = np.random.default_rng(8)
+    core = sorted_unique(rng, 2000, D)
+    lists = [np.union1d(synth.zipf_list(r, D), core).astype(np.uint32) for r in (2, 4, 16, 64, 256, 1024, 4096, 16384)]
+    _check(ctx, lists)
+
+
+def test_forced_tile_heights(ctx):
+    rng = np.random.default_rng(9)
+    a = sorted_unique(rng, 50_000, 160_000)
+    b = sorted_unique(rng, 70_000, 160_000)
+    seg = ctx.encode_lists([a, b])
+    want = orc.intersect([a, b])
+    for g in (1, 2, 3, 8):
+        ctx.set_option("intersect.g", g)
+        out, n = ctx.intersect([(seg, 0), (seg, 1)])
+        assert np.array_equal(out.download(n), want), g
+    ctx.set_option("intersect.g", 0)
+
+
+def test_config2_scaled_properties(ctx):
+    # BASELINE config 2 at 1/10 scale vs the oracle, full scale is covered by bench.py's checksum
+    D = 10_000_000
+    a, b = synth.zipf_list(2, D), synth.zipf_list(3, D)
+    _check(ctx, [a, b])
