@@ -177,6 +177,9 @@ int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local,
 int ii2_selftest(ii2_ctx *ctx);
 /* Tuning knobs, by name ("intersect.lookback", "merge.cap", …); unknown names are II2_EINVAL. */
 int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);
+/* With option "debug.stamps"=1 the intersect kernel sums, per workgroup, the shader cycles spent
+ * in each part of its tile loop; this copies those counters (8 words per workgroup) out. */
+int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "ii2_allgatherv": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
     "ii2_selftest": (C.c_int, [vp]),
     "ii2_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "ii2_debug_read": (C.c_int, [vp, u64p, C.c_uint64]),
 }
 
 _lib = None

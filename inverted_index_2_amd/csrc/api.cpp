@@ -38,7 +38,7 @@ struct DevBuf {
 static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // Workspace: reserve the total up front, then carve.
-static int ws_reserve(ii2_ctx *ctx, size_t bytes) {
+int ii2_ws_reserve(ii2_ctx *ctx, size_t bytes) {
     ctx->ws_used = 0;
     if (bytes <= ctx->ws_cap) return II2_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -57,7 +57,7 @@ template <class T> static T *ws_take(ii2_ctx *ctx, size_t count) {
     return p;
 }
 
-static int desc_reserve(ii2_ctx *ctx, size_t n) {
+int ii2_desc_reserve(ii2_ctx *ctx, size_t n) {
     if (n <= ctx->desc_cap) return II2_OK;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->desc) (void)hipFree(ctx->desc);
@@ -70,7 +70,7 @@ static int desc_reserve(ii2_ctx *ctx, size_t n) {
     ctx->desc_cap = want;
     return II2_OK;
 }
-static uint32_t next_epoch(ii2_ctx *ctx) {
+uint32_t ii2_next_epoch(ii2_ctx *ctx) {
     ctx->epoch = (ctx->epoch + 1) & 0x3FFFFFu;
     if (ctx->epoch == 0) {     // wrapped: forget every old descriptor
         (void)hipMemsetAsync(ctx->desc, 0, ctx->desc_cap * sizeof(unsigned long long), ctx->stream);
@@ -106,9 +106,7 @@ int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
     ctx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_mail, 64 * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_mail, 64 * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_ticket, 64) != hipSuccess ||
-        hipMemset(ctx->d_ticket, 0, 64) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_mail, 64 * sizeof(uint64_t)) != hipSuccess) {
         g_create_err = "context resource allocation failed";
         ii2_ctx_destroy(ctx);
         return II2_EHIP;
@@ -124,7 +122,8 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     ii2_comm_destroy_internal(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->desc) (void)hipFree(ctx->desc);
-    if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
+    if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -179,11 +178,15 @@ static void seg_release(ii2_seg *s) {
     if (s->d_blk_off) (void)hipFree(s->d_blk_off);
     if (s->d_skip) (void)hipFree(s->d_skip);
     if (s->d_payload) (void)hipFree(s->d_payload);
+    if (s->d_last_doc) (void)hipFree(s->d_last_doc);
     delete s;
 }
 
 // reads back the driver-choice statistics of single-list segments and the host blk_off mirror
 static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
+    if (hipMalloc((void **)&seg->d_last_doc, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_last_doc, ctx->stream));
     seg->h_blk_off.resize(seg->n_lists + 1);
     HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -425,6 +428,7 @@ static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListVi
     const uint32_t b0 = seg->h_blk_off[idx], b1 = seg->h_blk_off[idx + 1];
     v->skip = seg->d_skip + b0;
     v->payload = seg->d_payload;
+    v->last_doc = seg->d_last_doc + idx;
     v->nblk = b1 - b0;
     v->pad = 0;
     return II2_OK;
@@ -456,11 +460,24 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     uint32_t G = 1;
     if (ctx->opt_intersect_g > 0) G = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, ISECT_GMAX);
     else if (nblk0 > 1) {
-        ii2_skip ends[2];
-        HIP_TRY(ctx, hipMemcpyAsync(&ends[0], views[0].skip, sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(&ends[1], views[0].skip + (nblk0 - 1), sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        const double per_block = (double)(ends[1].first_doc - ends[0].first_doc) / (double)(nblk0 - 1);
+        const ii2_seg *dseg = nullptr;
+        uint64_t didx = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint64_t li = list_idx ? list_idx[i] : 0;
+            if (segs[i]->d_skip + segs[i]->h_blk_off[li] == views[0].skip) { dseg = segs[i]; didx = li; break; }
+        }
+        std::pair<uint32_t, uint32_t> ends;
+        auto hit = dseg->span_cache.find(didx);
+        if (hit != dseg->span_cache.end()) ends = hit->second;
+        else {
+            ii2_skip e[2];
+            HIP_TRY(ctx, hipMemcpyAsync(&e[0], views[0].skip, sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(&e[1], views[0].skip + (nblk0 - 1), sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+            ends = {e[0].first_doc, e[1].first_doc};
+            dseg->span_cache[didx] = ends;
+        }
+        const double per_block = (double)(ends.second - ends.first) / (double)(nblk0 - 1);
         const double g = per_block > 0 ? 0.85 * ISECT_SMAX / per_block : ISECT_GMAX;
         G = g >= ISECT_GMAX ? ISECT_GMAX : g < 1 ? 1u : (uint32_t)g;
         while (G > 1 && nblk0 / G < 8u * (uint32_t)ctx->cu_count) G >>= 1;
@@ -468,22 +485,21 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.G = G;
     p.n_tiles = (nblk0 + G - 1) / G;
     p.lookback = ctx->opt_intersect_lookback ? 1u : 0u;
-    size_t need = align_up((size_t)p.n_tiles * 2 * n * sizeof(uint32_t)) + 4096;
+    const size_t dstride = 2 + 4 * (size_t)n;
+    size_t need = align_up((size_t)p.n_tiles * dstride * sizeof(uint32_t)) + 4096;
     if (!p.lookback)
         need += align_up((size_t)p.n_tiles * G * 256 * sizeof(uint32_t)) + align_up((p.n_tiles + 1) * sizeof(uint32_t)) +
                 align_up((p.n_tiles + 1) * sizeof(uint64_t));
-    int rc = ws_reserve(ctx, need);
+    int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
-    p.ranges = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * 2 * n);
+    p.ranges = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * dstride);
+    p.max_grid = (uint32_t)ctx->cu_count * 4u;     // 4 x 37 KB of LDS per CU: all co-resident
     uint64_t *d_tile_off = nullptr;
     if (p.lookback) {
-        rc = desc_reserve(ctx, p.n_tiles);
+        rc = ii2_desc_reserve(ctx, p.n_tiles);
         if (rc) return rc;
         p.desc = ctx->desc;
-        p.epoch = next_epoch(ctx);
-        p.ticket = ctx->d_ticket;
-        p.ticket_base = ctx->ticket_val;
-        ctx->ticket_val += p.n_tiles;
+        p.epoch = ii2_next_epoch(ctx);
     } else {
         p.tmp = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * G * 256);
         p.tile_count = ws_take<uint32_t>(ctx, p.n_tiles + 1);
@@ -494,6 +510,12 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.out = d_out;
     p.out_cap = cap;
     p.d_count = d_count;
+    p.debug = nullptr;
+    if (ctx->opt_debug_stamps) {
+        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)ctx->cu_count * 4 * 8 * sizeof(unsigned long long)) != hipSuccess)
+            return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
+        p.debug = ctx->d_debug;
+    }
     HIP_TRY(ctx, launch_intersect(p, d_tile_off, st));
     return II2_OK;
 }
@@ -526,7 +548,7 @@ int ii2_selftest(ii2_ctx *ctx) {
     if (!ctx) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ws_reserve(ctx, SELFTEST_SCRATCH + 4096);
+    int rc = ii2_ws_reserve(ctx, SELFTEST_SCRATCH + 4096);
     if (rc) return rc;
     uint8_t *scratch = ws_take<uint8_t>(ctx, SELFTEST_SCRATCH);
     uint32_t *d_fail = (uint32_t *)ctx->d_mail;
@@ -544,14 +566,24 @@ int ii2_selftest(ii2_ctx *ctx) {
     return II2_OK;
 }
 
+int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words) {
+    if (!ctx || !out || !ctx->d_debug) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    const uint64_t have = (uint64_t)ctx->cu_count * 4 * 8;
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_debug, std::min(n_words, have) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return II2_OK;
+}
+
 int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     const std::string k(name);
     if (k == "intersect.lookback") ctx->opt_intersect_lookback = value;
     else if (k == "intersect.g") ctx->opt_intersect_g = value;
-    else if (k == "merge.cap") ctx->opt_merge_cap = value;
+    else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "merge.lookback") ctx->opt_merge_lookback = value;
+    else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

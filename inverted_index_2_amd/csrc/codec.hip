@@ -150,6 +150,34 @@ hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, 
     return hipGetLastError();
 }
 
+// last doc id of every list: one wave decodes the list's last block
+__global__ __launch_bounds__(256) void k_list_last_doc(const uint32_t *__restrict__ blk_off, const ii2_skip *__restrict__ skip,
+                                                       const uint8_t *__restrict__ payload, uint64_t n_lists,
+                                                       uint32_t *__restrict__ last_doc) {
+    const uint64_t li = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (li >= n_lists) return;
+    const uint32_t b0 = blk_off[li], b1 = blk_off[li + 1];
+    if (b1 == b0) { if (lane_id() == 0) last_doc[li] = 0; return; }
+    const uint32_t b = b1 - 1u;
+    uint32_t mx_ix = 0, mx_id = skip[b].first_doc;
+    decode_block_wave(payload, skip[b].byte_off, skip[b + 1].byte_off, skip[b].first_doc,
+                      [&](uint32_t ix, uint32_t id) { if (ix >= mx_ix) { mx_ix = ix; mx_id = id; } });
+    // the lane holding the highest posting index has the last id
+    uint32_t best_ix = mx_ix, best_id = mx_id;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t oi = (uint32_t)__shfl_xor((int)best_ix, d, 64), od = (uint32_t)__shfl_xor((int)best_id, d, 64);
+        if (oi > best_ix) { best_ix = oi; best_id = od; }
+    }
+    if (lane_id() == 0) last_doc[li] = best_id;
+}
+
+hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists,
+                                uint32_t *last_doc, hipStream_t s) {
+    if (n_lists == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_list_last_doc, dim3((unsigned)((n_lists + 3) / 4)), dim3(256), 0, s, blk_off, skip, payload, n_lists, last_doc);
+    return hipGetLastError();
+}
+
 // ---- tombstones -----------------------------------------------------------------------
 // RemovedLists.Values() (removed_list.go:44-54) as a dense bitmap: bit v set <=> v removed.
 __global__ void k_tomb_build(const uint32_t *__restrict__ removed, uint64_t n, uint32_t *__restrict__ words, uint64_t n_words) {

@@ -73,12 +73,27 @@ __device__ __forceinline__ uint32_t count_terminators(uint32_t w, uint32_t nb) {
     return (uint32_t)__popc(term);
 }
 
+// Byte sources for the block decoder: 4 payload bytes at byte offset q (any alignment).
+struct GlobalBytes {
+    const uint8_t *__restrict__ p;
+    __device__ __forceinline__ uint32_t operator()(uint32_t q) const { return load_u32_unaligned(p + q); }
+};
+// LDS-staged payload: two aligned dword reads + v_alignbyte (LDS reads must be dword aligned)
+struct LdsBytes {
+    const uint8_t *p;    // LDS, 4-byte aligned base
+    __device__ __forceinline__ uint32_t operator()(uint32_t q) const {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p + (q & ~3u));
+        const uint32_t lo = w[0], hi = w[1];
+        return __builtin_amdgcn_alignbyte(hi, lo, q & 3u);
+    }
+};
+
 // Decode one DV1 block with one wave.  emit(idx_in_block, doc_id) is called once per
 // posting, by the lane that owns the posting's terminator byte (lane 0 also owns posting 0).
-// Returns the number of postings in the block (wave-uniform).  All 64 lanes must call.
-template <class Emit>
-__device__ __forceinline__ uint32_t decode_block_wave(const uint8_t *__restrict__ payload, uint32_t q0,
-                                                      uint32_t q1, uint32_t first_doc, Emit emit) {
+// Returns the number of postings in the block (wave-uniform).  All 64 lanes must call with
+// wave-uniform q0, q1, first_doc.
+template <class Load, class Emit>
+__device__ __forceinline__ uint32_t decode_block_wave(Load load, uint32_t q0, uint32_t q1, uint32_t first_doc, Emit emit) {
     const int l = lane_id();
     if (l == 0) emit(0u, first_doc);
     uint32_t carry_id = first_doc;   // running id after the last byte of the previous chunk
@@ -87,7 +102,7 @@ __device__ __forceinline__ uint32_t decode_block_wave(const uint8_t *__restrict_
     for (uint32_t q = q0; q < q1; q += 256) {
         const uint32_t myq = q + 4u * (uint32_t)l;
         uint32_t nb = myq < q1 ? (q1 - myq < 4u ? q1 - myq : 4u) : 0u;
-        uint32_t w = nb ? load_u32_unaligned(payload + myq) : 0u;
+        uint32_t w = nb ? load(myq) : 0u;
         if (nb < 4) w &= nb ? ((1u << (8 * nb)) - 1u) : 0u;
         const uint32_t cont = w & 0x80808080u;
         const bool plain = (__ballot(cont != 0) == 0ull) && carry_run == 0;   // wave-uniform
@@ -138,6 +153,12 @@ __device__ __forceinline__ uint32_t decode_block_wave(const uint8_t *__restrict_
         carry_cnt += wave_bcast(ti, 63);
     }
     return carry_cnt;
+}
+
+template <class Emit>
+__device__ __forceinline__ uint32_t decode_block_wave(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1,
+                                                      uint32_t first_doc, Emit emit) {
+    return decode_block_wave(GlobalBytes{payload}, q0, q1, first_doc, emit);
 }
 
 // Posting count of a block without decoding ids (1 + terminators).  Wave-uniform result.

@@ -5,6 +5,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ii2.h"
@@ -24,13 +25,15 @@ struct ii2_ctx {
     uint32_t epoch = 0;   // look-back descriptor generation
     unsigned long long *desc = nullptr;   // look-back descriptors (only ever hold descriptors)
     size_t desc_cap = 0;
-    uint32_t *d_ticket = nullptr;         // monotonically increasing tile ticket
-    uint32_t ticket_val = 0;              // host mirror of *d_ticket after the enqueued launches
     // options
     int64_t opt_intersect_lookback = 1;
     int64_t opt_intersect_g = 0;        // 0 = auto
-    int64_t opt_merge_cap = 0;          // 0 = default
+    int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
     int64_t opt_merge_lookback = 1;
+    uint8_t *aux = nullptr;             // grow-only: merge tile descriptors
+    size_t aux_cap = 0;
+    int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
+    unsigned long long *d_debug = nullptr;
     void *comm = nullptr;               // ncclComm_t
     int world = 1, rank = 0;
     int cu_count = 256;
@@ -42,7 +45,10 @@ struct ii2_seg {
     uint32_t *d_blk_off = nullptr;   // [n_lists+1]
     ii2_skip *d_skip = nullptr;      // [n_blocks+1]
     uint8_t *d_payload = nullptr;    // [n_bytes + 16]
-    std::vector<uint32_t> h_blk_off; // host mirror when n_lists is small (<= 4096), else empty
+    uint32_t *d_last_doc = nullptr;  // [n_lists] last doc id of each list (0 for an empty list)
+    std::vector<uint32_t> h_blk_off; // host mirror of d_blk_off
+    // per list: first_doc of its first and of its last block (tile-height heuristic), fetched once
+    mutable std::unordered_map<uint64_t, std::pair<uint32_t, uint32_t>> span_cache;
 };
 
 struct ii2_tomb {
@@ -63,6 +69,7 @@ namespace ii2 {
 struct ListView {
     const ii2_skip *skip;
     const uint8_t *payload;
+    const uint32_t *last_doc;    // the list's last doc id
     uint32_t nblk;
     uint32_t pad;
 };
@@ -71,6 +78,7 @@ struct SegView {
     const uint32_t *blk_off;
     const ii2_skip *skip;
     const uint8_t *payload;
+    const uint32_t *last_doc;   // [n_lists] last doc id of each list (same indexing as blk_off)
 };
 
 constexpr uint32_t MAX_LISTS = II2_MAX_LISTS;
@@ -82,17 +90,17 @@ struct IntersectParams {
     uint32_t n_tiles;
     uint32_t tomb_nwords;
     const uint32_t *tomb;        // may be null
-    uint32_t *ranges;            // [n_tiles][n_lists][2]  block range per (tile, list)
+    uint32_t *ranges;            // [n_tiles][2 + 4*n_lists] tile doc range + per-list phase descriptors
     uint32_t *out;               // final ids
     uint64_t out_cap;
     uint32_t *tmp;               // non-lookback: per-tile slots of G*256
     uint32_t *tile_count;        // non-lookback
     unsigned long long *desc;    // lookback descriptors [n_tiles]
-    uint32_t *ticket;            // lookback dynamic tile id
     uint64_t *d_count;           // result count
+    unsigned long long *debug;   // optional per-workgroup phase cycle counters [grid][8] (diagnostics)
     uint32_t epoch;
     uint32_t lookback;
-    uint32_t ticket_base;        // value of *ticket before this launch
+    uint32_t max_grid;           // persistent grid bound (<= co-resident workgroups)
     uint32_t pad2;
 };
 
@@ -117,6 +125,8 @@ hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64
                             uint32_t *values, hipStream_t s);
 hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, uint64_t n_lists, uint64_t *post_off, hipStream_t s);
 hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, hipStream_t s);
+hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists,
+                                uint32_t *last_doc, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
 
 // intersect
@@ -125,26 +135,34 @@ constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map ca
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s);
 
 // merge / union
+constexpr uint32_t MERGE_CAP = 4096;        // postings per tile (LDS)
+constexpr uint32_t MERGE_OFFMAX = 2176;     // (terms per batch + 1) * k  must fit
 struct MergeParams {
     SegView segs[MAX_LISTS];
     uint32_t k;
-    uint32_t pad;
+    uint32_t n_tiles;
     uint64_t n_terms;
     const uint32_t *tomb;
     uint32_t tomb_nwords;
-    uint32_t cap;                 // postings per tile (LDS capacity)
-    // plan
-    const uint32_t *term_tile;    // [n_terms+1] first tile of each term (monotone)
-    const uint32_t *term_ub;      // [n_terms]   upper bound of the term's input postings
-    const uint32_t *large_split;  // [n_tiles]   doc-range splitters of large-term tiles (lo of tile), 0 for small
-    uint32_t n_tiles;
-    uint32_t small_max;
-    // outputs
-    uint32_t *out_counts;         // [n_terms] survivors per term
-    uint32_t *tile_count;         // [n_tiles]
-    uint32_t *tmp;                // parked survivors, tile t at tmp_off[t]
-    const uint64_t *tile_tmp_off; // [n_tiles+1]
+    uint32_t small_max;           // terms with a larger upper bound get their own doc-range tiles
+    uint32_t large_tile;          // target upper bound per large-term tile
+    uint32_t wmin;                // minimum packing weight of a term (bounds terms per batch)
+    uint32_t batch_q;             // batch id = weight prefix / batch_q
+    uint32_t epoch;
+    uint32_t *out_counts;         // [n_terms] survivors per term (zeroed by the host)
+    uint32_t *out_values;
+    uint64_t out_cap;
+    uint64_t *d_total;            // total survivors
+    uint32_t *overflow;           // tiles that did not fit LDS (host re-plans)
+    unsigned long long *desc;     // look-back descriptors
+    unsigned long long *debug;    // optional diagnostics words
 };
-hipError_t launch_merge_plan_ub(const MergeParams &p, uint32_t *term_ub, hipStream_t s);
+hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s);
+hipError_t launch_merge_heads(const MergeParams &p, const uint32_t *ntl, const uint64_t *wpre, uint32_t *head, hipStream_t s);
+hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, const uint32_t *head, const uint32_t *hpre,
+                                  const uint32_t *lpre, uint32_t *term_tile, hipStream_t s);
+hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
+hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s);
+hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 
 }  // namespace ii2

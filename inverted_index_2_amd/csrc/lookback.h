@@ -6,8 +6,9 @@
 // else is handed over between workgroups — no release/acquire pairing is needed
 // (MI355X_MICROARCH.md "Valid forms": the 8-byte {data, tag} granule).
 // Descriptors of earlier launches carry another epoch and read as "not yet published".
-// Tiles take their index from an atomic ticket, so every predecessor of a running tile
-// has itself started: the spin below always terminates.
+// Forward progress is the caller's contract: every tile < t must be held by a workgroup
+// that is resident and working on it (the posting kernels run persistent grids no larger
+// than what is co-resident, walking tiles in ascending order), so the spin terminates.
 #pragma once
 #include "dv1_device.h"
 

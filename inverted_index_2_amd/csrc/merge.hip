@@ -1,1 +1,581 @@
+// merge.hip — segmented k-way union of DV1 posting lists with fused tombstone filter
+// (gfx950, wave64, no MFMA).  One kernel family serves
+//   * the segment merge: the body of Shard.Merge's loop (reference shard.go:163-212) and the
+//     k-way merging iterator it drains (shard.go:253-278) folding equal terms with
+//     file.MergeTermValues (file/types.go:14-22) — for every aligned term the sorted,
+//     duplicate-free union of the k segments' lists, minus the tombstones (shard.go:181-190),
+//     empty terms reported with count 0 (shard.go:192-194);
+//   * the multi-term union of PrefixSearch (inverted_index.go:274-292) — one "term", k lists.
+//
+// Work is cut into TILES that fit LDS (<= CAP postings):
+//   small terms are packed, in term order, into batches of consecutive terms;
+//   a large term is cut into doc-id ranges by splitters sampled from its longest list.
+// A 256-thread workgroup handles a tile: it decodes the tile's blocks of every segment into
+// LDS as k runs sorted by (term, doc), folds the runs pairwise (log2 k levels; an element
+// finds its place by one binary search in the partner run's list of the same term), then
+// drops duplicates and tombstoned ids, compacts, and appends the survivors to the output in
+// tile order (decoupled look-back), so the output is the CSR the reference's writer would
+// have been fed: terms ascending, ids ascending.
+#include "dv1_device.h"
 #include "internal.h"
+#include "lookback.h"
+
+namespace ii2 {
+
+constexpr uint32_t MCAP = MERGE_CAP;              // postings per tile
+constexpr uint32_t OFFMAX = MERGE_OFFMAX;         // (nt+1) * k table entries
+constexpr uint32_t TINY_BYTES = 28;               // lane-serial decode for blocks up to this payload
+
+// ---- plan -------------------------------------------------------------------------------
+// upper bound of a term's input postings: payload bytes + blocks (every posting but the first
+// of a block owns >= 1 payload byte)
+__global__ void k_merge_term_ub(MergeParams p, uint32_t *__restrict__ ub, uint32_t *__restrict__ weight,
+                                uint32_t *__restrict__ ntiles_large) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > p.n_terms) return;
+    if (t == p.n_terms) { ub[t] = 0; weight[t] = 0; ntiles_large[t] = 0; return; }
+    uint64_t u = 0;
+    for (uint32_t s = 0; s < p.k; s++) {
+        const SegView sv = p.segs[s];
+        const uint32_t b0 = sv.blk_off[t], b1 = sv.blk_off[t + 1];
+        if (b1 > b0) u += (uint64_t)(sv.skip[b1].byte_off - sv.skip[b0].byte_off) + (b1 - b0);
+    }
+    const uint32_t u32 = u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)u;
+    ub[t] = u32;
+    if (u32 > p.small_max) {
+        weight[t] = 0;
+        ntiles_large[t] = (uint32_t)((u + p.large_tile - 1) / p.large_tile);
+    } else {
+        weight[t] = u32 > p.wmin ? u32 : p.wmin;
+        ntiles_large[t] = 0;
+    }
+}
+
+// head[t] = 1 when small term t opens a new batch
+__global__ void k_merge_heads(MergeParams p, const uint32_t *__restrict__ ntl, const uint64_t *__restrict__ wpre,
+                              uint32_t *__restrict__ head) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > p.n_terms) return;
+    if (t == p.n_terms || ntl[t] > 0) { head[t] = 0; return; }
+    bool h = t == 0 || ntl[t - 1] > 0;
+    if (!h) h = (wpre[t] / p.batch_q) != (wpre[t - 1] / p.batch_q);
+    head[t] = h ? 1u : 0u;
+}
+
+// term_tile[t] = id of the (first) tile of term t; monotone in t
+__global__ void k_merge_term_tile(MergeParams p, const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ head,
+                                  const uint32_t *__restrict__ hpre, const uint32_t *__restrict__ lpre,
+                                  uint32_t *__restrict__ term_tile) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > p.n_terms) return;
+    if (t == p.n_terms) { term_tile[t] = hpre[t] + lpre[t]; return; }
+    if (ntl[t] > 0) term_tile[t] = hpre[t] + lpre[t];
+    else term_tile[t] = hpre[t] + head[t] - 1u + lpre[t];
+}
+
+// tile descriptors {t0, t1, lo, hi}
+__global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile,
+                                  uint4 *__restrict__ desc) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= p.n_tiles) return;
+    // last term whose first tile <= tile
+    uint64_t lo = 0, hi = p.n_terms;           // term_tile[lo] <= tile < term_tile[hi] (term_tile[n_terms] = n_tiles)
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + ((hi - lo) >> 1);
+        if (term_tile[mid] <= tile) lo = mid; else hi = mid;
+    }
+    const uint64_t tl = lo;
+    if (ntl[tl] > 0) {                          // tile j of large term tl
+        const uint32_t m = ntl[tl], j = tile - term_tile[tl];
+        // splitters: block first_docs of the term's longest list
+        uint32_t best_s = 0, best_n = 0;
+        for (uint32_t s = 0; s < p.k; s++) {
+            const uint32_t nb = p.segs[s].blk_off[tl + 1] - p.segs[s].blk_off[tl];
+            if (nb > best_n) { best_n = nb; best_s = s; }
+        }
+        const SegView sv = p.segs[best_s];
+        const uint32_t B0 = sv.blk_off[tl];
+        // splitter j = doc id at fractional block position j*best_n/m of the longest list
+        // (linear interpolation inside the block, so m may exceed the list's block count)
+        auto splitter = [&](uint32_t jj) -> uint32_t {
+            const uint64_t num = (uint64_t)jj * best_n;
+            const uint32_t b = (uint32_t)(num / m);
+            const uint64_t rem = num % m;
+            const uint32_t f0 = sv.skip[B0 + b].first_doc;
+            const uint32_t f1 = b + 1u < best_n ? sv.skip[B0 + b + 1u].first_doc : sv.last_doc[tl];
+            const uint64_t span = f1 > f0 ? (uint64_t)(f1 - f0) : 0ull;
+            return f0 + (uint32_t)((span * rem) / m);
+        };
+        // tile j covers [S_j, S_{j+1}) with S_0 = 0 and S_m = 2^32; S is non-decreasing in j
+        const uint64_t lo64 = j > 0 ? (uint64_t)splitter(j) : 0ull;
+        const uint64_t hi64 = j + 1u < m ? (uint64_t)splitter(j + 1u) : (1ull << 32);
+        uint32_t dlo, dhi;
+        if (hi64 <= lo64) { dlo = 1u; dhi = 0u; }             // empty range
+        else { dlo = (uint32_t)lo64; dhi = (uint32_t)(hi64 - 1ull); }
+        desc[tile] = make_uint4((uint32_t)tl, (uint32_t)tl + 1u, dlo, dhi);
+    } else {
+        // batch: terms [first with term_tile == tile, last with term_tile == tile]
+        uint64_t a = 0, b = tl;                 // find first term with term_tile >= tile
+        if (term_tile[0] >= tile) b = 0;
+        else {
+            a = 0;                              // term_tile[a] < tile <= term_tile[b]
+            while (b - a > 1) {
+                const uint64_t mid = a + ((b - a) >> 1);
+                if (term_tile[mid] < tile) a = mid; else b = mid;
+            }
+        }
+        desc[tile] = make_uint4((uint32_t)b, (uint32_t)tl + 1u, 0u, 0xFFFFFFFFu);
+    }
+}
+
+// ---- the tile kernel ----------------------------------------------------------------------
+struct __align__(16) MergeSmem {
+    uint32_t vals[2][MCAP];
+    uint16_t tids[2][MCAP];             // (run << 10 | term) of each element
+    uint32_t offs[2][OFFMAX];           // per run: nt+1 list offsets inside the run
+    uint32_t runbase[2][MAX_LISTS + 2];
+    uint32_t sbl[MAX_LISTS];            // first block of each segment's range
+    uint32_t spre[MAX_LISTS + 1];       // prefix of block counts
+    uint32_t wsum[4];
+    uint32_t n_in;
+    uint32_t nbig;
+    uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
+    unsigned long long base;
+};
+
+// segment that owns tile-local block i
+__device__ __forceinline__ uint32_t seg_of_block(const uint32_t *spre, uint32_t k, uint32_t i) {
+    uint32_t lo = 0, hi = k;            // spre[lo] <= i < spre[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (spre[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total in *tot
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *tot) {
+    const int l = lane_id(), wv = (int)threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    __syncthreads();
+    if (l == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (int w = 0; w < wv; w++) pre += wsum[w];
+    *tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return pre + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
+    __shared__ MergeSmem sm;
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const uint32_t k = p.k;
+
+    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+        const uint4 td = tile_desc[tile];
+        const uint32_t t0 = td.x, t1 = td.y;
+        const uint32_t nt = t1 - t0;
+        const uint32_t stride = nt + 1u;
+        uint32_t *bcnt = sm.vals[1];                     // [NB+1] block counts / positions (idle ping-pong buffer)
+        uint16_t *bbelow = sm.tids[1];                   // [NB]  ranged: ids below the range per block
+        uint16_t *biglist = sm.tids[1];                  // [NB]  full: blocks that need a whole wave
+
+        // ---- steps A-C: blocks of the doc range [dlo, dhi], their posting counts and positions.
+        // Returns false when the range does not fit LDS (n_in > MCAP or too many blocks).
+        auto count_range = [&](uint32_t dlo, uint32_t dhi) -> bool {
+            const bool full = dlo == 0u && dhi == 0xFFFFFFFFu;
+            __syncthreads();
+            if ((uint32_t)tid < k) {
+                const SegView sv = p.segs[tid];
+                const uint32_t B0 = sv.blk_off[t0], B1 = sv.blk_off[t1];
+                uint32_t bl = B0, bh = B1;
+                if (!full && B1 > B0) {
+                    const uint32_t ub = skip_upper_bound(sv.skip, B0, B1, dlo);
+                    bl = ub > B0 ? ub - 1u : B0;
+                    bh = skip_upper_bound(sv.skip, bl, B1, dhi);
+                }
+                sm.sbl[tid] = bl;
+                sm.spre[tid] = bh - bl;
+            }
+            __syncthreads();
+            if (wv == 0) {
+                const uint32_t c = (uint32_t)l < k ? sm.spre[l] : 0u;
+                const uint32_t incl = wave_incl_scan(c);
+                if ((uint32_t)l < k) sm.spre[l] = incl - c;
+                if (l == 63) sm.spre[k] = incl;
+            }
+            // offs[1][s*stride + t] = tile-local index of the first block of list (s, t0+t)
+            if (full) {
+                for (uint32_t e = (uint32_t)tid; e < k * stride; e += 256u) {
+                    const uint32_t s = e / stride, t = e % stride;
+                    sm.offs[1][e] = p.segs[s].blk_off[t0 + t] - p.segs[s].blk_off[t0];
+                }
+            }
+            if (tid == 0) sm.nbig = 0;
+            __syncthreads();
+            const uint32_t NB = sm.spre[k];
+            if (!full) {                                   // ranged tiles hold one term: nt == 1
+                for (uint32_t s = (uint32_t)tid; s < k; s += 256u) {
+                    sm.offs[1][s * stride] = 0;
+                    sm.offs[1][s * stride + 1u] = sm.spre[s + 1u] - sm.spre[s];
+                }
+            }
+            if (NB >= MCAP) return false;
+            for (uint32_t i = (uint32_t)tid; i <= NB; i += 256u) bcnt[i] = 0;
+            __syncthreads();
+            if (full) {
+                // tiny blocks: one lane per block (all 7 possible dwords fetched at once); others are listed
+                for (uint32_t i = (uint32_t)tid; i < NB; i += 256u) {
+                    const uint32_t s = seg_of_block(sm.spre, k, i);
+                    const SegView sv = p.segs[s];
+                    const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
+                    const uint32_t q0 = sv.skip[b].byte_off, q1 = sv.skip[b + 1].byte_off;
+                    const uint32_t len = q1 - q0;
+                    if (len <= TINY_BYTES) {
+                        uint32_t w[7];
+#pragma unroll
+                        for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(sv.payload + q0 + 4u * j) : 0u;
+                        uint32_t c = 1;
+#pragma unroll
+                        for (int j = 0; j < 7; j++) {
+                            const uint32_t nb = len > (uint32_t)(4 * j) ? (len - 4u * j < 4u ? len - 4u * j : 4u) : 0u;
+                            c += count_terminators(w[j], nb);
+                        }
+                        bcnt[i] = c;
+                    } else {
+                        const uint32_t slot = atomicAdd(&sm.nbig, 1u);
+                        biglist[slot] = (uint16_t)i;
+                    }
+                }
+                __syncthreads();
+                const uint32_t nbig = sm.nbig;
+                for (uint32_t z = (uint32_t)wv; z < nbig; z += 4u) {
+                    const uint32_t i = biglist[z];
+                    const uint32_t s = seg_of_block(sm.spre, k, i);
+                    const SegView sv = p.segs[s];
+                    const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
+                    const uint32_t c = count_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off);
+                    if (l == 0) bcnt[i] = c;
+                }
+            } else {
+                for (uint32_t i = (uint32_t)wv; i < NB; i += 4u) {
+                    const uint32_t s = seg_of_block(sm.spre, k, i);
+                    const SegView sv = p.segs[s];
+                    const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
+                    uint32_t below = 0, inr = 0;
+                    decode_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off, sv.skip[b].first_doc,
+                                      [&](uint32_t, uint32_t id) {
+                                          below += id < dlo;
+                                          inr += (id >= dlo && id <= dhi);
+                                      });
+                    below = wave_sum(below);
+                    inr = wave_sum(inr);
+                    if (l == 0) { bcnt[i] = inr; bbelow[i] = (uint16_t)below; }
+                }
+            }
+            __syncthreads();
+            // block positions (exclusive scan of the counts, in place)
+            {
+                const uint32_t per = (NB + 1u + 255u) / 256u;
+                const uint32_t a = (uint32_t)tid * per;
+                uint32_t local = 0;
+                for (uint32_t i = a; i < a + per && i <= NB; i++) local += bcnt[i];
+                uint32_t tot;
+                uint32_t run = block_excl_scan(local, sm.wsum, &tot);
+                for (uint32_t i = a; i < a + per && i <= NB; i++) { const uint32_t c = bcnt[i]; bcnt[i] = run; run += c; }
+                if (tid == 0) sm.n_in = tot;
+            }
+            __syncthreads();
+            return sm.n_in <= MCAP;
+        };
+
+        // ---- steps D-F on a counted range: decode, fold the runs, dedupe + tombstones + compact.
+        // Survivors land in sm.vals[*outbuf][0..return); per-term counts go to out_counts when asked.
+        auto merge_range = [&](uint32_t dlo, uint32_t dhi, uint32_t *outbuf, bool emit_counts, bool atomic_counts) -> uint32_t {
+            const bool full = dlo == 0u && dhi == 0xFFFFFFFFu;
+            const uint32_t n_in = sm.n_in;
+            const uint32_t NB = sm.spre[k];
+            *outbuf = 0;
+            if (n_in == 0) return 0u;
+            for (uint32_t s = (uint32_t)tid; s <= k; s += 256u) sm.runbase[0][s] = s < k ? bcnt[sm.spre[s]] : n_in;
+            __syncthreads();
+            for (uint32_t e = (uint32_t)tid; e < k * stride; e += 256u) {
+                const uint32_t s = e / stride;
+                sm.offs[0][e] = bcnt[sm.spre[s] + sm.offs[1][e]] - sm.runbase[0][s];
+            }
+            __syncthreads();
+            // ---- D. decode into vals[0] / tids[0] ----
+            const uint32_t *BI = sm.offs[1];          // block-index form of the list table
+            if (full) {
+                for (uint32_t i = (uint32_t)tid; i < NB; i += 256u) {
+                    const uint32_t s = seg_of_block(sm.spre, k, i);
+                    const SegView sv = p.segs[s];
+                    const uint32_t lb = i - sm.spre[s];
+                    const uint32_t b = sm.sbl[s] + lb;
+                    const uint32_t q0 = sv.skip[b].byte_off, q1 = sv.skip[b + 1].byte_off;
+                    const uint32_t len = q1 - q0;
+                    if (len <= TINY_BYTES) {
+                        uint32_t w[7];
+#pragma unroll
+                        for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(sv.payload + q0 + 4u * j) : 0u;
+                        uint32_t ta = 0, tb = nt;      // last t with BI[s][t] <= lb
+                        while (tb - ta > 1u) {
+                            const uint32_t mid = (ta + tb) >> 1;
+                            if (BI[s * stride + mid] <= lb) ta = mid; else tb = mid;
+                        }
+                        const uint16_t tag = (uint16_t)((s << 10) | ta);
+                        uint32_t pos = bcnt[i];
+                        uint32_t cur = sv.skip[b].first_doc;
+                        sm.vals[0][pos] = cur; sm.tids[0][pos] = tag; pos++;
+                        uint32_t acc = 0, sh = 0;
+#pragma unroll
+                        for (int j = 0; j < 28; j++) {
+                            if ((uint32_t)j < len) {
+                                const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                                acc |= (c & 0x7Fu) << sh;
+                                if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
+                                else { cur += acc; sm.vals[0][pos] = cur; sm.tids[0][pos] = tag; pos++; acc = 0; sh = 0; }
+                            }
+                        }
+                    }
+                }
+            }
+            {
+                const uint32_t nwork = full ? sm.nbig : NB;
+                for (uint32_t z = (uint32_t)wv; z < nwork; z += 4u) {
+                    const uint32_t i = full ? (uint32_t)biglist[z] : z;
+                    const uint32_t s = seg_of_block(sm.spre, k, i);
+                    const SegView sv = p.segs[s];
+                    const uint32_t lb = i - sm.spre[s];
+                    const uint32_t b = sm.sbl[s] + lb;
+                    uint32_t ta = 0, tb = nt;
+                    while (tb - ta > 1u) {
+                        const uint32_t mid = (ta + tb) >> 1;
+                        if (BI[s * stride + mid] <= lb) ta = mid; else tb = mid;
+                    }
+                    const uint16_t tag = (uint16_t)((s << 10) | ta);
+                    const uint32_t pos0 = bcnt[i];
+                    const uint32_t below = full ? 0u : (uint32_t)bbelow[i];
+                    decode_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off, sv.skip[b].first_doc,
+                                      [&](uint32_t ix, uint32_t id) {
+                                          if (id >= dlo && id <= dhi) {
+                                              const uint32_t pos = pos0 + ix - below;
+                                              sm.vals[0][pos] = id;
+                                              sm.tids[0][pos] = tag;
+                                          }
+                                      });
+                }
+            }
+            __syncthreads();
+            // ---- E. fold the runs pairwise ----
+            uint32_t cur = 0, nruns = k;
+            while (nruns > 1u) {
+                const uint32_t *V = sm.vals[cur];
+                const uint16_t *T = sm.tids[cur];
+                const uint32_t *O = sm.offs[cur];
+                const uint32_t *RB = sm.runbase[cur];
+                uint32_t *V2 = sm.vals[cur ^ 1u];
+                uint16_t *T2 = sm.tids[cur ^ 1u];
+                for (uint32_t e = (uint32_t)tid; e < n_in; e += 256u) {
+                    const uint32_t v = V[e];
+                    const uint32_t tag = T[e];
+                    const uint32_t r = tag >> 10, t = tag & 1023u;
+                    const uint32_t ro = r ^ 1u;
+                    const uint32_t myoff = O[r * stride + t];
+                    const uint32_t i = e - RB[r] - myoff;
+                    uint32_t rank = 0, poff = 0;
+                    if (ro < nruns) {
+                        poff = O[ro * stride + t];
+                        const uint32_t plen = O[ro * stride + t + 1u] - poff;
+                        const uint32_t *P = V + RB[ro] + poff;
+                        uint32_t a = 0, b = plen;
+                        if (r & 1u) {            // odd run: count partner elements <= v
+                            while (a < b) { const uint32_t mid = (a + b) >> 1; if (P[mid] <= v) a = mid + 1u; else b = mid; }
+                        } else {                 // even run: count partner elements < v
+                            while (a < b) { const uint32_t mid = (a + b) >> 1; if (P[mid] < v) a = mid + 1u; else b = mid; }
+                        }
+                        rank = a;
+                    }
+                    const uint32_t dst = RB[r & ~1u] + myoff + poff + i + rank;
+                    V2[dst] = v;
+                    T2[dst] = (uint16_t)(((r >> 1) << 10) | t);
+                }
+                __syncthreads();
+                const uint32_t nr2 = (nruns + 1u) >> 1;
+                uint32_t *O2 = sm.offs[cur ^ 1u];
+                uint32_t *RB2 = sm.runbase[cur ^ 1u];
+                for (uint32_t e = (uint32_t)tid; e < nr2 * stride; e += 256u) {
+                    const uint32_t r2 = e / stride, t = e % stride;
+                    const uint32_t ra = 2u * r2, rb = ra + 1u;
+                    O2[e] = O[ra * stride + t] + (rb < nruns ? O[rb * stride + t] : 0u);
+                }
+                for (uint32_t r2 = (uint32_t)tid; r2 <= nr2; r2 += 256u) RB2[r2] = r2 < nr2 ? RB[2u * r2] : n_in;
+                __syncthreads();
+                cur ^= 1u;
+                nruns = nr2;
+            }
+            // ---- F. dedupe, tombstones, compact ----
+            const uint32_t *V = sm.vals[cur];
+            const uint16_t *T = sm.tids[cur];
+            uint32_t *V2 = sm.vals[cur ^ 1u];
+            uint16_t *T2 = sm.tids[cur ^ 1u];
+            const uint32_t per = (n_in + 255u) / 256u;
+            const uint32_t a = (uint32_t)tid * per;
+            const uint32_t b = a + per < n_in ? a + per : n_in;
+            uint32_t keepmask = 0;               // per <= 16: one bit per element
+            uint32_t cnt = 0;
+            for (uint32_t e = a; e < b; e++) {
+                const uint32_t v = V[e];
+                bool keep = !(e > 0 && V[e - 1] == v && (T[e - 1] & 1023u) == (T[e] & 1023u));
+                if (keep && p.tomb) {
+                    const uint32_t w = v >> 5;
+                    if (w < p.tomb_nwords && ((p.tomb[w] >> (v & 31u)) & 1u)) keep = false;
+                }
+                if (keep) { keepmask |= 1u << (e - a); cnt++; }
+            }
+            uint32_t tot;
+            uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
+            for (uint32_t e = a; e < b; e++) {
+                if ((keepmask >> (e - a)) & 1u) { V2[pos] = V[e]; T2[pos] = (uint16_t)(T[e] & 1023u); pos++; }
+            }
+            *outbuf = cur ^ 1u;
+            if (emit_counts) {
+                // per-term survivor counts from the boundaries of the compacted array
+                uint32_t *tstart = sm.offs[0], *tend = sm.offs[1];
+                __syncthreads();
+                for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) { tstart[t] = 0; tend[t] = 0; }
+                __syncthreads();
+                for (uint32_t q = (uint32_t)tid; q < tot; q += 256u) {
+                    const uint32_t t = T2[q];
+                    if (q == 0 || T2[q - 1] != t) tstart[t] = q;
+                    if (q + 1u == tot || T2[q + 1] != t) tend[t] = q + 1u;
+                }
+                __syncthreads();
+                for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+                    const uint32_t c = tend[t] - tstart[t];
+                    if (c) {
+                        if (atomic_counts) atomicAdd(&p.out_counts[t0 + t], c);
+                        else p.out_counts[t0 + t] = c;
+                    }
+                }
+            }
+            __syncthreads();
+            return tot;
+        };
+
+        const uint32_t dlo = td.z, dhi = td.w;
+        const bool root_full = dlo == 0u && dhi == 0xFFFFFFFFu;
+        uint32_t total = 0, outbuf = 0;
+        bool split = false;
+        if (dlo <= dhi) {
+            if (count_range(dlo, dhi)) total = merge_range(dlo, dhi, &outbuf, true, !root_full);
+            else split = true;
+        }
+        if (!split) {
+            // ---- ordered output of a tile that fit LDS ----
+            if (wv == 0) {
+                const unsigned long long base = lookback_exclusive(p.desc, tile, total, p.epoch);
+                if (l == 0) {
+                    sm.base = base;
+                    if (tile == p.n_tiles - 1u) *p.d_total = base + total;
+                }
+            }
+            __syncthreads();
+            const unsigned long long ob = sm.base;
+            const uint32_t *V = sm.vals[outbuf];
+            for (uint32_t q = (uint32_t)tid; q < total; q += 256u)
+                if (ob + q < p.out_cap) p.out_values[ob + q] = V[q];
+        } else {
+            // ---- the tile's range holds more than LDS: bisect the doc range (rare: a term whose
+            // lists are clustered differently).  Pass 0 only counts the survivors of every leaf so
+            // the tile can take its place in the output order; pass 1 redoes the leaves and writes.
+            unsigned long long wbase = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                uint32_t sp = 0;
+                unsigned long long running = 0;
+                __syncthreads();
+                if (tid == 0) { sm.stk[0][0] = dlo; sm.stk[0][1] = dhi; }
+                sp = 1;
+                while (sp > 0) {
+                    __syncthreads();
+                    const uint32_t lo = sm.stk[sp - 1][0], hi = sm.stk[sp - 1][1];
+                    sp--;
+                    if (!count_range(lo, hi)) {
+                        // lo < hi here: a single doc id never exceeds k postings
+                        const uint32_t mid = lo + ((hi - lo) >> 1);
+                        __syncthreads();
+                        if (tid == 0) {
+                            sm.stk[sp][0] = mid + 1u; sm.stk[sp][1] = hi;
+                            sm.stk[sp + 1][0] = lo;   sm.stk[sp + 1][1] = mid;
+                        }
+                        sp += 2;
+                        continue;
+                    }
+                    uint32_t ob2 = 0;
+                    const uint32_t c = merge_range(lo, hi, &ob2, pass == 1, true);
+                    if (pass == 1) {
+                        const uint32_t *V = sm.vals[ob2];
+                        for (uint32_t q = (uint32_t)tid; q < c; q += 256u)
+                            if (wbase + running + q < p.out_cap) p.out_values[wbase + running + q] = V[q];
+                    }
+                    running += c;
+                }
+                if (pass == 0) {
+                    __syncthreads();
+                    if (wv == 0) {
+                        const unsigned long long base = lookback_exclusive(p.desc, tile, (uint32_t)running, p.epoch);
+                        if (l == 0) {
+                            sm.base = base;
+                            if (tile == p.n_tiles - 1u) *p.d_total = base + running;
+                        }
+                    }
+                    __syncthreads();
+                    wbase = sm.base;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out) {
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += v[i] != 0;
+    c = wave_sum(c);
+    if (lane_id() == 0 && c) atomicAdd((unsigned long long *)out, (unsigned long long)c);
+}
+
+static unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_term_ub, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ub, weight, ntl);
+    return hipGetLastError();
+}
+hipError_t launch_merge_heads(const MergeParams &p, const uint32_t *ntl, const uint64_t *wpre, uint32_t *head, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_heads, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ntl, wpre, head);
+    return hipGetLastError();
+}
+hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, const uint32_t *head, const uint32_t *hpre,
+                                  const uint32_t *lpre, uint32_t *term_tile, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_term_tile, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ntl, head, hpre, lpre, term_tile);
+    return hipGetLastError();
+}
+hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s) {
+    if (p.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
+    return hipGetLastError();
+}
+hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s) {
+    if (p.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_tiles, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(256), 0, s, p, (const uint4 *)tile_desc);
+    return hipGetLastError();
+}
+hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = grid_for(n);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_count_nonzero, dim3(g), dim3(256), 0, s, v, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace ii2

@@ -1,10 +1,327 @@
-// TEMPORARY stubs (replaced by the merge/union implementation).
+// ops.cpp — segment merge and union entry points, and the host-buffer convenience calls
+// (include/ii2.h).  Planning (which terms share a tile) runs on the device; the host only
+// reads back three scalars per call.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
 #include "internal.h"
-extern "C" {
-int ii2_merge_segments(ii2_ctx *ctx, uint32_t, const ii2_seg *const *, const ii2_tomb *, uint64_t *, uint32_t *, uint64_t, ii2_merge_stats *) { if (ctx) ctx->err = "not implemented"; return II2_EINVAL; }
-int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t, const ii2_seg *const *, const ii2_tomb *, ii2_seg **, ii2_merge_stats *) { if (ctx) ctx->err = "not implemented"; return II2_EINVAL; }
-int ii2_union(ii2_ctx *ctx, uint32_t, const ii2_seg *const *, const uint64_t *, const ii2_tomb *, uint32_t *, uint64_t, uint64_t *) { if (ctx) ctx->err = "not implemented"; return II2_EINVAL; }
-int ii2_merge_host(ii2_ctx *ctx, uint32_t, uint64_t, const uint64_t *, const uint64_t *, const uint32_t *, const uint32_t *, uint64_t, uint64_t *, uint32_t *, uint64_t, ii2_merge_stats *) { if (ctx) ctx->err = "not implemented"; return II2_EINVAL; }
-int ii2_intersect_host(ii2_ctx *ctx, uint32_t, const uint64_t *, const uint32_t *, const uint32_t *, uint64_t, uint32_t *, uint64_t, uint64_t *) { if (ctx) ctx->err = "not implemented"; return II2_EINVAL; }
-int ii2_union_host(ii2_ctx *ctx, uint32_t, const uint64_t *, const uint32_t *, const uint32_t *, uint64_t, uint32_t *, uint64_t, uint64_t *) { if (ctx) ctx->err = "not implemented"; return II2_EINVAL; }
+
+using namespace ii2;
+
+#define HIP_TRY(ctx, expr)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+            return II2_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+static int fail(ii2_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
 }
+static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+int ii2_ws_reserve(ii2_ctx *ctx, size_t bytes);          // api.cpp
+int ii2_desc_reserve(ii2_ctx *ctx, size_t n);
+uint32_t ii2_next_epoch(ii2_ctx *ctx);
+
+template <class T> static T *carve(uint8_t *&cursor, size_t count) {
+    T *p = (T *)cursor;
+    cursor += align_up(count * sizeof(T));
+    return p;
+}
+
+// Core: k SegViews over n_terms aligned term slots -> d_out_off (u64[n_terms+1], may be null),
+// d_out_values.  Blocking (reads back total / overflow / surviving terms).
+static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n_terms, const ii2_tomb *tomb,
+                      uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
+    hipStream_t st = ctx->stream;
+    const uint64_t T = n_terms;
+    if (T >= (1ull << 31) - 2) return fail(ctx, II2_ERANGE, "too many term slots");
+    MergeParams p;
+    std::memset(&p, 0, sizeof p);
+    for (uint32_t s = 0; s < k; s++) p.segs[s] = views[s];
+    p.k = k;
+    p.n_terms = T;
+    p.tomb = tomb ? tomb->d_words : nullptr;
+    p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+    const uint32_t cap = MERGE_CAP;
+    // terms per batch are bounded by the list-offset table: (nt + 1) * k <= MERGE_OFFMAX
+    uint32_t nt_max = MERGE_OFFMAX / k - 1u;
+    if (nt_max > 1000u) nt_max = 1000u;
+    if (nt_max < 1u) nt_max = 1u;
+    p.small_max = cap / 4u;
+    p.batch_q = cap - p.small_max;
+    p.wmin = (cap + nt_max - 1u) / nt_max;
+    if (p.wmin > p.small_max) p.wmin = p.small_max;     // k = 64: one term per batch may still exceed nt_max? no: nt <= cap/wmin
+    uint32_t large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : cap / 2u;
+
+    const size_t scan_b = scan_temp_bytes((size_t)T + 1);
+    for (int attempt = 0; attempt < 6; attempt++, large_tile = std::max<uint32_t>(large_tile / 2u, 32u)) {
+        p.large_tile = large_tile;
+        // workspace: planning arrays
+        const size_t n1 = (size_t)T + 1;
+        size_t need = 8 * align_up(n1 * sizeof(uint32_t)) + align_up(n1 * sizeof(uint64_t)) + scan_b + 4096;
+        int rc = ii2_ws_reserve(ctx, need);
+        if (rc) return rc;
+        uint8_t *cur = ctx->ws;
+        uint32_t *d_ub = carve<uint32_t>(cur, n1);
+        uint32_t *d_w = carve<uint32_t>(cur, n1);
+        uint32_t *d_ntl = carve<uint32_t>(cur, n1);
+        uint32_t *d_head = carve<uint32_t>(cur, n1);
+        uint32_t *d_hpre = carve<uint32_t>(cur, n1);
+        uint32_t *d_lpre = carve<uint32_t>(cur, n1);
+        uint32_t *d_tt = carve<uint32_t>(cur, n1);
+        uint32_t *d_cnt = carve<uint32_t>(cur, n1);
+        uint64_t *d_wpre = carve<uint64_t>(cur, n1);
+        void *d_scan = cur;
+
+        HIP_TRY(ctx, launch_merge_plan1(p, d_ub, d_w, d_ntl, st));
+        HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_w, d_wpre, n1, st));
+        HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_ntl, d_lpre, n1, st));
+        HIP_TRY(ctx, launch_merge_heads(p, d_ntl, d_wpre, d_head, st));
+        HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
+        HIP_TRY(ctx, launch_merge_term_tile(p, d_ntl, d_head, d_hpre, d_lpre, d_tt, st));
+        uint32_t n_tiles = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_tiles, d_tt + T, sizeof n_tiles, hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        p.n_tiles = n_tiles;
+
+        // tile descriptors live in the grow-only aux buffer
+        const size_t aux_need = (size_t)n_tiles * 16 + 256;
+        if (aux_need > ctx->aux_cap) {
+            if (ctx->aux) (void)hipFree(ctx->aux);
+            ctx->aux = nullptr;
+            ctx->aux_cap = 0;
+            const size_t want = align_up(aux_need + aux_need / 2, 1 << 16);
+            if (hipMalloc((void **)&ctx->aux, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "tile descriptor allocation failed");
+            ctx->aux_cap = want;
+        }
+        HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, ctx->aux, st));
+
+        rc = ii2_desc_reserve(ctx, (size_t)n_tiles + 1);
+        if (rc) return rc;
+        p.desc = ctx->desc;
+        p.epoch = ii2_next_epoch(ctx);
+        p.out_counts = d_cnt;
+        p.out_values = d_out_values;
+        p.out_cap = out_cap;
+        uint64_t *d_total = ctx->d_mail;            // [0] total, [1] overflow (u32), [2] surviving terms
+        p.d_total = d_total;
+        p.overflow = (uint32_t *)(ctx->d_mail + 1);
+        p.debug = ctx->opt_debug_stamps ? (unsigned long long *)(ctx->d_mail + 8) : nullptr;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
+        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
+        // persistent grid: 2 workgroups of ~67 KB LDS per CU are always co-resident
+        HIP_TRY(ctx, launch_merge_tiles(p, ctx->aux, (uint32_t)ctx->cu_count * 2u, st));
+        HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
+        if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const uint32_t overflow = (uint32_t)ctx->h_mail[1];
+        if (ctx->opt_debug_stamps) {
+            (void)hipMemcpy(ctx->h_mail + 8, ctx->d_mail + 8, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+            uint32_t td[4] = {9, 9, 9, 9}, tt[2] = {9, 9};
+            (void)hipMemcpy(td, ctx->aux, 16, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(tt, d_tt, 8, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[ii2 merge dbg] tile_desc[0]=%u %u %x %x term_tile[0..1]=%u %u aux=%p ws=%p desc=%p\n", td[0], td[1], td[2], td[3], tt[0], tt[1],
+                    (void *)ctx->aux, (void *)ctx->ws, (void *)ctx->desc);
+            fprintf(stderr, "[ii2 merge dbg] NB|n_in=%llx t0|t1=%llx lo|hi=%llx buf|total=%llx tiles=%u ovf=%u\n", (unsigned long long)ctx->h_mail[8],
+                    (unsigned long long)ctx->h_mail[9], (unsigned long long)ctx->h_mail[10], (unsigned long long)ctx->h_mail[11], n_tiles, overflow);
+        }
+        if (overflow) continue;                     // unbalanced doc-range splitters: re-plan with smaller tiles
+        if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small (content unspecified)");
+        if (stats) {
+            stats->n_out = ctx->h_mail[0];
+            stats->n_terms_out = ctx->h_mail[2];
+            stats->n_tiles = n_tiles;
+        }
+        return II2_OK;
+    }
+    return fail(ctx, II2_ERANGE, "merge: a term's postings are too clustered for the doc-range tiling");
+}
+
+static int check_segs(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs) {
+    if (k == 0 || k > MAX_LISTS || !segs) return fail(ctx, II2_EINVAL, "segment count must be 1..64");
+    for (uint32_t s = 0; s < k; s++) {
+        if (!segs[s] || segs[s]->ctx != ctx) return fail(ctx, II2_EINVAL, "segment is NULL or belongs to another context");
+        if (segs[s]->n_lists != segs[0]->n_lists) return fail(ctx, II2_EINVAL, "segments must be term-aligned (same n_lists)");
+    }
+    return II2_OK;
+}
+
+static int merge_unlocked(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb, uint64_t *d_out_off,
+                          uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
+    int rc = check_segs(ctx, k, segs);
+    if (rc) return rc;
+    if (!d_out_values) return fail(ctx, II2_EINVAL, "merge: output buffer is NULL");
+    std::vector<SegView> views(k);
+    uint64_t n_in = 0;
+    for (uint32_t s = 0; s < k; s++) {
+        views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_last_doc};
+        n_in += segs[s]->n_postings;
+    }
+    ii2_merge_stats local;
+    std::memset(&local, 0, sizeof local);
+    rc = merge_core(ctx, k, views.data(), segs[0]->n_lists, tomb, d_out_off, d_out_values, out_cap, &local);
+    if (rc) return rc;
+    local.n_in = n_in;
+    if (stats) *stats = local;
+    return II2_OK;
+}
+
+extern "C" {
+
+int ii2_merge_segments(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb, uint64_t *d_out_off,
+                       uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return merge_unlocked(ctx, k, segs, tomb, d_out_off, d_out_values, out_cap, stats);
+}
+
+int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb, ii2_seg **out,
+                              ii2_merge_stats *stats) {
+    if (!ctx || !out) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    int rc = check_segs(ctx, k, segs);
+    if (rc) return rc;
+    uint64_t n_in = 0;
+    for (uint32_t s = 0; s < k; s++) n_in += segs[s]->n_postings;
+    const uint64_t T = segs[0]->n_lists;
+    DevBuf off, vals;
+    if (off.alloc((T + 1) * sizeof(uint64_t)) != hipSuccess || vals.alloc(n_in * sizeof(uint32_t)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "merge output allocation failed");
+    ii2_merge_stats local;
+    rc = merge_unlocked(ctx, k, segs, tomb, off.as<uint64_t>(), vals.as<uint32_t>(), n_in, &local);
+    if (rc) return rc;
+    if (stats) *stats = local;
+    if (local.n_terms_out == 0) return II2_OK;      // shard.go:219-225: nothing survives, no segment is written
+    return ii2_seg_encode_dev_unlocked(ctx, T, off.as<uint64_t>(), vals.as<uint32_t>(), local.n_out, out);
+}
+
+int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx, const ii2_tomb *tomb,
+              uint32_t *d_out, uint64_t cap, uint64_t *count) {
+    if (!ctx || !count) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n == 0 || n > MAX_LISTS || !segs) return fail(ctx, II2_EINVAL, "ii2_union: list count must be 1..64");
+    std::vector<SegView> views(n);
+    bool any = false;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint64_t li = list_idx ? list_idx[i] : 0;
+        if (!segs[i] || segs[i]->ctx != ctx || li >= segs[i]->n_lists) return fail(ctx, II2_EINVAL, "ii2_union: bad list");
+        // a one-term view of the segment: blk_off shifted to the list
+        views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_last_doc + li};
+        any |= segs[i]->h_blk_off[li + 1] > segs[i]->h_blk_off[li];
+    }
+    if (!any) { *count = 0; return II2_OK; }
+    if (!d_out) return fail(ctx, II2_EINVAL, "ii2_union: output buffer is NULL");
+    ii2_merge_stats st;
+    std::memset(&st, 0, sizeof st);
+    int rc = merge_core(ctx, n, views.data(), 1, tomb, nullptr, d_out, cap, &st);
+    if (rc) return rc;
+    *count = st.n_out;
+    return II2_OK;
+}
+
+// ---- host-buffer convenience -----------------------------------------------------------------
+int ii2_merge_host(ii2_ctx *ctx, uint32_t k, uint64_t n_terms, const uint64_t *seg_off, const uint64_t *seg_base,
+                   const uint32_t *values, const uint32_t *removed, uint64_t n_removed, uint64_t *out_off,
+                   uint32_t *out_values, uint64_t out_cap, ii2_merge_stats *stats) {
+    if (!ctx || !seg_off || !seg_base || !out_off || (k && seg_base[k] && !values))
+        return fail(ctx, II2_EINVAL, "ii2_merge_host: bad argument");
+    if (k == 0 || k > MAX_LISTS) return fail(ctx, II2_EINVAL, "segment count must be 1..64");
+    std::vector<ii2_seg *> segs(k, nullptr);
+    ii2_tomb *tomb = nullptr;
+    int rc = II2_OK;
+    uint64_t n_in = 0;
+    for (uint32_t s = 0; s < k && !rc; s++) {
+        rc = ii2_seg_encode(ctx, n_terms, seg_off + (size_t)s * (n_terms + 1), values + seg_base[s], II2_HOST, &segs[s]);
+        n_in += seg_base[s + 1] - seg_base[s];
+    }
+    if (!rc && n_removed) rc = ii2_tomb_create(ctx, removed, n_removed, II2_HOST, &tomb);
+    if (!rc && !out_values && n_in) rc = fail(ctx, II2_EINVAL, "ii2_merge_host: out_values is NULL");
+    if (!rc) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        DevBuf off, vals;
+        ii2_merge_stats local;
+        std::memset(&local, 0, sizeof local);
+        if (off.alloc((n_terms + 1) * sizeof(uint64_t)) != hipSuccess || vals.alloc(n_in * sizeof(uint32_t)) != hipSuccess)
+            rc = fail(ctx, II2_ENOMEM, "merge output allocation failed");
+        if (!rc) rc = merge_unlocked(ctx, k, segs.data(), tomb, off.as<uint64_t>(), vals.as<uint32_t>(), n_in, &local);
+        if (!rc && local.n_out > out_cap) rc = fail(ctx, II2_ECAPACITY, "ii2_merge_host: out_values too small; nothing was written");
+        if (!rc) {
+            hipError_t e = hipMemcpyAsync(out_off, off.p, (n_terms + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess && local.n_out)
+                e = hipMemcpyAsync(out_values, vals.p, local.n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { ctx->err = std::string("merge download: ") + hipGetErrorString(e); rc = II2_EHIP; }
+            if (stats) *stats = local;
+        }
+    }
+    for (ii2_seg *s : segs) ii2_seg_free(s);
+    ii2_tomb_free(tomb);
+    return rc;
+}
+
+static int lists_host(ii2_ctx *ctx, bool is_union, uint32_t n, const uint64_t *list_off, const uint32_t *values,
+                      const uint32_t *removed, uint64_t n_removed, uint32_t *out, uint64_t cap, uint64_t *count) {
+    if (!ctx || !list_off || !count || n == 0 || n > MAX_LISTS) return fail(ctx, II2_EINVAL, "bad argument");
+    ii2_seg *seg = nullptr;
+    ii2_tomb *tomb = nullptr;
+    int rc = ii2_seg_encode(ctx, n, list_off, values, II2_HOST, &seg);
+    if (!rc && n_removed) rc = ii2_tomb_create(ctx, removed, n_removed, II2_HOST, &tomb);
+    if (!rc) {
+        uint64_t bound = 0;
+        if (is_union) bound = list_off[n] - list_off[0];
+        else {
+            bound = ~0ull;
+            for (uint32_t i = 0; i < n; i++) bound = std::min<uint64_t>(bound, list_off[i + 1] - list_off[i]);
+        }
+        DevBuf d_out;
+        if (d_out.alloc((bound + 1) * sizeof(uint32_t)) != hipSuccess) rc = fail(ctx, II2_ENOMEM, "result allocation failed");
+        std::vector<const ii2_seg *> segs(n, seg);
+        std::vector<uint64_t> idx(n);
+        for (uint32_t i = 0; i < n; i++) idx[i] = i;
+        uint64_t c = 0;
+        if (!rc)
+            rc = is_union ? ii2_union(ctx, n, segs.data(), idx.data(), tomb, d_out.as<uint32_t>(), bound + 1, &c)
+                          : ii2_intersect(ctx, n, segs.data(), idx.data(), tomb, d_out.as<uint32_t>(), bound + 1, &c);
+        if (!rc && c > cap) rc = fail(ctx, II2_ECAPACITY, "output buffer too small; nothing was written");
+        if (!rc && c) {
+            if (!out) rc = fail(ctx, II2_EINVAL, "output buffer is NULL");
+            else rc = ii2_copy_d2h(ctx, out, d_out.p, c * sizeof(uint32_t));
+        }
+        if (!rc) *count = c;
+    }
+    ii2_seg_free(seg);
+    ii2_tomb_free(tomb);
+    return rc;
+}
+
+int ii2_intersect_host(ii2_ctx *ctx, uint32_t n, const uint64_t *list_off, const uint32_t *values, const uint32_t *removed,
+                       uint64_t n_removed, uint32_t *out, uint64_t cap, uint64_t *count) {
+    return lists_host(ctx, false, n, list_off, values, removed, n_removed, out, cap, count);
+}
+
+int ii2_union_host(ii2_ctx *ctx, uint32_t n, const uint64_t *list_off, const uint32_t *values, const uint32_t *removed,
+                   uint64_t n_removed, uint32_t *out, uint64_t cap, uint64_t *count) {
+    return lists_host(ctx, true, n, list_off, values, removed, n_removed, out, cap, count);
+}
+
+}  // extern "C"
