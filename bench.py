@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""bench.py — posting-list hot path on MI355X: postings/s and fraction of the HBM roofline.
+
+Workload at N=1 (BASELINE.json configs[1]): 2-term intersection over a 100M-doc index, Zipf
+ranks 2 and 3 (≈50M and ≈33M postings), block-Δ-varint (DV1) lists resident in HBM, decoded
+in-kernel; output = the ascending doc ids of the intersection, resident in HBM.
+A step = one pass of the hot path (partition pre-pass + tile kernel) over that input.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): the doc-id space is sharded —
+rank g holds the lists' postings in [g*D, (g+1)*D) — so per-GPU work is fixed (weak scaling)
+and ranks do not talk during the timed steps (the reference's shards are independent,
+inverted_index.go:83-103).  The rank-order concatenation of the per-rank results
+(RCCL all-gatherv, inverted_index.go:330-339) runs once after the timed region and is
+reported separately as `allgatherv_ms` (use --gather-timed to put it inside every step).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--docs", type=int, default=100_000_000, help="doc-id universe per GPU (config 2: 100M)")
+    ap.add_argument("--workload", choices=["intersect", "merge"], default="intersect")
+    ap.add_argument("--tombstones", action="store_true", help="apply a 1%% tombstone bitmap during the intersection")
+    ap.add_argument("--gather-timed", action="store_true", help="include the RCCL all-gatherv in every timed step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--merge-terms", type=int, default=200_000, help="merge workload: aligned terms")
+    ap.add_argument("--merge-segments", type=int, default=16)
+    ap.add_argument("--merge-mean", type=float, default=1000.0)
+    return ap.parse_args()
+
+
+def cpu_baseline_intersect(lists, removed, reps):
+    """The oracle (CPU restatement: DV1 decode + two-pointer intersection), single thread."""
+    from oracle import oracle as orc
+    po = np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.uint64)
+    flat = np.concatenate(lists)
+    blk, skip, payload = orc.dv1_encode(po, flat)
+    n_post = int(flat.size)
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(reps):
+        po2, vals = orc.dv1_decode(blk, skip, payload, n_post)
+        dec = [vals[int(po2[i]):int(po2[i + 1])] for i in range(len(lists))]
+        res = orc.intersect(dec, removed if removed is not None else ())
+    dt = (time.perf_counter() - t0) / reps
+    return n_post / dt, res, dt
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from inverted_index_2_amd import Context, comm_unique_id, synth
+
+    ctx = Context(local_rank)
+    ctx.selftest()
+
+    if args.workload == "merge":
+        return bench_merge(args, ctx, torch, dist, world, rank)
+
+    D = args.docs
+    offset = rank * D
+    if offset + D > (1 << 32):
+        raise SystemExit("doc-id shards exceed the uint32 id space")
+    a = synth.zipf_list(2, D, offset)
+    b = synth.zipf_list(3, D, offset)
+    removed = None
+    tomb = None
+    if args.tombstones:
+        removed = (synth.geometric_postings(0.01, D, synth.term_seed(10**6), offset)).astype(np.uint32)
+        tomb = ctx.tombstones(removed)
+    seg = ctx.encode_lists([a, b])
+    lists = [(seg, 0), (seg, 1)]
+    n_in = int(a.size + b.size)
+    out = ctx.empty(min(a.size, b.size) + 512)
+    d_count = ctx.empty(8, np.uint64)
+
+    # correctness of this rank's result before timing: count + order + checksum
+    _, n_out = ctx.intersect(lists, tomb=tomb, out=out)
+    got = out.download(n_out)
+    want_np = np.intersect1d(a, b, assume_unique=True)
+    if removed is not None:
+        want_np = np.setdiff1d(want_np, removed, assume_unique=True)
+    if n_out != want_np.size or not np.array_equal(got, want_np):
+        raise SystemExit(f"rank {rank}: GPU intersection differs from the numpy cross-check")
+
+    gather_out = None
+    if world > 1:
+        uid = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(world, rank, uid[0])
+        gather_out = ctx.empty((min(a.size, b.size) + 512) * world)
+
+    def step():
+        ctx.intersect_async(lists, tomb, out, d_count)
+        if args.gather_timed and world > 1:
+            ctx.allgatherv(out, n_out, gather_out, world)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_option("profile.events", 1)
+    ctx.profile_read()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = ctx.profile_read()
+    ctx.set_option("profile.events", 0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # the exchange step, once, outside the timed region: rank-order concatenation of the results
+    gather_ms = None
+    total_out = n_out
+    if world > 1:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        counts = ctx.allgatherv(out, n_out, gather_out, world)
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        total_out = sum(counts)
+        allv = gather_out.download(total_out)
+        if not (np.all(np.diff(allv.astype(np.int64)) > 0) and np.array_equal(allv[sum(counts[:rank]):sum(counts[:rank + 1])], got)):
+            raise SystemExit(f"rank {rank}: all-gatherv result is not the rank-order concatenation")
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    info = seg.info
+    # algorithmic bytes of one launch of the dominant (tile) kernel — DESIGN.md §Roofline:
+    # encoded payload + 8 B per block of skip table + 4 B per result id (+ D/8 tombstone bitmap)
+    alg_bytes = info.n_bytes + 8 * info.n_blocks + 4 * n_out + (D // 8 if tomb is not None else 0)
+    kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
+    achieved = alg_bytes / kern_avg_s / 1e9 if kern_n else None
+
+    result = {
+        "metric": "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline",
+        "value": n_in * world * args.steps / dt,
+        "unit": "postings/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": "2-term intersection (Zipf ranks 2 and 3), %d-doc universe per GPU, DV1 block-delta-varint "
+                        "decoded in-kernel, doc-range sharded" % D,
+            "postings_per_gpu": n_in, "result_ids_per_gpu": n_out, "tombstones": bool(args.tombstones),
+            "encoded_bytes_per_gpu": int(info.n_bytes), "blocks_per_gpu": int(info.n_blocks),
+            "parallelism": "docrange%d" % world, "allgatherv": "timed" if args.gather_timed else "after timed region",
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "ii2::k_isect_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_us": kern_avg_s * 1e6, "launches_timed": int(kern_n),
+        },
+    }
+    if gather_ms is not None:
+        result["allgatherv_ms"] = gather_ms
+        result["allgatherv_ids"] = int(total_out)
+    if not args.no_cpu_baseline:
+        reps = 10
+        v, res, per = cpu_baseline_intersect([a, b], removed, reps)
+        if not np.array_equal(res, got):
+            raise SystemExit("GPU result differs from the oracle")
+        result["cpu_baseline"] = {
+            "value": v, "unit": "postings/s", "cores": 1, "kind": "port",
+            "sample": "the full rank-0 workload (DV1 decode + two-pointer intersection of %d postings), %d repetitions, "
+                      "%.2f s each, single thread of the oracle (oracle/ii2_oracle.c)" % (n_in, reps, per),
+        }
+    print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_merge(args, ctx, torch, dist, world, rank):
+    """Secondary workload (BASELINE config 3 family): k-way segment merge with tombstones.
+    Terms are sharded over the ranks in contiguous ranges; each rank generates its own shard."""
+    from inverted_index_2_amd import synth
+    T, k = args.merge_terms, args.merge_segments
+    offs, vals, removed = synth.merge_workload(T, k, args.merge_mean, args.docs, seed=synth.GLOBAL_SEED + rank)
+    segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+    tomb = ctx.tombstones(removed)
+    n_in = int(sum(int(o[-1]) for o in offs))
+    out_off = ctx.empty(T + 1, np.uint64)
+    out_vals = ctx.empty(n_in)
+    _, _, st = ctx.merge(segs, tomb, out_off, out_vals)
+    for _ in range(args.warmup):
+        ctx.merge(segs, tomb, out_off, out_vals)
+    ctx.set_option("profile.events", 1)
+    ctx.profile_read()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.merge(segs, tomb, out_off, out_vals)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_n = ctx.profile_read()
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    enc = sum(s.info.n_bytes for s in segs)
+    nblk = sum(s.info.n_blocks for s in segs)
+    alg = enc + 8 * nblk + 4 * k * (T + 1) + args.docs // 8 + 4 * st.n_out + 4 * (T + 1)
+    kavg = kern_ms / max(kern_n, 1) * 1e-3
+    result = {
+        "metric": "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline",
+        "value": n_in * world * args.steps / dt, "unit": "postings/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%d-way segment merge, %d terms x mean %.0f postings per GPU, 1%% tombstones, term-sharded"
+                               % (k, T, args.merge_mean), "postings_in_per_gpu": n_in, "postings_out_per_gpu": int(st.n_out),
+                   "tiles": int(st.n_tiles), "parallelism": "terms%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "ii2::k_merge_tiles", "achieved": alg / kavg / 1e9, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": alg / kavg / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": int(alg), "kernel_avg_us": kavg * 1e6, "launches_timed": int(kern_n)},
+    }
+    if not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        ncores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        w_off, w_vals, _ = orc.merge_segments(offs, vals, removed, threads=ncores)
+        cdt = time.perf_counter() - t0
+        if not (np.array_equal(out_off.download(), w_off) and np.array_equal(out_vals.download(int(w_off[-1])), w_vals)):
+            raise SystemExit("GPU merge differs from the oracle")
+        result["cpu_baseline"] = {"value": n_in / cdt, "unit": "postings/s", "cores": ncores, "kind": "port",
+                                  "sample": "the full rank-0 merge workload once, oracle worker pool over term ranges"}
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ii2_selftest": (C.c_int, [vp]),
     "ii2_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "ii2_debug_read": (C.c_int, [vp, u64p, C.c_uint64]),
+    "ii2_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), u64p]),
 }
 
 _lib = None

@@ -79,7 +79,35 @@ uint32_t ii2_next_epoch(ii2_ctx *ctx) {
     return ctx->epoch;
 }
 
+bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1) {
+    if (!ctx->opt_profile_events) return false;
+    std::pair<hipEvent_t, hipEvent_t> pr;
+    if (!ctx->prof_pool.empty()) { pr = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+    else if (hipEventCreate(&pr.first) != hipSuccess || hipEventCreate(&pr.second) != hipSuccess) return false;
+    ctx->prof_events.push_back(pr);
+    *e0 = pr.first;
+    *e1 = pr.second;
+    return true;
+}
+
 extern "C" {
+
+int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches) {
+    if (!ctx || !total_ms || !launches) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    uint64_t n = 0;
+    for (auto &pr : ctx->prof_events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { tot += ms; n++; }
+        ctx->prof_pool.push_back(pr);
+    }
+    ctx->prof_events.clear();
+    *total_ms = tot;
+    *launches = n;
+    return II2_OK;
+}
 
 int ii2_abi_version(void) { return II2_ABI_VERSION; }
 
@@ -126,6 +154,8 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+    for (auto *v : {&ctx->prof_events, &ctx->prof_pool})
+        for (auto &pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -516,7 +546,9 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }
-    HIP_TRY(ctx, launch_intersect(p, d_tile_off, st));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ii2_profile_pair(ctx, &e0, &e1);
+    HIP_TRY(ctx, launch_intersect(p, d_tile_off, st, e0, e1));
     return II2_OK;
 }
 
@@ -584,6 +616,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "merge.lookback") ctx->opt_merge_lookback = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
+    else if (k == "profile.events") ctx->opt_profile_events = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

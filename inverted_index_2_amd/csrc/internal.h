@@ -33,6 +33,9 @@ struct ii2_ctx {
     uint8_t *aux = nullptr;             // grow-only: merge tile descriptors
     size_t aux_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
+    int64_t opt_profile_events = 0;     // bracket the dominant kernel of each call with HIP events
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;     // reusable pairs
     unsigned long long *d_debug = nullptr;
     void *comm = nullptr;               // ncclComm_t
     int world = 1, rank = 0;
@@ -58,6 +61,7 @@ struct ii2_tomb {
 };
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
+bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);   // false when profiling is off
 int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values,
                                 uint64_t n_postings, ii2_seg **out);
 int ii2_seg_decode_dev_unlocked(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *d_post_off, uint32_t *d_values);
@@ -132,7 +136,7 @@ hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStrea
 // intersect
 constexpr uint32_t ISECT_GMAX = 8;          // driver blocks per tile (max)
 constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
-hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s);
+hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // merge / union
 constexpr uint32_t MERGE_CAP = 4096;        // postings per tile (LDS)
@@ -162,7 +166,8 @@ hipError_t launch_merge_heads(const MergeParams &p, const uint32_t *ntl, const u
 hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, const uint32_t *head, const uint32_t *hpre,
                                   const uint32_t *lpre, uint32_t *term_tile, hipStream_t s);
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
-hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s);
+hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0 = nullptr,
+                              hipEvent_t ev1 = nullptr);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 
 }  // namespace ii2

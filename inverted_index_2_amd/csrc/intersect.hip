@@ -396,12 +396,14 @@ __global__ __launch_bounds__(256) void k_isect_copy(IntersectParams p, const uin
         if (ob + i < p.out_cap) p.out[ob + i] = src[i];
 }
 
-hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s) {
+hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
     const uint64_t nthr = (uint64_t)p.n_tiles * p.n_lists;
     hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p);
     const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
+    if (ev0) (void)hipEventRecord(ev0, s);
     hipLaunchKernelGGL(k_isect_tiles, dim3(grid), dim3(256), 0, s, p);
+    if (ev1) (void)hipEventRecord(ev1, s);
     if (!p.lookback) {
         hipLaunchKernelGGL(k_isect_scan_counts, dim3(1), dim3(1024), 0, s, (const uint32_t *)p.tile_count, p.n_tiles, d_tile_off, p.d_count);
         hipLaunchKernelGGL(k_isect_copy, dim3(p.n_tiles), dim3(256), 0, s, p, (const uint64_t *)d_tile_off);

@@ -565,9 +565,11 @@ hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, con
     hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
     return hipGetLastError();
 }
-hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s) {
+hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
+    if (ev0) (void)hipEventRecord(ev0, s);
     hipLaunchKernelGGL(k_merge_tiles, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(256), 0, s, p, (const uint4 *)tile_desc);
+    if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s) {

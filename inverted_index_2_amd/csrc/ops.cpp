@@ -125,7 +125,9 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
         HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
         // persistent grid: 2 workgroups of ~67 KB LDS per CU are always co-resident
-        HIP_TRY(ctx, launch_merge_tiles(p, ctx->aux, (uint32_t)ctx->cu_count * 2u, st));
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ii2_profile_pair(ctx, &e0, &e1);
+        HIP_TRY(ctx, launch_merge_tiles(p, ctx->aux, (uint32_t)ctx->cu_count * 2u, st, e0, e1));
         HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
         if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));

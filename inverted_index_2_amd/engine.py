@@ -112,6 +112,12 @@ class Context:
     def set_option(self, name: str, value: int) -> None:
         self._ck(self.lib.ii2_set_option(self.h, name.encode(), int(value)))
 
+    def profile_read(self):
+        """(total device ms, launches) of the dominant kernel since the last read (option profile.events)."""
+        ms, n = C.c_double(), C.c_uint64()
+        self._ck(self.lib.ii2_profile_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def selftest(self) -> None:
         self._ck(self.lib.ii2_selftest(self.h))
 
