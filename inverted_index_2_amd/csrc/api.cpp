@@ -514,27 +514,23 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     }
     p.G = G;
     p.n_tiles = (nblk0 + G - 1) / G;
-    p.lookback = ctx->opt_intersect_lookback ? 1u : 0u;
     const size_t dstride = 2 + 4 * (size_t)n;
-    size_t need = align_up((size_t)p.n_tiles * dstride * sizeof(uint32_t)) + 4096;
-    if (!p.lookback)
-        need += align_up((size_t)p.n_tiles * G * 256 * sizeof(uint32_t)) + align_up((p.n_tiles + 1) * sizeof(uint32_t)) +
-                align_up((p.n_tiles + 1) * sizeof(uint64_t));
+    uint32_t slot_words = (ISECT_SMAX + 32u) / 32u;
+    if (slot_words < G * 256u) slot_words = G * 256u;
+    slot_words = (slot_words + 3u) & ~3u;
+    p.slot_words = slot_words;
+    size_t need = align_up((size_t)p.n_tiles * dstride * sizeof(uint32_t)) + align_up((size_t)p.n_tiles * slot_words * sizeof(uint32_t)) +
+                  align_up(((size_t)p.n_tiles + 1) * sizeof(uint32_t)) + align_up(((size_t)p.n_tiles / 64 + p.n_tiles / 4096 + 4) * sizeof(uint32_t)) + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     p.ranges = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * dstride);
-    p.max_grid = (uint32_t)ctx->cu_count * 4u;     // 4 x 37 KB of LDS per CU: all co-resident
+    p.tmp = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * slot_words);
+    p.tile_count = ws_take<uint32_t>(ctx, (size_t)p.n_tiles + 1);
+    p.n_sums1 = p.n_tiles / 64 + 1;
+    p.n_sums = p.n_sums1;
+    p.sums = ws_take<uint32_t>(ctx, p.n_sums);
     uint64_t *d_tile_off = nullptr;
-    if (p.lookback) {
-        rc = ii2_desc_reserve(ctx, p.n_tiles);
-        if (rc) return rc;
-        p.desc = ctx->desc;
-        p.epoch = ii2_next_epoch(ctx);
-    } else {
-        p.tmp = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * G * 256);
-        p.tile_count = ws_take<uint32_t>(ctx, p.n_tiles + 1);
-        d_tile_off = ws_take<uint64_t>(ctx, p.n_tiles + 1);
-    }
+    p.max_grid = (uint32_t)ctx->cu_count * 5u;     // ~29 KB of LDS per workgroup: 5 per CU
     p.tomb = tomb ? tomb->d_words : nullptr;
     p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
     p.out = d_out;
@@ -542,7 +538,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.d_count = d_count;
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
-        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)ctx->cu_count * 4 * 8 * sizeof(unsigned long long)) != hipSuccess)
+        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)ctx->cu_count * 8 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }
@@ -601,7 +597,7 @@ int ii2_selftest(ii2_ctx *ctx) {
 int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words) {
     if (!ctx || !out || !ctx->d_debug) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
-    const uint64_t have = (uint64_t)ctx->cu_count * 4 * 8;
+    const uint64_t have = (uint64_t)ctx->cu_count * 8 * 8;
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_debug, std::min(n_words, have) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return II2_OK;

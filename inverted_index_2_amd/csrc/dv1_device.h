@@ -22,6 +22,11 @@ constexpr int WAVE = 64;
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not wait for the
+// wave's outstanding global loads / stores / atomics (vmcnt), so prefetches and result stores keep
+// draining behind it.  Use only where the waves exchange data through LDS.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Inclusive prefix sum over the 64 lanes of a wave (all lanes must be active).
 // row_shr 1/2/4/8 inside each row of 16, then row_bcast:15 / row_bcast:31 carry the row
 // totals across rows (gfx9 DPP).
@@ -88,14 +93,18 @@ struct LdsBytes {
     }
 };
 
-// Decode one DV1 block with one wave.  emit(idx_in_block, doc_id) is called once per
-// posting, by the lane that owns the posting's terminator byte (lane 0 also owns posting 0).
+// Decode one DV1 block with one wave, four postings at a time.
+// emit4(ix, id0, id1, id2, id3, mask) is called once per 256-byte chunk by every lane: bit j of
+// mask says byte j of the lane's dword terminates a posting whose id is id_j; the lane's valid
+// postings have consecutive indices starting at ix.  Posting 0 (first_doc) is delivered first,
+// by lane 0, as emit4(0, first_doc, 0, 0, 0, 1) (mask 0 on the other lanes).  Handing the four
+// candidates over together lets the caller issue its LDS reads back to back before any write.
 // Returns the number of postings in the block (wave-uniform).  All 64 lanes must call with
 // wave-uniform q0, q1, first_doc.
-template <class Load, class Emit>
-__device__ __forceinline__ uint32_t decode_block_wave(Load load, uint32_t q0, uint32_t q1, uint32_t first_doc, Emit emit) {
+template <class Load, class Emit4>
+__device__ __forceinline__ uint32_t decode_block_wave4(Load load, uint32_t q0, uint32_t q1, uint32_t first_doc, Emit4 emit4) {
     const int l = lane_id();
-    if (l == 0) emit(0u, first_doc);
+    emit4(0u, first_doc, 0u, 0u, 0u, l == 0 ? 1u : 0u);
     uint32_t carry_id = first_doc;   // running id after the last byte of the previous chunk
     uint32_t carry_cnt = 1;          // postings emitted so far
     uint32_t carry_run = 0;          // continuation bytes pending at the chunk boundary
@@ -107,10 +116,10 @@ __device__ __forceinline__ uint32_t decode_block_wave(Load load, uint32_t q0, ui
         const uint32_t cont = w & 0x80808080u;
         const bool plain = (__ballot(cont != 0) == 0ull) && carry_run == 0;   // wave-uniform
         uint32_t c0, c1, c2, c3;         // per-byte contributions
-        uint32_t t0, t1, t2, t3;         // per-byte terminator flags (valid bytes only)
+        uint32_t mask;                   // per-byte terminator flags (valid bytes only)
         if (plain) {
             c0 = w & 0xFFu; c1 = (w >> 8) & 0xFFu; c2 = (w >> 16) & 0xFFu; c3 = w >> 24;
-            t0 = nb > 0; t1 = nb > 1; t2 = nb > 2; t3 = nb > 3;
+            mask = (1u << nb) - 1u;
         } else {
             const uint32_t k0b = cont & 0x80u, k1b = cont & 0x8000u, k2b = cont & 0x800000u, k3b = cont & 0x80000000u;
             // trailing continuation run of this lane's valid bytes
@@ -136,29 +145,103 @@ __device__ __forceinline__ uint32_t decode_block_wave(Load load, uint32_t q0, ui
             c1 = ((w >> 8) & 0x7Fu) << (7u * r1);
             c2 = ((w >> 16) & 0x7Fu) << (7u * r2);
             c3 = ((w >> 24) & 0x7Fu) << (7u * r3);
-            t0 = (nb > 0) && !k0b; t1 = (nb > 1) && !k1b; t2 = (nb > 2) && !k2b; t3 = (nb > 3) && !k3b;
+            mask = ((nb > 0 && !k0b) ? 1u : 0u) | ((nb > 1 && !k1b) ? 2u : 0u) | ((nb > 2 && !k2b) ? 4u : 0u) |
+                   ((nb > 3 && !k3b) ? 8u : 0u);
             carry_run = wave_bcast(trail == 4u ? (r0 + 4u > 4u ? 4u : r0 + 4u) : trail, 63);
         }
         const uint32_t s = c0 + c1 + c2 + c3;
-        const uint32_t tc = t0 + t1 + t2 + t3;
+        const uint32_t tc = (uint32_t)__popc(mask);
         const uint32_t si = wave_incl_scan(s);
         const uint32_t ti = wave_incl_scan(tc);
-        uint32_t id = carry_id + (si - s);
-        uint32_t ix = carry_cnt + (ti - tc);
-        id += c0; if (t0) { emit(ix, id); ix++; }
-        id += c1; if (t1) { emit(ix, id); ix++; }
-        id += c2; if (t2) { emit(ix, id); ix++; }
-        id += c3; if (t3) { emit(ix, id); ix++; }
+        const uint32_t id0 = carry_id + (si - s) + c0;
+        const uint32_t id1 = id0 + c1, id2 = id1 + c2, id3 = id2 + c3;
+        emit4(carry_cnt + (ti - tc), id0, id1, id2, id3, mask);
         carry_id += wave_bcast(si, 63);
         carry_cnt += wave_bcast(ti, 63);
     }
     return carry_cnt;
 }
 
+// Per-posting form: emit(idx_in_block, doc_id) once per posting, by the lane that owns the
+// posting's terminator byte (lane 0 also owns posting 0).
+template <class Load, class Emit>
+__device__ __forceinline__ uint32_t decode_block_wave(Load load, uint32_t q0, uint32_t q1, uint32_t first_doc, Emit emit) {
+    return decode_block_wave4(load, q0, q1, first_doc,
+                              [&](uint32_t ix, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                                  if (mask & 1u) { emit(ix, id0); ix++; }
+                                  if (mask & 2u) { emit(ix, id1); ix++; }
+                                  if (mask & 4u) { emit(ix, id2); ix++; }
+                                  if (mask & 8u) { emit(ix, id3); ix++; }
+                              });
+}
+
 template <class Emit>
 __device__ __forceinline__ uint32_t decode_block_wave(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1,
                                                       uint32_t first_doc, Emit emit) {
     return decode_block_wave(GlobalBytes{payload}, q0, q1, first_doc, emit);
+}
+
+// ---- four blocks per wave: one 16-lane DPP row per block, 16 payload bytes per lane ---------
+// Inclusive prefix sum inside each row of 16 lanes (no cross-row steps).
+__device__ __forceinline__ uint32_t row_incl_scan(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    return x;
+}
+
+// 16 payload bytes at byte offset q (any alignment) as four dwords
+struct GlobalBytes16 {
+    const uint8_t *__restrict__ p;
+    __device__ __forceinline__ uint4 operator()(uint32_t q) const {
+        uint4 v;
+        __builtin_memcpy(&v, p + q, 16);
+        return v;
+    }
+};
+struct LdsBytes16 {
+    const uint8_t *p;    // LDS, 4-byte aligned base; 20 bytes are read
+    __device__ __forceinline__ uint4 operator()(uint32_t q) const {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(p + (q & ~3u));
+        const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+        const uint32_t sh = q & 3u;
+        return make_uint4(__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                          __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh));
+    }
+};
+
+// Row decode of one block per 16-lane row (fast path: payload <= 256 bytes, one byte per gap).
+// Every lane passes ITS row's block: payload byte range [q0, q1) and first_doc; rows without a
+// block pass q0 == q1 and row_valid = false.  On success each lane gets base = id of the posting
+// just before its 16 bytes and w = its 16 gap bytes (bytes past the block's end are 0, so the
+// running id simply stops advancing there) and true is returned.  Returns false — for the whole
+// wave, nothing decoded — when any row's block needs the general decoder.
+template <class Load16>
+__device__ __forceinline__ bool decode_rows16(Load16 load16, uint32_t q0, uint32_t q1, uint32_t first_doc, bool row_valid,
+                                              uint32_t &base, uint4 &w) {
+    const uint32_t rl = (uint32_t)lane_id() & 15u;
+    const uint32_t len = row_valid ? q1 - q0 : 0u;
+    const uint32_t myoff = 16u * rl;
+    const uint32_t nb = len > myoff ? (len - myoff < 16u ? len - myoff : 16u) : 0u;
+    w = nb ? load16(q0 + myoff) : make_uint4(0, 0, 0, 0);
+    if (nb < 16u) {     // zero the bytes past the end of the block
+        const uint32_t n0 = nb < 4u ? nb : 4u, n1 = nb < 4u ? 0u : (nb < 8u ? nb - 4u : 4u);
+        const uint32_t n2 = nb < 8u ? 0u : (nb < 12u ? nb - 8u : 4u), n3 = nb < 12u ? 0u : nb - 12u;
+        w.x &= n0 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n0)) - 1u);
+        w.y &= n1 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n1)) - 1u);
+        w.z &= n2 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n2)) - 1u);
+        w.w &= n3 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n3)) - 1u);
+    }
+    const bool hard = len > 256u || (((w.x | w.y | w.z | w.w) & 0x80808080u) != 0u);
+    if (__ballot(hard) != 0ull) return false;
+    uint32_t s = __builtin_amdgcn_sad_u8(w.x, 0u, 0u);
+    s = __builtin_amdgcn_sad_u8(w.y, 0u, s);
+    s = __builtin_amdgcn_sad_u8(w.z, 0u, s);
+    s = __builtin_amdgcn_sad_u8(w.w, 0u, s);
+    const uint32_t incl = row_incl_scan(s);
+    base = first_doc + incl - s;
+    return true;
 }
 
 // Posting count of a block without decoding ids (1 + terminators).  Wave-uniform result.

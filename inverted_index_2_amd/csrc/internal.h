@@ -97,15 +97,14 @@ struct IntersectParams {
     uint32_t *ranges;            // [n_tiles][2 + 4*n_lists] tile doc range + per-list phase descriptors
     uint32_t *out;               // final ids
     uint64_t out_cap;
-    uint32_t *tmp;               // non-lookback: per-tile slots of G*256
-    uint32_t *tile_count;        // non-lookback
-    unsigned long long *desc;    // lookback descriptors [n_tiles]
+    uint32_t *tmp;               // per-tile slot of slot_words: result bitmap words or survivor id list
+    uint32_t *tile_count;        // [n_tiles] survivors per tile (bit 31: the slot holds an id list)
     uint64_t *d_count;           // result count
     unsigned long long *debug;   // optional per-workgroup phase cycle counters [grid][8] (diagnostics)
-    uint32_t epoch;
-    uint32_t lookback;
-    uint32_t max_grid;           // persistent grid bound (<= co-resident workgroups)
-    uint32_t pad2;
+    uint32_t *sums;              // [n_sums] partial sums of tile_count: per 64 tiles, then per 4096 tiles
+    uint32_t n_sums, n_sums1;    // total entries, entries of the per-64 level
+    uint32_t slot_words;
+    uint32_t max_grid;           // workgroups of the tile kernel (each walks tiles w, w+grid, ...)
 };
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
@@ -134,7 +133,7 @@ hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, c
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
 
 // intersect
-constexpr uint32_t ISECT_GMAX = 8;          // driver blocks per tile (max)
+constexpr uint32_t ISECT_GMAX = 16;         // driver blocks per tile (max)
 constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 

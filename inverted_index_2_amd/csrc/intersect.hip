@@ -6,72 +6,95 @@
 //
 // Tiling.  The shortest list is the DRIVER.  A tile = G consecutive driver blocks
 // (G*256 candidate ids, doc range [lo, hi]); a pre-pass finds, per tile and per other list,
-// the block range whose ids can fall in [lo, hi] (binary search on the skip tables).  One
-// 256-thread workgroup per tile:
+// the block range whose ids can fall in [lo, hi] (binary search on the skip tables).
 //   byte-map path (hi-lo < 16 Ki docs — dense lists): the tile keeps one LDS byte per doc of
 //     its range.  Driver postings write 1; list j's postings turn a j into j+1 (lists are
-//     duplicate-free, so no two lanes ever race on a byte); bytes equal to n are the
-//     result.  Every block is decoded by one wave straight from HBM (4 bytes per lane, one
-//     DPP prefix sum), so a posting costs one LDS byte access and nothing is sorted,
-//     merged or searched.
+//     duplicate-free, so no two lanes ever race on a byte); bytes equal to n are the result.
+//     Every block is decoded by one wave (4 bytes per lane, one DPP prefix sum), so a posting
+//     costs one LDS byte access and nothing is sorted, merged or searched.  The tile leaves its
+//     result as a BITMAP (1 bit per doc of its range, tombstones already cleared) plus a count.
 //   gallop path (sparse / skewed tiles): candidates sit in LDS as a sorted array; for each
 //     other list every live candidate binary-searches that list's skip table for the one
 //     block that could hold it, a wave decodes just those blocks into LDS and the
-//     candidates search them.  Blocks without a candidate are never touched.
-// Output order: tiles are in doc order and a tile's survivors are in doc order, so the
-// result is the concatenation of the tiles' survivors; offsets come from a decoupled
-// look-back over the tile counts (single pass) or, with lookback off, from a count scan
-// and a copy pass.
+//     candidates search them.  Blocks without a candidate are never touched.  The tile leaves
+//     its survivors as a short id list plus a count.
+// Output order.  Tiles are in doc order and independent of each other (no inter-workgroup
+// hand-off at all): a scan of the tile counts gives every tile its output offset and an
+// expand pass turns bitmaps / lists into the final ascending id array.  Intermediate traffic
+// is 1 bit per doc of the driver's range instead of a second copy of the ids.
+#include <algorithm>
+
 #include "dv1_device.h"
 #include "internal.h"
-#include "lookback.h"
 
 namespace ii2 {
 
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t LIST_FLAG = 0x80000000u;       // tile_count: the tile left an id list, not a bitmap
+constexpr uint32_t MAP_BYTES = ISECT_SMAX + 32u;  // byte map origin is rounded down to a multiple of 32 docs
 
 // ---- pre-pass: tile doc ranges and per-list phase descriptors ----------------------------
-// desc layout per tile (DESC_STRIDE(n) = 2 + 4n words): [lo, hi] then per list j (0 = driver)
+// desc layout per tile (2 + 4n words): [lo, hi] then per list j (0 = driver)
 // {bl, bh, qlo, qhi}: block range and payload byte range of the phase (tile, j).
 __host__ __device__ constexpr uint32_t desc_stride(uint32_t n) { return 2u + 4u * n; }
 
-__global__ void k_isect_partition(IntersectParams p) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// first index i in [lo, hi) with skip[i].first_doc > x, searched 64 ways per round by one wave
+__device__ __forceinline__ uint32_t wave_skip_upper_bound(const ii2_skip *__restrict__ skip, uint32_t lo, uint32_t hi, uint32_t x) {
+    const uint32_t l = (uint32_t)lane_id();
+    while (lo < hi) {
+        const uint32_t span = hi - lo;
+        const uint32_t step = (span + 63u) >> 6;              // >= 1
+        const uint32_t pos = lo + l * step;                   // probe positions, ascending over the lanes
+        const bool in = pos < hi;
+        const bool le = in && skip[pos].first_doc <= x;       // true on a prefix of the lanes (sorted table)
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(le));
+        const uint32_t nin = (uint32_t)__popcll(__ballot(in));
+        // answer lies in (pos[cnt-1], pos[cnt]]
+        const uint32_t nlo = cnt ? lo + (cnt - 1u) * step + 1u : lo;
+        const uint32_t nhi = cnt < nin ? lo + cnt * step : hi;
+        if (step == 1u) return cnt < nin ? lo + cnt : hi;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
+    const uint64_t gw = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;   // one wave per (tile, list)
     const uint32_t n = p.n_lists;
-    if (gid >= (uint64_t)p.n_tiles * n) return;
-    const uint32_t t = (uint32_t)(gid / n), j = (uint32_t)(gid % n);
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < p.n_sums) p.sums[gid] = 0;                      // level sums of the tile counts (filled by the tile kernel)
+    if (gw >= (uint64_t)p.n_tiles * n) return;
+    const uint32_t t = (uint32_t)(gw / n), j = (uint32_t)(gw % n);
     const ListView d = p.lists[0];
     const uint32_t b0 = t * p.G;
     const uint32_t b1 = b0 + p.G < d.nblk ? b0 + p.G : d.nblk;
     const uint32_t lo = d.skip[b0].first_doc;
-    uint32_t hi;
-    if (b1 < d.nblk) {
-        hi = d.skip[b1].first_doc - 1u;
-    } else {
-        hi = *d.last_doc;                        // last tile ends at the list's last id
-    }
+    const uint32_t hi = b1 < d.nblk ? d.skip[b1].first_doc - 1u : *d.last_doc;
     uint32_t *r = p.ranges + (uint64_t)t * desc_stride(n);
     if (j == 0) {
-        r[0] = lo; r[1] = hi;
-        r[2] = b0; r[3] = b1; r[4] = d.skip[b0].byte_off; r[5] = d.skip[b1].byte_off;
+        if (lane_id() == 0) {
+            r[0] = lo; r[1] = hi;
+            r[2] = b0; r[3] = b1; r[4] = d.skip[b0].byte_off; r[5] = d.skip[b1].byte_off;
+        }
         return;
     }
     const ListView L = p.lists[j];
     // first block that may hold ids >= lo: the last block whose first_doc <= lo
-    uint32_t ub = skip_upper_bound(L.skip, 0u, L.nblk, lo);
+    const uint32_t ub = wave_skip_upper_bound(L.skip, 0u, L.nblk, lo);
     const uint32_t bl = ub ? ub - 1u : 0u;
-    const uint32_t bh = skip_upper_bound(L.skip, bl, L.nblk, hi);   // first block starting after hi
-    r[2 + 4 * j] = bl;
-    r[3 + 4 * j] = bh;
-    r[4 + 4 * j] = L.skip[bl].byte_off;
-    r[5 + 4 * j] = L.skip[bh].byte_off;
+    const uint32_t bh = wave_skip_upper_bound(L.skip, bl, L.nblk, hi);   // first block starting after hi
+    if (lane_id() == 0) {
+        r[2 + 4 * j] = bl;
+        r[3 + 4 * j] = bh;
+        r[4 + 4 * j] = L.skip[bl].byte_off;
+        r[5 + 4 * j] = L.skip[bh].byte_off;
+    }
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------
-// Persistent workgroups: the grid never exceeds what is co-resident (host: <= 4 per CU), and
-// workgroup w walks tiles w, w+grid, w+2*grid, ...  Every tile a workgroup waits on in the
-// look-back is therefore held by a resident workgroup that is working on it — forward
-// progress does not depend on dispatch order and needs no atomic ticket.
+// Workgroup w walks tiles w, w+grid, ... so that it can fetch its next tile's bytes while it
+// works on the current one.
 //
 // Software pipeline.  A phase = (tile, list).  Its payload bytes and skip entries are
 // contiguous in HBM, so all 256 threads fetch them with 16-byte loads into registers one
@@ -82,21 +105,16 @@ constexpr uint32_t SKIPCAP = 256;     // staged skip entries per phase (1 per th
 constexpr uint32_t DESC_WORDS = 2u + 4u * MAX_LISTS;
 
 struct __align__(16) IsectSmem {
-    uint8_t map[ISECT_SMAX];                 // byte map | gallop: cand[GMAX*256] u32 + hit[GMAX*256] u8
-    uint32_t stage[ISECT_GMAX * 256];        // survivors | gallop: 4 x 256 decoded block (one per wave)
-    uint8_t raw[RAWCAP + 16];
+    uint8_t map[MAP_BYTES];                  // byte map | gallop: cand[GMAX*256] u32 + hit[GMAX*256] u8
+    uint8_t raw[RAWCAP + 32];                // staged payload | gallop: 4 x 256 decoded block (one per wave)
     ii2_skip skipbuf[SKIPCAP + 8];
     uint32_t desc[2][DESC_WORDS];
     uint32_t wcnt[4];
     uint32_t ncand;
     uint32_t pad;
-    unsigned long long base;
 };
-
-__device__ __forceinline__ bool tomb_hit(const uint32_t *__restrict__ tomb, uint32_t nwords, uint32_t doc) {
-    const uint32_t w = doc >> 5;
-    return w < nwords && ((tomb[w] >> (doc & 31u)) & 1u);
-}
+constexpr uint32_t GALLOP_SUB = 8;         // driver blocks the gallop path handles per round
+static_assert(GALLOP_SUB * 256u * 5u <= MAP_BYTES, "gallop candidates + flags must fit the byte map");
 
 struct Phase { uint32_t bl, bh, qlo, qhi; };
 __device__ __forceinline__ bool can_stage(const Phase &d) {
@@ -121,6 +139,14 @@ __device__ __forceinline__ void prefetch_commit(IsectSmem &sm, const Prefetch &p
     if ((uint32_t)tid < nch) *reinterpret_cast<uint4 *>(&sm.raw[16u * (uint32_t)tid]) = pf.r0;
     if ((uint32_t)tid + 256u < nch) *reinterpret_cast<uint4 *>(&sm.raw[16u * ((uint32_t)tid + 256u)]) = pf.r1;
     if ((uint32_t)tid <= d.bh - d.bl) sm.skipbuf[tid] = pf.sk;
+}
+
+// bytes of w equal to the byte replicated in n4 -> 4-bit mask (bit k = byte k)
+__device__ __forceinline__ uint32_t bytes_eq_mask(uint32_t w, uint32_t n4) {
+    const uint32_t x = w ^ n4;                                   // zero byte <=> match
+    const uint32_t t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+    const uint32_t z = ~(t | x | 0x7F7F7F7Fu);                   // 0x80 in every zero byte, exact
+    return (((z >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
 
 __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
@@ -163,12 +189,14 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
         uint32_t dreg = 0;
         if (has_next && (uint32_t)tid < stride) dreg = p.ranges[(uint64_t)next_tile * stride + tid];
         const ListView drv = p.lists[0];
-        uint32_t total = 0;
+        uint32_t *slot = p.tmp + (uint64_t)tile * p.slot_words;     // this tile's bitmap words / id list
 
         if (span < ISECT_SMAX) {
             // ================= byte-map path =================
-            const uint32_t nbytes = (span + 1u + 15u) & ~15u;
-            for (uint32_t i = (uint32_t)tid * 16u; i < nbytes; i += 256u * 16u)
+            const uint32_t mlo = lo & ~31u;                  // map origin: 32-doc aligned
+            const uint32_t mspan = hi - mlo;                 // last valid map offset
+            const uint32_t nwords = (mspan >> 5) + 1u;       // <= MAP_BYTES / 32
+            for (uint32_t i = (uint32_t)tid * 16u; i < nwords * 32u; i += 256u * 16u)
                 *reinterpret_cast<uint4 *>(&sm.map[i]) = make_uint4(0, 0, 0, 0);
             for (uint32_t j = 0; j < n; j++) {
                 const ListView L = p.lists[j];
@@ -176,7 +204,8 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
                 const bool staged = can_stage(d);
                 if (j == n - 1u && has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
                 if (staged) prefetch_commit(sm, pf, d, tid);
-                __syncthreads();
+                II2_STAMP(4)      // clear + commit (waits for the prefetched bytes)
+                lds_barrier();
                 // fetch the next phase while this one decodes
                 if (j + 1u < n) {
                     const Phase dn = {D[6 + 4 * j], D[7 + 4 * j], D[8 + 4 * j], D[9 + 4 * j]};
@@ -189,143 +218,212 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
                 II2_STAMP(0)      // clear + commit + barrier + prefetch issue
                 const uint32_t nblk = d.bh - d.bl;
                 const uint8_t want = (uint8_t)j;
-                auto mark = [&](uint32_t, uint32_t id) {
-                    const uint32_t off = id - lo;
-                    if (off <= span && sm.map[off] == want) sm.map[off] = (uint8_t)(want + 1u);
+                // driver: plain stores of 1.  list j: read the four candidate bytes, then bump the ones at j.
+                auto mark4 = [&](uint32_t, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                    const uint32_t o0 = id0 - mlo, o1 = id1 - mlo, o2 = id2 - mlo, o3 = id3 - mlo;
+                    const bool v0 = (mask & 1u) && o0 <= mspan, v1 = (mask & 2u) && o1 <= mspan;
+                    const bool v2 = (mask & 4u) && o2 <= mspan, v3 = (mask & 8u) && o3 <= mspan;
+                    if (want == 0) {
+                        if (v0) sm.map[o0] = 1;
+                        if (v1) sm.map[o1] = 1;
+                        if (v2) sm.map[o2] = 1;
+                        if (v3) sm.map[o3] = 1;
+                    } else {
+                        const uint8_t m0 = v0 ? sm.map[o0] : (uint8_t)0xFE, m1 = v1 ? sm.map[o1] : (uint8_t)0xFE;
+                        const uint8_t m2 = v2 ? sm.map[o2] : (uint8_t)0xFE, m3 = v3 ? sm.map[o3] : (uint8_t)0xFE;
+                        const uint8_t nx = (uint8_t)(want + 1u);
+                        if (m0 == want) sm.map[o0] = nx;
+                        if (m1 == want) sm.map[o1] = nx;
+                        if (m2 == want) sm.map[o2] = nx;
+                        if (m3 == want) sm.map[o3] = nx;
+                    }
                 };
+                // four blocks per wave round: one 16-lane row per block, 16 gap bytes per lane;
+                // all 17 candidate bytes of a lane are read before any is written
+                const uint32_t dummy = mspan + 1u;           // harmless byte: masked out when the map is finalised
+                const uint32_t rl = (uint32_t)l & 15u, row = (uint32_t)l >> 4;
+                auto mark16 = [&](uint32_t base, const uint4 &w, bool rv, uint32_t first_doc) {
+                    uint32_t acc = rv ? base - mlo : 0xFFFFFFFFu;
+                    uint32_t o[16];
+                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        acc += (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                        o[k] = acc < dummy ? acc : dummy;
+                    }
+                    const uint32_t f = first_doc - mlo;
+                    const uint32_t of = (rv && rl == 0u && f < dummy) ? f : dummy;
+                    if (want == 0) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) sm.map[o[k]] = 1;
+                        sm.map[of] = 1;
+                    } else {
+                        uint8_t m[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) m[k] = sm.map[o[k]];
+                        const uint8_t mf = sm.map[of];
+                        const uint8_t nx = (uint8_t)(want + 1u);
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (m[k] == want) sm.map[o[k]] = nx;
+                        if (mf == want) sm.map[of] = nx;
+                    }
+                };
+                const uint32_t ngroups = (nblk + 3u) >> 2;
                 if (staged) {
                     const uint32_t base16 = d.qlo & ~15u;
-                    for (uint32_t i = (uint32_t)wv; i < nblk; i += 4u) {
-                        const ii2_skip e0 = sm.skipbuf[i], e1 = sm.skipbuf[i + 1u];
-                        decode_block_wave(LdsBytes{sm.raw}, e0.byte_off - base16, e1.byte_off - base16, e0.first_doc, mark);
+                    for (uint32_t g = (uint32_t)wv; g < ngroups; g += 4u) {
+                        const uint32_t bi = 4u * g + row;
+                        const bool rv = bi < nblk;
+                        ii2_skip e0 = {0u, 0u}, e1 = {0u, 0u};
+                        if (rv) { e0 = sm.skipbuf[bi]; e1 = sm.skipbuf[bi + 1u]; }
+                        uint32_t base;
+                        uint4 w;
+                        if (decode_rows16(LdsBytes16{sm.raw}, e0.byte_off - base16, e1.byte_off - base16, e0.first_doc, rv, base, w)) {
+                            mark16(base, w, rv, e0.first_doc);
+                        } else {
+                            for (uint32_t i = 4u * g; i < 4u * g + 4u && i < nblk; i++) {
+                                const ii2_skip f0 = sm.skipbuf[i], f1 = sm.skipbuf[i + 1u];
+                                decode_block_wave4(LdsBytes{sm.raw}, f0.byte_off - base16, f1.byte_off - base16, f0.first_doc, mark4);
+                            }
+                        }
                     }
                 } else {
-                    for (uint32_t b = d.bl + (uint32_t)wv; b < d.bh; b += 4u)
-                        decode_block_wave(L.payload, L.skip[b].byte_off, L.skip[b + 1].byte_off, L.skip[b].first_doc, mark);
+                    for (uint32_t g = (uint32_t)wv; g < ngroups; g += 4u) {
+                        const uint32_t bi = 4u * g + row;
+                        const bool rv = bi < nblk;
+                        ii2_skip e0 = {0u, 0u}, e1 = {0u, 0u};
+                        if (rv) { e0 = L.skip[d.bl + bi]; e1 = L.skip[d.bl + bi + 1u]; }
+                        uint32_t base;
+                        uint4 w;
+                        if (decode_rows16(GlobalBytes16{L.payload}, e0.byte_off, e1.byte_off, e0.first_doc, rv, base, w)) {
+                            mark16(base, w, rv, e0.first_doc);
+                        } else {
+                            for (uint32_t b = d.bl + 4u * g; b < d.bl + 4u * g + 4u && b < d.bh; b++)
+                                decode_block_wave4(GlobalBytes{L.payload}, L.skip[b].byte_off, L.skip[b + 1].byte_off,
+                                                   L.skip[b].first_doc, mark4);
+                        }
+                    }
                 }
                 II2_STAMP(1)      // decode
-                __syncthreads();
+                lds_barrier();
                 II2_STAMP(2)      // barrier after decode
             }
-            // pass 1: finalise (tombstones) and count; wave w owns a contiguous quarter of the map
-            const uint32_t quarter = ((nbytes / 4u) + 255u) & ~255u;
-            const uint32_t w0 = (uint32_t)wv * quarter;
-            const uint32_t w1 = w0 + quarter < nbytes ? w0 + quarter : nbytes;
+            // finalise: byte map -> bitmap words (32 docs each), tombstones cleared, survivors counted
+            const uint32_t n4 = n * 0x01010101u;
             uint32_t mine = 0;
-            for (uint32_t base = w0; base < w1; base += 256u) {
-                const uint32_t off = base + 4u * (uint32_t)l;
-                if (off < w1) {
-                    uint32_t w = *reinterpret_cast<uint32_t *>(&sm.map[off]);
-                    uint32_t out = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (((w >> (8 * k)) & 0xFFu) == n) {
-                            const uint32_t doc = lo + off + (uint32_t)k;
-                            if (!(p.tomb && tomb_hit(p.tomb, p.tomb_nwords, doc))) { out |= 0xFFu << (8 * k); mine++; }
-                        }
-                    }
-                    *reinterpret_cast<uint32_t *>(&sm.map[off]) = out;
+            for (uint32_t wi = (uint32_t)tid; wi < nwords; wi += 256u) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(&sm.map[32u * wi]);
+                const uint4 b = *reinterpret_cast<const uint4 *>(&sm.map[32u * wi + 16u]);
+                uint32_t word = bytes_eq_mask(a.x, n4) | (bytes_eq_mask(a.y, n4) << 4) | (bytes_eq_mask(a.z, n4) << 8) |
+                                (bytes_eq_mask(a.w, n4) << 12) | (bytes_eq_mask(b.x, n4) << 16) | (bytes_eq_mask(b.y, n4) << 20) |
+                                (bytes_eq_mask(b.z, n4) << 24) | (bytes_eq_mask(b.w, n4) << 28);
+                if (wi == nwords - 1u && (mspan & 31u) != 31u) word &= (2u << (mspan & 31u)) - 1u;   // drop the dummy byte and beyond
+                if (p.tomb) {
+                    const uint32_t tw = (mlo >> 5) + wi;
+                    if (tw < p.tomb_nwords) word &= ~p.tomb[tw];
                 }
+                slot[wi] = word;
+                mine += (uint32_t)__popc(word);
             }
             mine = wave_sum(mine);
             if (l == 0) sm.wcnt[wv] = mine;
-            __syncthreads();
-            II2_STAMP(3)          // pass 1
-            uint32_t pos = 0;
-            for (int w = 0; w < wv; w++) pos += sm.wcnt[w];
-            total = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
-            // pass 2: ordered write into stage
-            for (uint32_t base = w0; base < w1; base += 256u) {
-                const uint32_t off = base + 4u * (uint32_t)l;
-                uint32_t w = off < w1 ? *reinterpret_cast<uint32_t *>(&sm.map[off]) : 0u;
-                const uint32_t m = (uint32_t)__popc(w & 0x01010101u);
-                const uint32_t incl = wave_incl_scan(m);
-                uint32_t q = pos + incl - m;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if ((w >> (8 * k)) & 1u) sm.stage[q++] = lo + off + (uint32_t)k;
-                pos += wave_bcast(incl, 63);
+            lds_barrier();
+            if (tid == 0) {
+                const uint32_t c = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
+                p.tile_count[tile] = c;
+                if (c) atomicAdd(&p.sums[tile >> 6], c);
             }
-            __syncthreads();
-            II2_STAMP(4)          // pass 2
+            II2_STAMP(3)          // finalise
         } else {
             // ================= gallop path =================
-            const uint32_t b0 = D[2], b1 = D[3];
             uint32_t *cand = reinterpret_cast<uint32_t *>(sm.map);
-            uint8_t *hit = sm.map + ISECT_GMAX * 256u * 4u;
-            uint32_t *wbuf = sm.stage + (uint32_t)wv * 256u;
-            for (uint32_t b = b0 + (uint32_t)wv; b < b1; b += 4u) {
-                const uint32_t pb = (b - b0) * 256u;
-                const uint32_t c = decode_block_wave(drv.payload, drv.skip[b].byte_off, drv.skip[b + 1].byte_off,
-                                                     drv.skip[b].first_doc, [&](uint32_t ix, uint32_t id) {
-                                                         cand[pb + ix] = id;
-                                                         hit[pb + ix] = 1;
-                                                     });
-                if (b == b1 - 1u && l == 0) sm.ncand = pb + c;
-            }
-            __syncthreads();
-            const uint32_t ncand = sm.ncand;
-            for (uint32_t j = 1; j < n; j++) {
-                const ListView L = p.lists[j];
-                const uint32_t bl = D[2 + 4 * j], bh = D[3 + 4 * j];
-                for (uint32_t base = (uint32_t)wv * 64u; base < ncand; base += 256u) {
-                    const uint32_t pi = base + (uint32_t)l;
-                    const bool alive = pi < ncand && hit[pi] == (uint8_t)j;
-                    const uint32_t c = alive ? cand[pi] : 0u;
-                    uint32_t blk = NONE;
-                    if (alive && bl < bh) {
-                        const uint32_t ub = skip_upper_bound(L.skip, bl, bh, c);
-                        if (ub > bl) blk = ub - 1u;
-                    }
-                    unsigned long long pending = __ballot(blk != NONE);
-                    while (pending) {
-                        const int leader = __ffsll((long long)pending) - 1;
-                        const uint32_t cur = wave_bcast(blk, leader);
-                        const uint32_t cnt = decode_block_wave(L.payload, L.skip[cur].byte_off, L.skip[cur + 1].byte_off,
-                                                               L.skip[cur].first_doc,
-                                                               [&](uint32_t ix, uint32_t id) { wbuf[ix] = id; });
-                        __threadfence_block();
-                        if (blk == cur) {
-                            uint32_t a = 0, e = cnt;
-                            while (a < e) {
-                                const uint32_t mid = (a + e) >> 1;
-                                if (wbuf[mid] < c) a = mid + 1u; else e = mid;
-                            }
-                            if (a < cnt && wbuf[a] == c) hit[pi] = (uint8_t)(j + 1u);
-                        }
-                        __threadfence_block();
-                        pending &= ~__ballot(blk == cur);
-                    }
+            uint8_t *hit = sm.map + GALLOP_SUB * 256u * 4u;
+            uint32_t *wbuf = reinterpret_cast<uint32_t *>(sm.raw) + (uint32_t)wv * 256u;
+            uint32_t total = 0;
+            for (uint32_t b0 = D[2]; b0 < D[3]; b0 += GALLOP_SUB) {
+                const uint32_t b1 = b0 + GALLOP_SUB < D[3] ? b0 + GALLOP_SUB : D[3];
+                __syncthreads();
+                for (uint32_t b = b0 + (uint32_t)wv; b < b1; b += 4u) {
+                    const uint32_t pb = (b - b0) * 256u;
+                    const uint32_t c = decode_block_wave(GlobalBytes{drv.payload}, drv.skip[b].byte_off, drv.skip[b + 1].byte_off,
+                                                         drv.skip[b].first_doc, [&](uint32_t ix, uint32_t id) {
+                                                             cand[pb + ix] = id;
+                                                             hit[pb + ix] = 1;
+                                                         });
+                    if (b == b1 - 1u && l == 0) sm.ncand = pb + c;
                 }
                 __syncthreads();
-            }
-            // finalise + count: wave w owns candidates [w*Q, (w+1)*Q)
-            const uint32_t quarter = (((ncand + 3u) / 4u) + 63u) & ~63u;
-            const uint32_t w0 = (uint32_t)wv * quarter;
-            const uint32_t w1 = w0 + quarter < ncand ? w0 + quarter : ncand;
-            uint32_t mine = 0;
-            for (uint32_t base = w0; base < w1; base += 64u) {
-                const uint32_t pi = base + (uint32_t)l;
-                if (pi < w1) {
-                    bool keep = hit[pi] == (uint8_t)n;
-                    if (keep && p.tomb && tomb_hit(p.tomb, p.tomb_nwords, cand[pi])) keep = false;
-                    if (keep && pi > 0 && cand[pi - 1] == cand[pi]) keep = false;   // tolerate a duplicated driver id
-                    hit[pi] = keep ? 0xFF : 0;
-                    mine += keep;
+                const uint32_t ncand = sm.ncand;
+                for (uint32_t j = 1; j < n; j++) {
+                    const ListView L = p.lists[j];
+                    const uint32_t bl = D[2 + 4 * j], bh = D[3 + 4 * j];
+                    for (uint32_t base = (uint32_t)wv * 64u; base < ncand; base += 256u) {
+                        const uint32_t pi = base + (uint32_t)l;
+                        const bool alive = pi < ncand && hit[pi] == (uint8_t)j;
+                        const uint32_t c = alive ? cand[pi] : 0u;
+                        uint32_t blk = NONE;
+                        if (alive && bl < bh) {
+                            const uint32_t ub = skip_upper_bound(L.skip, bl, bh, c);
+                            if (ub > bl) blk = ub - 1u;
+                        }
+                        unsigned long long pending = __ballot(blk != NONE);
+                        while (pending) {
+                            const int leader = __ffsll((long long)pending) - 1;
+                            const uint32_t cur = wave_bcast(blk, leader);
+                            const uint32_t cnt = decode_block_wave(GlobalBytes{L.payload}, L.skip[cur].byte_off,
+                                                                   L.skip[cur + 1].byte_off, L.skip[cur].first_doc,
+                                                                   [&](uint32_t ix, uint32_t id) { wbuf[ix] = id; });
+                            __threadfence_block();
+                            if (blk == cur) {
+                                uint32_t a = 0, e = cnt;
+                                while (a < e) {
+                                    const uint32_t mid = (a + e) >> 1;
+                                    if (wbuf[mid] < c) a = mid + 1u; else e = mid;
+                                }
+                                if (a < cnt && wbuf[a] == c) hit[pi] = (uint8_t)(j + 1u);
+                            }
+                            __threadfence_block();
+                            pending &= ~__ballot(blk == cur);
+                        }
+                    }
+                    __syncthreads();
                 }
+                // finalise + count: wave w owns candidates [w*Q, (w+1)*Q)
+                const uint32_t quarter = (((ncand + 3u) / 4u) + 63u) & ~63u;
+                const uint32_t w0 = (uint32_t)wv * quarter;
+                const uint32_t w1 = w0 + quarter < ncand ? w0 + quarter : ncand;
+                uint32_t mine = 0;
+                for (uint32_t base = w0; base < w1; base += 64u) {
+                    const uint32_t pi = base + (uint32_t)l;
+                    if (pi < w1) {
+                        bool keep = hit[pi] == (uint8_t)n;
+                        if (keep && p.tomb) {
+                            const uint32_t v = cand[pi], w = v >> 5;
+                            if (w < p.tomb_nwords && ((p.tomb[w] >> (v & 31u)) & 1u)) keep = false;
+                        }
+                        if (keep && pi > 0 && cand[pi - 1] == cand[pi]) keep = false;   // tolerate a duplicated driver id
+                        hit[pi] = keep ? 0xFF : 0;
+                        mine += keep;
+                    }
+                }
+                mine = wave_sum(mine);
+                if (l == 0) sm.wcnt[wv] = mine;
+                __syncthreads();
+                uint32_t pos = total;
+                for (int w = 0; w < wv; w++) pos += sm.wcnt[w];
+                for (uint32_t base = w0; base < w1; base += 64u) {
+                    const uint32_t pi = base + (uint32_t)l;
+                    const uint32_t m = (pi < w1 && hit[pi]) ? 1u : 0u;
+                    const uint32_t incl = wave_incl_scan(m);
+                    if (m) slot[pos + incl - 1u] = cand[pi];
+                    pos += wave_bcast(incl, 63);
+                }
+                total += sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
             }
-            mine = wave_sum(mine);
-            if (l == 0) sm.wcnt[wv] = mine;
-            __syncthreads();               // also: all waves are done with wbuf (aliases stage)
-            uint32_t pos = 0;
-            for (int w = 0; w < wv; w++) pos += sm.wcnt[w];
-            total = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
-            for (uint32_t base = w0; base < w1; base += 64u) {
-                const uint32_t pi = base + (uint32_t)l;
-                const uint32_t m = (pi < w1 && hit[pi]) ? 1u : 0u;
-                const uint32_t incl = wave_incl_scan(m);
-                if (m) sm.stage[pos + incl - 1u] = cand[pi];
-                pos += wave_bcast(incl, 63);
+            if (tid == 0) {
+                p.tile_count[tile] = total | LIST_FLAG;
+                if (total) atomicAdd(&p.sums[tile >> 6], total);
             }
             // restart the pipeline for the next tile
             if (has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
@@ -336,78 +434,99 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
                 if (DN[1] - DN[0] < ISECT_SMAX && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
             }
         }
-
-        // ---- ordered output ----
-        if (p.lookback) {
-            if (wv == 0) {
-                const unsigned long long base = lookback_exclusive(p.desc, tile, total, p.epoch);
-                if (l == 0) {
-                    sm.base = base;
-                    if (tile == p.n_tiles - 1u) *p.d_count = base + total;
-                }
-            }
-            __syncthreads();
-            const unsigned long long ob = sm.base;
-            for (uint32_t i = (uint32_t)tid; i < total; i += 256u)
-                if (ob + i < p.out_cap) p.out[ob + i] = sm.stage[i];
-        } else {
-            uint32_t *dst = p.tmp + (uint64_t)tile * p.G * 256u;
-            for (uint32_t i = (uint32_t)tid; i < total; i += 256u) dst[i] = sm.stage[i];
-            if (tid == 0) p.tile_count[tile] = total;
-        }
-        __syncthreads();      // stage / map / base are reused by the next tile
-        II2_STAMP(5)              // look-back + output
+        lds_barrier();        // map / wcnt are reused by the next tile
     }
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
 #undef II2_STAMP
 }
 
-// ---- non-lookback epilogue: offsets from a serial-chunked scan, then a copy ------------
-__global__ __launch_bounds__(1024) void k_isect_scan_counts(const uint32_t *__restrict__ cnt, uint32_t n, uint64_t *__restrict__ off,
-                                                            uint64_t *__restrict__ d_count) {
-    __shared__ uint32_t wsum[16];
-    __shared__ unsigned long long carry;
-    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry = 0ull;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024u) {
-        const uint32_t i = base + (uint32_t)tid;
-        const uint32_t v = i < n ? cnt[i] : 0u;
-        const uint32_t incl = wave_incl_scan(v);
-        if (l == 63) wsum[wv] = incl;
-        __syncthreads();
-        uint32_t pre = 0;
-        for (int w = 0; w < wv; w++) pre += wsum[w];
-        if (i < n) off[i] = carry + pre + incl - v;
-        __syncthreads();
-        if (tid == 1023) carry += (unsigned long long)pre + incl;
-        __syncthreads();
-    }
-    if (tid == 0) { off[n] = carry; *d_count = carry; }
+// ---- expand: bitmaps / id lists -> the final ascending id array -----------------------------
+// A tile's output offset = sum of the counts of the tiles before it, read off the per-64-tile
+// sums the tile kernel accumulated plus the counts inside the tile's own group of 64 — a few
+// 64-wide loads, once per expand workgroup (it then walks consecutive tiles), instead of a
+// separate scan launch.  (Sums per 64 tiles keep the atomics spread: 64 adds per address.)
+__device__ __forceinline__ unsigned long long tile_offset(const IntersectParams &p, uint32_t tile) {
+    const uint32_t l = (uint32_t)lane_id();
+    unsigned long long off = 0;
+    const uint32_t e1 = tile >> 6;
+    for (uint32_t i = 0; i < e1; i += 64u) off += wave_sum(i + l < e1 ? p.sums[i + l] : 0u);
+    const uint32_t a0 = e1 << 6;
+    off += wave_sum(a0 + l < tile ? (p.tile_count[a0 + l] & ~LIST_FLAG) : 0u);
+    return off;
 }
 
-__global__ __launch_bounds__(256) void k_isect_copy(IntersectParams p, const uint64_t *__restrict__ off) {
-    const uint32_t tile = blockIdx.x;
-    const uint32_t c = p.tile_count[tile];
-    const uint32_t *src = p.tmp + (uint64_t)tile * p.G * 256u;
-    const uint64_t ob = off[tile];
-    for (uint32_t i = threadIdx.x; i < c; i += 256u)
-        if (ob + i < p.out_cap) p.out[ob + i] = src[i];
+__global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
+    __shared__ unsigned long long s_off;
+    __shared__ uint32_t stage[ISECT_GMAX * 256u];
+    __shared__ uint32_t wsum[4];
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const uint32_t stride = desc_stride(p.n_lists);
+    // workgroup w expands the consecutive tiles [w*per, (w+1)*per): one offset lookup, then a running sum
+    const uint32_t per = (p.n_tiles + gridDim.x - 1u) / gridDim.x;
+    const uint32_t tbeg = blockIdx.x * per;
+    const uint32_t tend = tbeg + per < p.n_tiles ? tbeg + per : p.n_tiles;
+    if (tbeg >= tend) return;
+    if (wv == 0) {
+        const unsigned long long o = tile_offset(p, tbeg);
+        if (l == 0) s_off = o;
+    }
+    __syncthreads();
+    unsigned long long running = s_off;
+    for (uint32_t tile = tbeg; tile < tend; tile++) {
+        const uint32_t cf = p.tile_count[tile];
+        const uint32_t c = cf & ~LIST_FLAG;
+        const uint64_t ob = running;
+        running += c;
+        if (tile == p.n_tiles - 1u && tid == 0) *p.d_count = running;
+        if (c == 0) continue;
+        const uint32_t *slot = p.tmp + (uint64_t)tile * p.slot_words;
+        if (cf & LIST_FLAG) {
+            for (uint32_t i = (uint32_t)tid; i < c; i += 256u)
+                if (ob + i < p.out_cap) p.out[ob + i] = slot[i];
+            continue;
+        }
+        const uint32_t *r = p.ranges + (uint64_t)tile * stride;
+        const uint32_t mlo = r[0] & ~31u;
+        const uint32_t nwords = ((r[1] - mlo) >> 5) + 1u;
+        uint32_t done = 0;                       // ids written by earlier rounds
+        for (uint32_t w0 = 0; w0 < nwords; w0 += 256u) {
+            const uint32_t wi = w0 + (uint32_t)tid;
+            uint32_t word = wi < nwords ? slot[wi] : 0u;
+            const uint32_t pc = (uint32_t)__popc(word);
+            const uint32_t incl = wave_incl_scan(pc);
+            __syncthreads();                      // stage / wsum are free (previous round fully written out)
+            if (l == 63) wsum[wv] = incl;
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+            for (int w = 0; w < 4; w++) { if (w < wv) pre += wsum[w]; tot += wsum[w]; }
+            uint32_t q = pre + incl - pc;
+            const uint32_t basedoc = mlo + 32u * wi;
+            while (word) {
+                const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+                stage[q++] = basedoc + bit;
+                word &= word - 1u;
+            }
+            __syncthreads();
+            for (uint32_t i = (uint32_t)tid; i < tot; i += 256u)
+                if (ob + done + i < p.out_cap) p.out[ob + done + i] = stage[i];
+            done += tot;
+        }
+        __syncthreads();
+    }
 }
 
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
     const uint64_t nthr = (uint64_t)p.n_tiles * p.n_lists;
-    hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, p);
+    const uint64_t pthr = std::max<uint64_t>(nthr * 64u, p.n_sums);
+    hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
     const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
     if (ev0) (void)hipEventRecord(ev0, s);
     hipLaunchKernelGGL(k_isect_tiles, dim3(grid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);
-    if (!p.lookback) {
-        hipLaunchKernelGGL(k_isect_scan_counts, dim3(1), dim3(1024), 0, s, (const uint32_t *)p.tile_count, p.n_tiles, d_tile_off, p.d_count);
-        hipLaunchKernelGGL(k_isect_copy, dim3(p.n_tiles), dim3(256), 0, s, p, (const uint64_t *)d_tile_off);
-    }
+    const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
+    hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 

@@ -30,16 +30,17 @@ for lb in (1, 0):
         alg = seg.info.n_bytes + 8 * seg.info.n_blocks + 4 * n
         print(f"  g={g} {dt*1e6:.1f} us/step  {(a.size+b.size)/dt/1e9:.1f} Gpostings/s  alg {alg/dt/1e12:.3f} TB/s", flush=True)
     ctx.set_option("intersect.g", 0)
-# per-phase cycle shares (diagnostic build path)
+# per-phase cycle shares (diagnostic path)
 import ctypes as C
-ctx.set_option("intersect.lookback", 1); ctx.set_option("debug.stamps", 1)
+ctx.set_option("debug.stamps", 1)
 ctx.intersect_async([(seg, 0), (seg, 1)], None, out, dcnt); ctx.sync()
-buf = (C.c_uint64 * (1024 * 8))()
-ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, 1024 * 8))
+nwg = 1280
+buf = (C.c_uint64 * (nwg * 8))()
+ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, nwg * 8))
 arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
-names = ["commit+bar+prefetch", "decode", "bar-after-decode", "pass1", "pass2", "lookback+out", "-", "-"]
+names = ["clear+commit+bar+prefetch", "decode", "bar-after-decode", "finalise", "-", "-", "-", "-"]
 tot = arr.sum(axis=1).mean()
-print("mean cycles per WG", tot, "tiles/WG", 16275 / 1024)
-for i, nm in enumerate(names[:6]):
-    print(f"  {nm:22s} {arr[:, i].mean():10.0f}  {100 * arr[:, i].mean() / tot:5.1f}%")
+print("mean cycles per WG", tot)
+for i, nm in enumerate(names[:4]):
+    print(f"  {nm:26s} {arr[:, i].mean():10.0f}  {100 * arr[:, i].mean() / tot:5.1f}%")
 ctx.set_option("debug.stamps", 0)
