@@ -101,6 +101,11 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const ui
 int ii2_seg_decode(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *post_off, uint32_t *values, int where);
 /* Copy the DV1 arrays out (any of the three may be NULL). */
 int ii2_seg_export(ii2_ctx *ctx, const ii2_seg *seg, uint32_t *blk_off, ii2_skip *skip, uint8_t *payload);
+/* A view of `src` with n_out term slots that shares src's skip table and payload: slot i holds list
+ * src_list[i] of src, or is empty when src_list[i] < 0.  This is how the host aligns the term ids of
+ * k segments before a merge (terms a segment lacks become empty slots) and drops emptied terms after
+ * one.  Selected indices must ascend and may only skip empty lists between two selected ones. */
+int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64_t *src_list, ii2_seg **out);
 int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info);
 void ii2_seg_free(ii2_seg *seg);
 

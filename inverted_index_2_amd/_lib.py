@@ -47,6 +47,7 @@ PROTOTYPES = {
     "ii2_seg_import": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_int, vpp]),
     "ii2_seg_decode": (C.c_int, [vp, vp, vp, vp, C.c_int]),
     "ii2_seg_export": (C.c_int, [vp, vp, vp, vp, vp]),
+    "ii2_seg_select": (C.c_int, [vp, vp, C.c_uint64, vp, vpp]),
     "ii2_seg_get_info": (C.c_int, [vp, C.POINTER(SegInfo)]),
     "ii2_seg_free": (None, [vp]),
     "ii2_tomb_create": (C.c_int, [vp, vp, C.c_uint64, C.c_int, vpp]),

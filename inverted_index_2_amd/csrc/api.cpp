@@ -206,14 +206,21 @@ int ii2_copy_d2h(ii2_ctx *ctx, void *dst, const void *src, size_t bytes) {
 static void seg_release(ii2_seg *s) {
     if (!s) return;
     if (s->d_blk_off) (void)hipFree(s->d_blk_off);
-    if (s->d_skip) (void)hipFree(s->d_skip);
-    if (s->d_payload) (void)hipFree(s->d_payload);
+    if (!s->store) {          // not yet handed to a store: still owned directly
+        if (s->d_skip) (void)hipFree(s->d_skip);
+        if (s->d_payload) (void)hipFree(s->d_payload);
+    }
     if (s->d_last_doc) (void)hipFree(s->d_last_doc);
     delete s;
 }
 
 // reads back the driver-choice statistics of single-list segments and the host blk_off mirror
 static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
+    if (!seg->store) {
+        seg->store = std::make_shared<ii2_seg_store>();
+        seg->store->d_skip = seg->d_skip;
+        seg->store->d_payload = seg->d_payload;
+    }
     if (hipMalloc((void **)&seg->d_last_doc, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_last_doc, ctx->stream));
@@ -385,6 +392,52 @@ int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info) {
     info->n_postings = seg->n_postings;
     info->n_blocks = seg->n_blocks;
     info->n_bytes = seg->n_bytes;
+    return II2_OK;
+}
+
+int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64_t *src_list, ii2_seg **out) {
+    if (!ctx || !src || !out || (n_out && !src_list) || src->ctx != ctx) return fail(ctx, II2_EINVAL, "ii2_seg_select: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    // selected lists must ascend, and only empty lists may be skipped between two selected ones
+    std::vector<uint32_t> blk(n_out + 1, 0);
+    int64_t prev = -1;
+    uint32_t prev_end = 0;
+    bool any = false;
+    for (uint64_t i = 0; i < n_out; i++) {
+        const int64_t j = src_list[i];
+        if (j < 0) continue;
+        if ((uint64_t)j >= src->n_lists || j <= prev) return fail(ctx, II2_EINVAL, "ii2_seg_select: list indices must ascend");
+        const uint32_t b0 = src->h_blk_off[j], b1 = src->h_blk_off[j + 1];
+        if (any && b0 != prev_end) return fail(ctx, II2_EINVAL, "ii2_seg_select: a non-empty list lies between two selected lists");
+        prev = j;
+        prev_end = b1;
+        any = true;
+    }
+    uint32_t next = any ? prev_end : 0u;
+    blk[n_out] = next;
+    for (uint64_t i = n_out; i-- > 0;) {
+        const int64_t j = src_list[i];
+        if (j >= 0) next = src->h_blk_off[j];
+        blk[i] = next;
+    }
+    std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
+    if (!seg) return II2_ENOMEM;
+    seg->ctx = ctx;
+    seg->store = src->store;
+    seg->d_skip = src->d_skip;
+    seg->d_payload = src->d_payload;
+    seg->n_lists = n_out;
+    seg->n_blocks = src->n_blocks;
+    seg->n_bytes = src->n_bytes;
+    seg->n_postings = src->n_postings;      // upper bound: postings of unselected window lists are still counted
+    if (hipMalloc((void **)&seg->d_blk_off, (n_out + 1) * sizeof(uint32_t)) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off, blk.data(), (n_out + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = seg_finish(ctx, seg.get());
+    if (rc) return rc;
+    *out = seg.release();
     return II2_OK;
 }
 

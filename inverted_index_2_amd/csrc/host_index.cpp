@@ -1,0 +1,449 @@
+// host_index.cpp — host-side mirror of the reference's Shard / InvertedIndex operations above
+// the C ABI (include/ii2.h).  The reference is Go; this image has no Go toolchain, so the host
+// layer is C++ with the reference's names, argument meaning and error behaviour, and the posting
+// work of every operation goes to the GPU through the same entry points a cgo binding would
+// use.  Segments live in HBM (DV1); term dictionaries are plain sorted byte strings here (the
+// reference's vellum FST, files, locks and pools are out of scope — SURVEY.md §8).
+//
+//   Shard.Put / Read / Remove / Merge / MinMax      shard.go:33-298
+//   Segments.add ordering                            segments.go:56-64
+//   RemovedLists.Put / Values / Sync                 removed_list.go:36-71
+//   InvertedIndex.Put / Read / Merge / PutRemoved / PrefixSearch   inverted_index.go:41-340
+//   shardKey                                         shard.go:362-378
+//   Intersect(terms)                                 additive
+//
+// A small C facade (ii2h_*) at the bottom lets the Python tests replay the reference's test
+// scripts against this layer.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/ii2.h"
+
+namespace ii2h {
+
+using Term = std::string;      // raw bytes; std::string compares like bytes.Compare (unsigned char order)
+
+struct TermValues {            // file/types.go:9-12
+    Term term;
+    std::vector<uint32_t> values;
+};
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+static void ck(ii2_ctx *ctx, int rc, const char *what) {
+    if (rc) throw Error(std::string(what) + ": " + ii2_last_error(ctx));     // fmt.Errorf("…: %w", err)
+}
+
+static bool term_less(const Term &a, const Term &b) {
+    const size_t m = std::min(a.size(), b.size());
+    const int c = m ? std::memcmp(a.data(), b.data(), m) : 0;
+    return c ? c < 0 : a.size() < b.size();
+}
+
+struct SegHandle {
+    ii2_seg *h = nullptr;
+    explicit SegHandle(ii2_seg *s) : h(s) {}
+    ~SegHandle() { ii2_seg_free(h); }
+    SegHandle(const SegHandle &) = delete;
+};
+
+struct Segment {               // segments.go:16-24
+    int64_t key;               // unix-ns key
+    std::vector<Term> terms;   // sorted
+    std::shared_ptr<SegHandle> seg;   // terms.size() lists
+    bool merging = false;
+};
+
+static int64_t now_ns() {
+    static int64_t last = 0;
+    int64_t t = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+    if (t <= last) t = last + 1;
+    last = t;
+    return t;
+}
+
+class Shard {
+   public:
+    explicit Shard(ii2_ctx *ctx) : ctx_(ctx) {}
+
+    // shard.go:33-67 — one direct segment, every term -> [val]
+    void Put(std::vector<Term> terms, uint32_t val) {
+        std::sort(terms.begin(), terms.end(), term_less);
+        terms.erase(std::unique(terms.begin(), terms.end()), terms.end());
+        std::vector<uint64_t> off(terms.size() + 1);
+        for (size_t i = 0; i <= terms.size(); i++) off[i] = i;
+        std::vector<uint32_t> vals(terms.size(), val);
+        ii2_seg *s = nullptr;
+        ck(ctx_, ii2_seg_encode(ctx_, terms.size(), off.data(), vals.data(), II2_HOST, &s), "s: put");
+        add(Segment{now_ns(), std::move(terms), std::make_shared<SegHandle>(s)});
+    }
+
+    // shard.go:72-75 + makeIterator :253-278 — merged view of all segments, [min,max] inclusive, no tombstones
+    std::vector<TermValues> Read(const Term *min, const Term *max) const {
+        std::vector<const Segment *> segs;
+        for (auto &s : segments_) segs.push_back(s.get());
+        return merged(segs, min, max, nullptr);
+    }
+
+    // shard.go:78-105
+    void Remove(const std::vector<uint32_t> &values) {
+        if (values.empty()) return;
+        std::vector<int64_t> ts{now_ns()};
+        for (auto &s : segments_) ts.push_back(s->key);
+        removed_sync(ts);
+        removed_[now_ns()] = values;
+    }
+
+    // removed_list.go:44-54
+    std::vector<uint32_t> RemovedValues() const {
+        std::vector<uint32_t> r;
+        for (auto &kv : removed_) r.insert(r.end(), kv.second.begin(), kv.second.end());
+        std::sort(r.begin(), r.end());
+        return r;
+    }
+
+    // shard.go:127-245
+    int Merge(int reqCount, int mCount) {
+        if ((int)segments_.size() < reqCount) return 0;
+        std::vector<std::shared_ptr<Segment>> picked;
+        for (auto &s : segments_) {
+            if ((int)picked.size() == mCount) break;
+            if (!s->merging) { s->merging = true; picked.push_back(s); }
+        }
+        if (picked.size() < 2) return 0;           // NB: a lone picked flag stays set (shard.go:149-151)
+        std::vector<const Segment *> segs;
+        for (auto &s : picked) segs.push_back(s.get());
+        const std::vector<uint32_t> removed = RemovedValues();
+        Segment out;
+        const bool any = merged_segment(segs, removed, &out);
+        if (any) add(std::move(out));              // lazy writer: nothing survives -> no segment (shard.go:219-225)
+        segments_.erase(std::remove_if(segments_.begin(), segments_.end(),
+                                       [&](const std::shared_ptr<Segment> &s) {
+                                           return std::find(picked.begin(), picked.end(), s) != picked.end();
+                                       }),
+                        segments_.end());
+        return (int)picked.size();
+    }
+
+    // shard.go:280-298
+    bool MinMax(Term *mn, Term *mx) const {
+        bool any = false;
+        for (auto &s : segments_) {
+            if (s->terms.empty()) continue;
+            if (!any || term_less(s->terms.front(), *mn)) *mn = s->terms.front();
+            if (!any || term_less(*mx, s->terms.back())) *mx = s->terms.back();
+            any = true;
+        }
+        return any;
+    }
+
+    size_t SegmentCount() const { return segments_.size(); }
+
+   private:
+    // segments.go:56-64 — insert before the first segment with terms >= new.terms
+    void add(Segment s) {
+        auto sp = std::make_shared<Segment>(std::move(s));
+        size_t pos = 0;
+        while (pos < segments_.size() && segments_[pos]->terms.size() < sp->terms.size()) pos++;
+        segments_.insert(segments_.begin() + pos, sp);
+    }
+
+    void removed_sync(const std::vector<int64_t> &ts) {   // removed_list.go:57-71
+        if (ts.empty()) return;
+        const int64_t oldest = *std::min_element(ts.begin(), ts.end());
+        for (auto it = removed_.begin(); it != removed_.end();) it = it->first < oldest ? removed_.erase(it) : ++it;
+    }
+
+    // Term alignment (host; file.CompareTermValues order): union of the segments' terms inside [min,max]
+    // and, per segment, an aligned view with one slot per union term.
+    struct Aligned {
+        std::vector<Term> terms;
+        std::vector<std::shared_ptr<SegHandle>> views;
+    };
+    Aligned align(const std::vector<const Segment *> &segs, const Term *min, const Term *max) const {
+        Aligned a;
+        for (auto *s : segs)
+            for (auto &t : s->terms) {
+                if (min && term_less(t, *min)) continue;
+                if (max && term_less(*max, t)) continue;
+                a.terms.push_back(t);
+            }
+        std::sort(a.terms.begin(), a.terms.end(), term_less);
+        a.terms.erase(std::unique(a.terms.begin(), a.terms.end()), a.terms.end());
+        for (auto *s : segs) {
+            std::vector<int64_t> src(a.terms.size(), -1);
+            size_t j = 0;
+            bool any = false;
+            for (size_t i = 0; i < a.terms.size(); i++) {
+                while (j < s->terms.size() && term_less(s->terms[j], a.terms[i])) j++;
+                if (j < s->terms.size() && s->terms[j] == a.terms[i]) { src[i] = (int64_t)j; any = true; }
+            }
+            if (!any) continue;                    // segment has nothing in range: skipped (shard.go:257-261)
+            ii2_seg *v = nullptr;
+            ck(ctx_, ii2_seg_select(ctx_, s->seg->h, a.terms.size(), src.data(), &v), "index read");
+            a.views.push_back(std::make_shared<SegHandle>(v));
+        }
+        return a;
+    }
+
+    std::vector<TermValues> merged(const std::vector<const Segment *> &segs, const Term *min, const Term *max,
+                                   const std::vector<uint32_t> *removed) const {
+        std::vector<TermValues> out;
+        Aligned a = align(segs, min, max);
+        if (a.views.empty()) return out;
+        ii2_tomb *tomb = nullptr;
+        if (removed && !removed->empty()) ck(ctx_, ii2_tomb_create(ctx_, removed->data(), removed->size(), II2_HOST, &tomb), "s: merge");
+        std::vector<const ii2_seg *> hs;
+        uint64_t cap = 0;
+        for (auto &v : a.views) {
+            hs.push_back(v->h);
+            ii2_seg_info info;
+            ii2_seg_get_info(v->h, &info);
+            cap += info.n_postings;
+        }
+        const uint64_t T = a.terms.size();
+        void *d_off = nullptr, *d_vals = nullptr;
+        ck(ctx_, ii2_dev_alloc(ctx_, (T + 1) * 8, &d_off), "s: merge");
+        ck(ctx_, ii2_dev_alloc(ctx_, (cap + 1) * 4, &d_vals), "s: merge");
+        ii2_merge_stats st;
+        int rc = ii2_merge_segments(ctx_, (uint32_t)hs.size(), hs.data(), tomb, (uint64_t *)d_off, (uint32_t *)d_vals, cap + 1, &st);
+        std::vector<uint64_t> off(T + 1);
+        std::vector<uint32_t> vals(st.n_out);
+        if (!rc) rc = ii2_copy_d2h(ctx_, off.data(), d_off, (T + 1) * 8);
+        if (!rc && st.n_out) rc = ii2_copy_d2h(ctx_, vals.data(), d_vals, st.n_out * 4);
+        ii2_dev_free(ctx_, d_off);
+        ii2_dev_free(ctx_, d_vals);
+        ii2_tomb_free(tomb);
+        ck(ctx_, rc, "s: merge");
+        for (uint64_t t = 0; t < T; t++) {
+            TermValues tv{a.terms[t], std::vector<uint32_t>(vals.begin() + off[t], vals.begin() + off[t + 1])};
+            if (removed && tv.values.empty()) continue;      // merge drops emptied terms (shard.go:192-194)
+            out.push_back(std::move(tv));
+        }
+        return out;
+    }
+
+    // Merge into a new device-resident segment; false when no term survives.
+    bool merged_segment(const std::vector<const Segment *> &segs, const std::vector<uint32_t> &removed, Segment *out) const {
+        Aligned a = align(segs, nullptr, nullptr);
+        if (a.views.empty()) return false;
+        ii2_tomb *tomb = nullptr;
+        if (!removed.empty()) ck(ctx_, ii2_tomb_create(ctx_, removed.data(), removed.size(), II2_HOST, &tomb), "s: merge");
+        std::vector<const ii2_seg *> hs;
+        for (auto &v : a.views) hs.push_back(v->h);
+        ii2_seg *m = nullptr;
+        ii2_merge_stats st;
+        int rc = ii2_merge_segments_to_seg(ctx_, (uint32_t)hs.size(), hs.data(), tomb, &m, &st);
+        ii2_tomb_free(tomb);
+        ck(ctx_, rc, "s: merge");
+        if (!m) return false;
+        SegHandle full(m);
+        // drop the terms that lost every posting: compacted view over the merged segment
+        const uint64_t T = a.terms.size();
+        std::vector<uint64_t> off(T + 1);
+        ck(ctx_, ii2_seg_decode(ctx_, m, off.data(), nullptr, II2_HOST), "s: merge");
+        std::vector<int64_t> src;
+        for (uint64_t t = 0; t < T; t++)
+            if (off[t + 1] > off[t]) { src.push_back((int64_t)t); out->terms.push_back(a.terms[t]); }
+        ii2_seg *c = nullptr;
+        ck(ctx_, ii2_seg_select(ctx_, m, src.size(), src.data(), &c), "s: merge");
+        out->seg = std::make_shared<SegHandle>(c);
+        out->key = now_ns();
+        return true;
+    }
+
+    ii2_ctx *ctx_;
+    std::vector<std::shared_ptr<Segment>> segments_;       // sorted by term count
+    std::map<int64_t, std::vector<uint32_t>> removed_;     // RemovedLists.lists
+};
+
+// shard.go:362-378
+static uint32_t shard_key(const Term &t) {
+    uint8_t a = 0, b = 0;
+    if (t.size() >= 2) { a = (uint8_t)t[0]; b = (uint8_t)t[1]; }
+    return (uint32_t)((uint16_t)((uint16_t)(a << 8) + b) >> 6);
+}
+
+class InvertedIndex {
+   public:
+    explicit InvertedIndex(ii2_ctx *ctx) : ctx_(ctx) {}
+
+    void Put(const std::vector<Term> &terms, uint32_t val) {                  // inverted_index.go:113-145
+        std::map<uint32_t, std::vector<Term>> groups;
+        for (auto &t : terms) groups[shard_key(t)].push_back(t);
+        for (auto &g : groups) shard(g.first).Put(g.second, val);
+    }
+    void PutRemoved(const std::vector<uint32_t> &values) {                    // inverted_index.go:41-55
+        for (auto &s : shards_) s.second->Remove(values);
+    }
+    int64_t Merge(int reqCount, int mCount, int /*concurrency*/) {            // inverted_index.go:62-109
+        int64_t n = 0;
+        for (auto &s : shards_) n += s.second->Merge(reqCount, mCount);
+        return n;
+    }
+    std::vector<TermValues> Read(const Term *min, const Term *max) const {    // inverted_index.go:300-340
+        std::vector<TermValues> out;
+        for (auto &s : shards_) {                                             // ascending shard key
+            Term mn, mx;
+            if (!s.second->MinMax(&mn, &mx)) continue;
+            if (min && term_less(mx, *min)) continue;
+            if (max && term_less(*max, mn)) continue;
+            auto part = s.second->Read(min, max);
+            out.insert(out.end(), std::make_move_iterator(part.begin()), std::make_move_iterator(part.end()));
+        }
+        return out;
+    }
+    std::map<Term, std::vector<uint32_t>> PrefixSearch(std::vector<Term> prefixes) const {   // inverted_index.go:192-295
+        std::sort(prefixes.begin(), prefixes.end(), term_less);
+        std::map<Term, std::vector<std::vector<uint32_t>>> found;
+        for (auto &s : shards_) {
+            Term mn, mx;
+            if (!s.second->MinMax(&mn, &mx)) continue;
+            std::vector<Term> mine;
+            for (auto &p : prefixes) {
+                size_t l = std::min(p.size(), mn.size());
+                if (p.compare(0, l, mn, 0, l) < 0) continue;
+                l = std::min(p.size(), mx.size());
+                if (p.compare(0, l, mx, 0, l) > 0) continue;
+                mine.push_back(p);
+            }
+            if (mine.empty()) continue;
+            const Term &greatest = mine.back();
+            for (auto &tv : s.second->Read(&mine.front(), nullptr)) {
+                const Term tp = tv.term.substr(0, std::min(tv.term.size(), greatest.size()));
+                if (term_less(greatest, tp)) break;
+                for (auto &p : mine)
+                    if (tv.term.compare(0, p.size(), p) == 0 && tv.term.size() >= p.size()) found[p].push_back(tv.values);
+            }
+        }
+        std::map<Term, std::vector<uint32_t>> out;
+        for (auto &f : found) out[f.first] = lists_op(true, f.second);        // :288-292 sort + compact, on the GPU
+        return out;
+    }
+    // additive: ids present under every term
+    std::vector<uint32_t> Intersect(const std::vector<Term> &terms) const {
+        std::vector<std::vector<uint32_t>> lists;
+        for (auto &t : terms) {
+            std::vector<uint32_t> v;
+            auto it = shards_.find(shard_key(t));
+            if (it != shards_.end())
+                for (auto &tv : it->second->Read(&t, &t)) v = tv.values;
+            lists.push_back(std::move(v));
+        }
+        return lists_op(false, lists);
+    }
+    size_t ShardCount() const { return shards_.size(); }
+    Shard *OnlyShard() { return shards_.empty() ? nullptr : shards_.begin()->second.get(); }
+
+   private:
+    Shard &shard(uint32_t key) {
+        auto it = shards_.find(key);
+        if (it == shards_.end()) it = shards_.emplace(key, std::make_unique<Shard>(ctx_)).first;
+        return *it->second;
+    }
+    std::vector<uint32_t> lists_op(bool is_union, const std::vector<std::vector<uint32_t>> &lists) const {
+        std::vector<uint64_t> off(lists.size() + 1, 0);
+        std::vector<uint32_t> flat;
+        for (size_t i = 0; i < lists.size(); i++) {
+            flat.insert(flat.end(), lists[i].begin(), lists[i].end());
+            off[i + 1] = flat.size();
+        }
+        std::vector<uint32_t> out(flat.size() + 1);
+        uint64_t n = 0;
+        if (lists.empty()) return {};
+        int rc = is_union ? ii2_union_host(ctx_, (uint32_t)lists.size(), off.data(), flat.data(), nullptr, 0, out.data(), out.size(), &n)
+                          : ii2_intersect_host(ctx_, (uint32_t)lists.size(), off.data(), flat.data(), nullptr, 0, out.data(), out.size(), &n);
+        ck(ctx_, rc, is_union ? "prefix search" : "intersect");
+        out.resize(n);
+        return out;
+    }
+    ii2_ctx *ctx_;
+    std::map<uint32_t, std::unique_ptr<Shard>> shards_;    // sorted by key, like ii.shards
+};
+
+}  // namespace ii2h
+
+// ---- C facade for the Python tests ----------------------------------------------------------
+using namespace ii2h;
+
+struct ii2h_target {
+    std::unique_ptr<Shard> shard;
+    std::unique_ptr<InvertedIndex> index;
+    std::string err;
+    std::vector<TermValues> result;     // last Read / PrefixSearch result
+    std::vector<uint32_t> ids;          // last Intersect / RemovedValues result
+};
+
+static std::vector<Term> unpack_terms(const uint8_t *bytes, const uint64_t *off, uint64_t n) {
+    std::vector<Term> t(n);
+    for (uint64_t i = 0; i < n; i++) t[i].assign((const char *)bytes + off[i], off[i + 1] - off[i]);
+    return t;
+}
+
+#define H_TRY(t, ...)                                   \
+    try { __VA_ARGS__; return 0; }                      \
+    catch (const std::exception &e) { (t)->err = e.what(); return -1; }
+
+extern "C" {
+
+ii2h_target *ii2h_create(ii2_ctx *ctx, int is_index) {
+    auto *t = new ii2h_target();
+    if (is_index) t->index = std::make_unique<InvertedIndex>(ctx);
+    else t->shard = std::make_unique<Shard>(ctx);
+    return t;
+}
+void ii2h_destroy(ii2h_target *t) { delete t; }
+const char *ii2h_last_error(const ii2h_target *t) { return t->err.c_str(); }
+
+int ii2h_put(ii2h_target *t, const uint8_t *bytes, const uint64_t *off, uint64_t n, uint32_t val) {
+    H_TRY(t, { auto terms = unpack_terms(bytes, off, n); if (t->index) t->index->Put(terms, val); else t->shard->Put(terms, val); })
+}
+int ii2h_remove(ii2h_target *t, const uint32_t *vals, uint64_t n) {
+    H_TRY(t, { std::vector<uint32_t> v(vals, vals + n); if (t->index) t->index->PutRemoved(v); else t->shard->Remove(v); })
+}
+int ii2h_merge(ii2h_target *t, int req, int m, int concurrency, int64_t *merged) {
+    H_TRY(t, { *merged = t->index ? t->index->Merge(req, m, concurrency) : t->shard->Merge(req, m); })
+}
+// min/max: NULL pointer = nil
+int ii2h_read(ii2h_target *t, const uint8_t *mn, uint64_t mnl, int has_min, const uint8_t *mx, uint64_t mxl, int has_max, uint64_t *n_terms) {
+    H_TRY(t, {
+        Term a((const char *)mn, has_min ? mnl : 0), b((const char *)mx, has_max ? mxl : 0);
+        t->result = t->index ? t->index->Read(has_min ? &a : nullptr, has_max ? &b : nullptr)
+                             : t->shard->Read(has_min ? &a : nullptr, has_max ? &b : nullptr);
+        *n_terms = t->result.size();
+    })
+}
+int ii2h_prefix_search(ii2h_target *t, const uint8_t *bytes, const uint64_t *off, uint64_t n, uint64_t *n_found) {
+    H_TRY(t, {
+        t->result.clear();
+        for (auto &kv : t->index->PrefixSearch(unpack_terms(bytes, off, n))) t->result.push_back(TermValues{kv.first, kv.second});
+        *n_found = t->result.size();
+    })
+}
+int ii2h_intersect(ii2h_target *t, const uint8_t *bytes, const uint64_t *off, uint64_t n, uint64_t *n_ids) {
+    H_TRY(t, { t->ids = t->index->Intersect(unpack_terms(bytes, off, n)); *n_ids = t->ids.size(); })
+}
+int ii2h_removed_values(ii2h_target *t, uint64_t *n_ids) {
+    H_TRY(t, { Shard *s = t->shard ? t->shard.get() : t->index->OnlyShard(); t->ids = s ? s->RemovedValues() : std::vector<uint32_t>(); *n_ids = t->ids.size(); })
+}
+uint64_t ii2h_result_term_len(const ii2h_target *t, uint64_t i) { return t->result[i].term.size(); }
+uint64_t ii2h_result_values_len(const ii2h_target *t, uint64_t i) { return t->result[i].values.size(); }
+void ii2h_result_copy(const ii2h_target *t, uint64_t i, uint8_t *term, uint32_t *values) {
+    std::memcpy(term, t->result[i].term.data(), t->result[i].term.size());
+    if (!t->result[i].values.empty()) std::memcpy(values, t->result[i].values.data(), t->result[i].values.size() * 4);
+}
+void ii2h_ids_copy(const ii2h_target *t, uint32_t *out) {
+    if (!t->ids.empty()) std::memcpy(out, t->ids.data(), t->ids.size() * 4);
+}
+uint64_t ii2h_segment_count(const ii2h_target *t) { return t->shard ? t->shard->SegmentCount() : 0; }
+uint64_t ii2h_shard_count(const ii2h_target *t) { return t->index ? t->index->ShardCount() : 1; }
+
+}  // extern "C"

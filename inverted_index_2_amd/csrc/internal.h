@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -42,8 +43,19 @@ struct ii2_ctx {
     int cu_count = 256;
 };
 
+// skip table + payload of one encoded segment; shared by the views made with ii2_seg_select
+struct ii2_seg_store {
+    ii2_skip *d_skip = nullptr;
+    uint8_t *d_payload = nullptr;
+    ~ii2_seg_store() {
+        if (d_skip) (void)hipFree(d_skip);
+        if (d_payload) (void)hipFree(d_payload);
+    }
+};
+
 struct ii2_seg {
     ii2_ctx *ctx = nullptr;
+    std::shared_ptr<ii2_seg_store> store;   // owns d_skip / d_payload
     uint64_t n_lists = 0, n_postings = 0, n_blocks = 0, n_bytes = 0;
     uint32_t *d_blk_off = nullptr;   // [n_lists+1]
     ii2_skip *d_skip = nullptr;      // [n_blocks+1]

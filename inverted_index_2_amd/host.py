@@ -1,0 +1,168 @@
+"""Python face of the C++ host mirror (csrc/host_index.cpp): the reference's Shard and
+InvertedIndex operations — Put / Read / Merge / Remove (PutRemoved) / PrefixSearch, plus the
+additive Intersect — with every posting operation executed on the GPU through the C ABI.
+Segments stay in HBM; terms are byte strings.  Errors surface as HostError with the
+reference-style "s: merge: …" prefix."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .engine import Context
+
+vp = C.c_void_p
+u64p = C.POINTER(C.c_uint64)
+
+
+class HostError(RuntimeError):
+    pass
+
+
+_typed = False
+
+
+def _lib_typed():
+    global _typed
+    lib = _lib.load()
+    if not _typed:
+        lib.ii2h_create.restype = vp
+        lib.ii2h_create.argtypes = [vp, C.c_int]
+        lib.ii2h_destroy.argtypes = [vp]
+        lib.ii2h_last_error.restype = C.c_char_p
+        lib.ii2h_last_error.argtypes = [vp]
+        lib.ii2h_put.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint32]
+        lib.ii2h_remove.argtypes = [vp, vp, C.c_uint64]
+        lib.ii2h_merge.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64)]
+        lib.ii2h_read.argtypes = [vp, C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int, u64p]
+        lib.ii2h_prefix_search.argtypes = [vp, vp, vp, C.c_uint64, u64p]
+        lib.ii2h_intersect.argtypes = [vp, vp, vp, C.c_uint64, u64p]
+        lib.ii2h_removed_values.argtypes = [vp, u64p]
+        for f in ("ii2h_result_term_len", "ii2h_result_values_len"):
+            getattr(lib, f).restype = C.c_uint64
+            getattr(lib, f).argtypes = [vp, C.c_uint64]
+        lib.ii2h_result_copy.argtypes = [vp, C.c_uint64, vp, vp]
+        lib.ii2h_ids_copy.argtypes = [vp, vp]
+        for f in ("ii2h_segment_count", "ii2h_shard_count"):
+            getattr(lib, f).restype = C.c_uint64
+            getattr(lib, f).argtypes = [vp]
+        _typed = True
+    return lib
+
+
+def _pack(terms: List[bytes]):
+    off = np.zeros(len(terms) + 1, np.uint64)
+    if terms:
+        off[1:] = np.cumsum([len(t) for t in terms])
+    blob = np.frombuffer(b"".join(terms) + b"\0", dtype=np.uint8).copy()
+    return blob, off
+
+
+class _Target:
+    def __init__(self, ctx: Context, is_index: bool):
+        self.lib = _lib_typed()
+        self.ctx = ctx
+        self.h = self.lib.ii2h_create(ctx.h, 1 if is_index else 0)
+
+    def _ck(self, rc: int) -> None:
+        if rc:
+            raise HostError((self.lib.ii2h_last_error(self.h) or b"").decode())
+
+    def close(self) -> None:
+        if self.h:
+            self.lib.ii2h_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.close()
+        except Exception:
+            pass
+
+    def put(self, terms: List[bytes], val: int) -> None:
+        blob, off = _pack(list(terms))
+        self._ck(self.lib.ii2h_put(self.h, blob.ctypes.data, off.ctypes.data, len(terms), val))
+
+    def _results(self, n: int) -> List[Tuple[bytes, List[int]]]:
+        out = []
+        for i in range(n):
+            tl = self.lib.ii2h_result_term_len(self.h, i)
+            vl = self.lib.ii2h_result_values_len(self.h, i)
+            tb = np.zeros(max(tl, 1), np.uint8)
+            vb = np.zeros(max(vl, 1), np.uint32)
+            self.lib.ii2h_result_copy(self.h, i, tb.ctypes.data, vb.ctypes.data)
+            out.append((tb[:tl].tobytes(), vb[:vl].tolist()))
+        return out
+
+    def read(self, lo: Optional[bytes] = None, hi: Optional[bytes] = None):
+        n = C.c_uint64()
+        self._ck(self.lib.ii2h_read(self.h, lo or b"", len(lo or b""), lo is not None, hi or b"", len(hi or b""), hi is not None,
+                                    C.byref(n)))
+        return self._results(n.value)
+
+    def _merge(self, req: int, m: int, conc: int) -> int:
+        out = C.c_int64()
+        self._ck(self.lib.ii2h_merge(self.h, req, m, conc, C.byref(out)))
+        return out.value
+
+    def _remove(self, values) -> None:
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        self._ck(self.lib.ii2h_remove(self.h, v.ctypes.data, v.size))
+
+    def removed_values(self) -> List[int]:
+        n = C.c_uint64()
+        self._ck(self.lib.ii2h_removed_values(self.h, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self.lib.ii2h_ids_copy(self.h, out.ctypes.data)
+        return out[: n.value].tolist()
+
+
+class Shard(_Target):
+    """shard.go: Put / Read / Remove / Merge."""
+
+    def __init__(self, ctx: Context):
+        super().__init__(ctx, False)
+
+    def merge(self, req_count: int, m_count: int) -> int:
+        return self._merge(req_count, m_count, 1)
+
+    def remove(self, values) -> None:
+        self._remove(values)
+
+    @property
+    def n_segments(self) -> int:
+        return self.lib.ii2h_segment_count(self.h)
+
+
+class InvertedIndex(_Target):
+    """inverted_index.go: Put / Read / Merge / PutRemoved / PrefixSearch (+ Intersect)."""
+
+    def __init__(self, ctx: Context):
+        super().__init__(ctx, True)
+
+    def merge(self, req_count: int, m_count: int, concurrency: int = 1) -> int:
+        return self._merge(req_count, m_count, concurrency)
+
+    def put_removed(self, values) -> None:
+        self._remove(values)
+
+    def prefix_search(self, prefixes: List[bytes]) -> Dict[bytes, List[int]]:
+        blob, off = _pack(list(prefixes))
+        n = C.c_uint64()
+        self._ck(self.lib.ii2h_prefix_search(self.h, blob.ctypes.data, off.ctypes.data, len(prefixes), C.byref(n)))
+        return dict(self._results(n.value))
+
+    def intersect(self, terms: List[bytes]) -> List[int]:
+        blob, off = _pack(list(terms))
+        n = C.c_uint64()
+        self._ck(self.lib.ii2h_intersect(self.h, blob.ctypes.data, off.ctypes.data, len(terms), C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self.lib.ii2h_ids_copy(self.h, out.ctypes.data)
+        return out[: n.value].tolist()
+
+    @property
+    def n_shards(self) -> int:
+        return self.lib.ii2h_shard_count(self.h)
