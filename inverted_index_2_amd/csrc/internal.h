@@ -152,6 +152,7 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
 // merge / union
 constexpr uint32_t MERGE_CAP = 4096;        // postings per tile (LDS)
 constexpr uint32_t MERGE_OFFMAX = 2176;     // (terms per batch + 1) * k  must fit
+constexpr uint32_t MERGE_THREADS = 512;     // threads per workgroup of the tile kernel
 struct MergeParams {
     SegView segs[MAX_LISTS];
     uint32_t k;
@@ -163,13 +164,15 @@ struct MergeParams {
     uint32_t large_tile;          // target upper bound per large-term tile
     uint32_t wmin;                // minimum packing weight of a term (bounds terms per batch)
     uint32_t batch_q;             // batch id = weight prefix / batch_q
-    uint32_t epoch;
+    uint32_t pad0;
+    const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' upper bounds: scratch slot of each term
+    uint32_t *tmp;                // scratch: parked survivors
+    uint32_t *tile_count;         // [n_tiles+1] survivors per tile
+    unsigned long long *tile_slot;   // [n_tiles] where in tmp the tile parked them
     uint32_t *out_counts;         // [n_terms] survivors per term (zeroed by the host)
     uint32_t *out_values;
     uint64_t out_cap;
     uint64_t *d_total;            // total survivors
-    uint32_t *overflow;           // tiles that did not fit LDS (host re-plans)
-    unsigned long long *desc;     // look-back descriptors
     unsigned long long *debug;    // optional diagnostics words
 };
 hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s);
@@ -179,6 +182,7 @@ hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, con
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0 = nullptr,
                               hipEvent_t ev1 = nullptr);
+hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 
 }  // namespace ii2

@@ -13,22 +13,24 @@
 // A 256-thread workgroup handles a tile: it decodes the tile's blocks of every segment into
 // LDS as k runs sorted by (term, doc), folds the runs pairwise (log2 k levels; an element
 // finds its place by one binary search in the partner run's list of the same term), then
-// drops duplicates and tombstoned ids, compacts, and appends the survivors to the output in
-// tile order (decoupled look-back), so the output is the CSR the reference's writer would
-// have been fed: terms ascending, ids ascending.
+// drops duplicates and tombstoned ids and compacts.  Tiles are independent: each parks its
+// survivors in a scratch array at the input rank of its first posting; a scan of the tile counts
+// and a packing pass then produce the CSR the reference's writer would have been fed: terms
+// ascending, ids ascending.
 #include "dv1_device.h"
 #include "internal.h"
-#include "lookback.h"
 
 namespace ii2 {
 
 constexpr uint32_t MCAP = MERGE_CAP;              // postings per tile
 constexpr uint32_t OFFMAX = MERGE_OFFMAX;         // (nt+1) * k table entries
 constexpr uint32_t TINY_BYTES = 28;               // lane-serial decode for blocks up to this payload
+constexpr uint32_t MT = MERGE_THREADS;            // threads per workgroup of the tile kernel
+constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
 
 // ---- plan -------------------------------------------------------------------------------
-// upper bound of a term's input postings: payload bytes + blocks (every posting but the first
-// of a block owns >= 1 payload byte)
+// upper bound of a term's input postings: min(payload bytes + blocks, 256 per block) (every posting
+// but the first of a block owns >= 1 payload byte)
 __global__ void k_merge_term_ub(MergeParams p, uint32_t *__restrict__ ub, uint32_t *__restrict__ weight,
                                 uint32_t *__restrict__ ntiles_large) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +40,11 @@ __global__ void k_merge_term_ub(MergeParams p, uint32_t *__restrict__ ub, uint32
     for (uint32_t s = 0; s < p.k; s++) {
         const SegView sv = p.segs[s];
         const uint32_t b0 = sv.blk_off[t], b1 = sv.blk_off[t + 1];
-        if (b1 > b0) u += (uint64_t)(sv.skip[b1].byte_off - sv.skip[b0].byte_off) + (b1 - b0);
+        if (b1 > b0) {
+            const uint64_t by_bytes = (uint64_t)(sv.skip[b1].byte_off - sv.skip[b0].byte_off) + (b1 - b0);
+            const uint64_t by_blocks = (uint64_t)(b1 - b0) * II2_DV1_BLOCK;
+            u += by_bytes < by_blocks ? by_bytes : by_blocks;
+        }
     }
     const uint32_t u32 = u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)u;
     ub[t] = u32;
@@ -136,11 +142,11 @@ struct __align__(16) MergeSmem {
     uint32_t runbase[2][MAX_LISTS + 2];
     uint32_t sbl[MAX_LISTS];            // first block of each segment's range
     uint32_t spre[MAX_LISTS + 1];       // prefix of block counts
-    uint32_t wsum[4];
+    uint32_t wsum[MW];
     uint32_t n_in;
+    uint32_t rank;                      // input postings of the tile's term(s) that precede the tile's doc range
     uint32_t nbig;
     uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
-    unsigned long long base;
 };
 
 // segment that owns tile-local block i
@@ -153,7 +159,7 @@ __device__ __forceinline__ uint32_t seg_of_block(const uint32_t *spre, uint32_t 
     return lo;
 }
 
-// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, total in *tot
+// block-wide exclusive scan of one value per thread (MT threads); returns exclusive prefix, total in *tot
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *tot) {
     const int l = lane_id(), wv = (int)threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan(v);
@@ -161,15 +167,27 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     if (l == 63) wsum[wv] = incl;
     __syncthreads();
     uint32_t pre = 0;
-    for (int w = 0; w < wv; w++) pre += wsum[w];
-    *tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    uint32_t t = 0;
+    for (int w = 0; w < (int)MW; w++) { if (w < wv) pre += wsum[w]; t += wsum[w]; }
+    *tot = t;
     return pre + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
+__global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
     __shared__ MergeSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t k = p.k;
+    // diagnostics only: thread 0 sums the cycles spent in each step of the tile loop
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    const bool stamps = p.debug != nullptr;
+#define II2_STAMP(i)                                                    \
+    if (stamps) {                                                       \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();    \
+        tacc[i] += tn_ - tprev;                                         \
+        tprev = tn_;                                                    \
+    }
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
     for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
         const uint4 td = tile_desc[tile];
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
             }
             // offs[1][s*stride + t] = tile-local index of the first block of list (s, t0+t)
             if (full) {
-                for (uint32_t e = (uint32_t)tid; e < k * stride; e += 256u) {
+                for (uint32_t e = (uint32_t)tid; e < k * stride; e += MT) {
                     const uint32_t s = e / stride, t = e % stride;
                     sm.offs[1][e] = p.segs[s].blk_off[t0 + t] - p.segs[s].blk_off[t0];
                 }
@@ -215,17 +233,18 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
             __syncthreads();
             const uint32_t NB = sm.spre[k];
             if (!full) {                                   // ranged tiles hold one term: nt == 1
-                for (uint32_t s = (uint32_t)tid; s < k; s += 256u) {
+                for (uint32_t s = (uint32_t)tid; s < k; s += MT) {
                     sm.offs[1][s * stride] = 0;
                     sm.offs[1][s * stride + 1u] = sm.spre[s + 1u] - sm.spre[s];
                 }
             }
+            II2_STAMP(0)      // A: block ranges, list table
             if (NB >= MCAP) return false;
-            for (uint32_t i = (uint32_t)tid; i <= NB; i += 256u) bcnt[i] = 0;
+            for (uint32_t i = (uint32_t)tid; i <= NB; i += MT) bcnt[i] = 0;
             __syncthreads();
             if (full) {
                 // tiny blocks: one lane per block (all 7 possible dwords fetched at once); others are listed
-                for (uint32_t i = (uint32_t)tid; i < NB; i += 256u) {
+                for (uint32_t i = (uint32_t)tid; i < NB; i += MT) {
                     const uint32_t s = seg_of_block(sm.spre, k, i);
                     const SegView sv = p.segs[s];
                     const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
@@ -249,7 +268,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 }
                 __syncthreads();
                 const uint32_t nbig = sm.nbig;
-                for (uint32_t z = (uint32_t)wv; z < nbig; z += 4u) {
+                for (uint32_t z = (uint32_t)wv; z < nbig; z += MW) {
                     const uint32_t i = biglist[z];
                     const uint32_t s = seg_of_block(sm.spre, k, i);
                     const SegView sv = p.segs[s];
@@ -258,7 +277,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                     if (l == 0) bcnt[i] = c;
                 }
             } else {
-                for (uint32_t i = (uint32_t)wv; i < NB; i += 4u) {
+                for (uint32_t i = (uint32_t)wv; i < NB; i += MW) {
                     const uint32_t s = seg_of_block(sm.spre, k, i);
                     const SegView sv = p.segs[s];
                     const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
@@ -274,9 +293,10 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 }
             }
             __syncthreads();
+            II2_STAMP(1)      // B: count pass
             // block positions (exclusive scan of the counts, in place)
             {
-                const uint32_t per = (NB + 1u + 255u) / 256u;
+                const uint32_t per = (NB + 1u + MT - 1u) / MT;
                 const uint32_t a = (uint32_t)tid * per;
                 uint32_t local = 0;
                 for (uint32_t i = a; i < a + per && i <= NB; i++) local += bcnt[i];
@@ -285,7 +305,19 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 for (uint32_t i = a; i < a + per && i <= NB; i++) { const uint32_t c = bcnt[i]; bcnt[i] = run; run += c; }
                 if (tid == 0) sm.n_in = tot;
             }
+            // input postings of the term that lie before the range: where the tile's output slot starts
+            if (wv == 0) {
+                uint32_t r = 0;
+                if (!full && (uint32_t)l < k) {
+                    const SegView sv = p.segs[l];
+                    r = (sm.sbl[l] - sv.blk_off[t0]) * II2_DV1_BLOCK;
+                    if (sm.spre[l + 1] > sm.spre[l]) r += bbelow[sm.spre[l]];
+                }
+                r = wave_sum(r);
+                if (l == 0) sm.rank = r;
+            }
             __syncthreads();
+            II2_STAMP(2)      // C: positions
             return sm.n_in <= MCAP;
         };
 
@@ -297,9 +329,9 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
             const uint32_t NB = sm.spre[k];
             *outbuf = 0;
             if (n_in == 0) return 0u;
-            for (uint32_t s = (uint32_t)tid; s <= k; s += 256u) sm.runbase[0][s] = s < k ? bcnt[sm.spre[s]] : n_in;
+            for (uint32_t s = (uint32_t)tid; s <= k; s += MT) sm.runbase[0][s] = s < k ? bcnt[sm.spre[s]] : n_in;
             __syncthreads();
-            for (uint32_t e = (uint32_t)tid; e < k * stride; e += 256u) {
+            for (uint32_t e = (uint32_t)tid; e < k * stride; e += MT) {
                 const uint32_t s = e / stride;
                 sm.offs[0][e] = bcnt[sm.spre[s] + sm.offs[1][e]] - sm.runbase[0][s];
             }
@@ -307,7 +339,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
             // ---- D. decode into vals[0] / tids[0] ----
             const uint32_t *BI = sm.offs[1];          // block-index form of the list table
             if (full) {
-                for (uint32_t i = (uint32_t)tid; i < NB; i += 256u) {
+                for (uint32_t i = (uint32_t)tid; i < NB; i += MT) {
                     const uint32_t s = seg_of_block(sm.spre, k, i);
                     const SegView sv = p.segs[s];
                     const uint32_t lb = i - sm.spre[s];
@@ -342,7 +374,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
             }
             {
                 const uint32_t nwork = full ? sm.nbig : NB;
-                for (uint32_t z = (uint32_t)wv; z < nwork; z += 4u) {
+                for (uint32_t z = (uint32_t)wv; z < nwork; z += MW) {
                     const uint32_t i = full ? (uint32_t)biglist[z] : z;
                     const uint32_t s = seg_of_block(sm.spre, k, i);
                     const SegView sv = p.segs[s];
@@ -367,6 +399,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 }
             }
             __syncthreads();
+            II2_STAMP(3)      // D: decode
             // ---- E. fold the runs pairwise ----
             uint32_t cur = 0, nruns = k;
             while (nruns > 1u) {
@@ -376,7 +409,7 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 const uint32_t *RB = sm.runbase[cur];
                 uint32_t *V2 = sm.vals[cur ^ 1u];
                 uint16_t *T2 = sm.tids[cur ^ 1u];
-                for (uint32_t e = (uint32_t)tid; e < n_in; e += 256u) {
+                for (uint32_t e = (uint32_t)tid; e < n_in; e += MT) {
                     const uint32_t v = V[e];
                     const uint32_t tag = T[e];
                     const uint32_t r = tag >> 10, t = tag & 1023u;
@@ -404,22 +437,23 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 const uint32_t nr2 = (nruns + 1u) >> 1;
                 uint32_t *O2 = sm.offs[cur ^ 1u];
                 uint32_t *RB2 = sm.runbase[cur ^ 1u];
-                for (uint32_t e = (uint32_t)tid; e < nr2 * stride; e += 256u) {
+                for (uint32_t e = (uint32_t)tid; e < nr2 * stride; e += MT) {
                     const uint32_t r2 = e / stride, t = e % stride;
                     const uint32_t ra = 2u * r2, rb = ra + 1u;
                     O2[e] = O[ra * stride + t] + (rb < nruns ? O[rb * stride + t] : 0u);
                 }
-                for (uint32_t r2 = (uint32_t)tid; r2 <= nr2; r2 += 256u) RB2[r2] = r2 < nr2 ? RB[2u * r2] : n_in;
+                for (uint32_t r2 = (uint32_t)tid; r2 <= nr2; r2 += MT) RB2[r2] = r2 < nr2 ? RB[2u * r2] : n_in;
                 __syncthreads();
                 cur ^= 1u;
                 nruns = nr2;
             }
+            II2_STAMP(4)      // E: fold
             // ---- F. dedupe, tombstones, compact ----
             const uint32_t *V = sm.vals[cur];
             const uint16_t *T = sm.tids[cur];
             uint32_t *V2 = sm.vals[cur ^ 1u];
             uint16_t *T2 = sm.tids[cur ^ 1u];
-            const uint32_t per = (n_in + 255u) / 256u;
+            const uint32_t per = (n_in + MT - 1u) / MT;
             const uint32_t a = (uint32_t)tid * per;
             const uint32_t b = a + per < n_in ? a + per : n_in;
             uint32_t keepmask = 0;               // per <= 16: one bit per element
@@ -443,15 +477,15 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 // per-term survivor counts from the boundaries of the compacted array
                 uint32_t *tstart = sm.offs[0], *tend = sm.offs[1];
                 __syncthreads();
-                for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) { tstart[t] = 0; tend[t] = 0; }
+                for (uint32_t t = (uint32_t)tid; t < nt; t += MT) { tstart[t] = 0; tend[t] = 0; }
                 __syncthreads();
-                for (uint32_t q = (uint32_t)tid; q < tot; q += 256u) {
+                for (uint32_t q = (uint32_t)tid; q < tot; q += MT) {
                     const uint32_t t = T2[q];
                     if (q == 0 || T2[q - 1] != t) tstart[t] = q;
                     if (q + 1u == tot || T2[q + 1] != t) tend[t] = q + 1u;
                 }
                 __syncthreads();
-                for (uint32_t t = (uint32_t)tid; t < nt; t += 256u) {
+                for (uint32_t t = (uint32_t)tid; t < nt; t += MT) {
                     const uint32_t c = tend[t] - tstart[t];
                     if (c) {
                         if (atomic_counts) atomicAdd(&p.out_counts[t0 + t], c);
@@ -460,42 +494,32 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                 }
             }
             __syncthreads();
+            II2_STAMP(5)      // F: dedupe / filter / compact / counts
             return tot;
         };
 
         const uint32_t dlo = td.z, dhi = td.w;
         const bool root_full = dlo == 0u && dhi == 0xFFFFFFFFu;
-        uint32_t total = 0, outbuf = 0;
-        bool split = false;
+        // The tile parks its survivors in the scratch array at the input rank of its first posting
+        // (term slots start at the prefix of the terms' upper bounds), which no other tile can reach:
+        // survivors never outnumber the inputs that precede the next tile.  A later pass packs them.
+        const unsigned long long term_slot = p.ub_prefix[t0];
+        unsigned long long slot = term_slot;
+        uint32_t total = 0;
         if (dlo <= dhi) {
-            if (count_range(dlo, dhi)) total = merge_range(dlo, dhi, &outbuf, true, !root_full);
-            else split = true;
-        }
-        if (!split) {
-            // ---- ordered output of a tile that fit LDS ----
-            if (wv == 0) {
-                const unsigned long long base = lookback_exclusive(p.desc, tile, total, p.epoch);
-                if (l == 0) {
-                    sm.base = base;
-                    if (tile == p.n_tiles - 1u) *p.d_total = base + total;
-                }
-            }
-            __syncthreads();
-            const unsigned long long ob = sm.base;
-            const uint32_t *V = sm.vals[outbuf];
-            for (uint32_t q = (uint32_t)tid; q < total; q += 256u)
-                if (ob + q < p.out_cap) p.out_values[ob + q] = V[q];
-        } else {
-            // ---- the tile's range holds more than LDS: bisect the doc range (rare: a term whose
-            // lists are clustered differently).  Pass 0 only counts the survivors of every leaf so
-            // the tile can take its place in the output order; pass 1 redoes the leaves and writes.
-            unsigned long long wbase = 0;
-            for (int pass = 0; pass < 2; pass++) {
-                uint32_t sp = 0;
-                unsigned long long running = 0;
+            uint32_t outbuf = 0;
+            if (count_range(dlo, dhi)) {
+                slot = term_slot + (root_full ? 0u : sm.rank);
+                total = merge_range(dlo, dhi, &outbuf, true, !root_full);
+                const uint32_t *V = sm.vals[outbuf];
+                for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
+            } else {
+                // the range holds more than LDS (a term whose lists are clustered differently): bisect the
+                // doc range; leaves are handled in doc order and appended to the tile's slot.
+                bool have_slot = false;
+                uint32_t sp = 1;
                 __syncthreads();
                 if (tid == 0) { sm.stk[0][0] = dlo; sm.stk[0][1] = dhi; }
-                sp = 1;
                 while (sp > 0) {
                     __syncthreads();
                     const uint32_t lo = sm.stk[sp - 1][0], hi = sm.stk[sp - 1][1];
@@ -511,31 +535,36 @@ __global__ __launch_bounds__(256) void k_merge_tiles(MergeParams p, const uint4 
                         sp += 2;
                         continue;
                     }
+                    if (!have_slot) { slot = term_slot + sm.rank; have_slot = true; }   // first (lowest) leaf
                     uint32_t ob2 = 0;
-                    const uint32_t c = merge_range(lo, hi, &ob2, pass == 1, true);
-                    if (pass == 1) {
-                        const uint32_t *V = sm.vals[ob2];
-                        for (uint32_t q = (uint32_t)tid; q < c; q += 256u)
-                            if (wbase + running + q < p.out_cap) p.out_values[wbase + running + q] = V[q];
-                    }
-                    running += c;
-                }
-                if (pass == 0) {
-                    __syncthreads();
-                    if (wv == 0) {
-                        const unsigned long long base = lookback_exclusive(p.desc, tile, (uint32_t)running, p.epoch);
-                        if (l == 0) {
-                            sm.base = base;
-                            if (tile == p.n_tiles - 1u) *p.d_total = base + running;
-                        }
-                    }
-                    __syncthreads();
-                    wbase = sm.base;
+                    const uint32_t c = merge_range(lo, hi, &ob2, true, true);
+                    const uint32_t *V = sm.vals[ob2];
+                    for (uint32_t q = (uint32_t)tid; q < c; q += MT) p.tmp[slot + total + q] = V[q];
+                    total += c;
                 }
             }
         }
+        if (tid == 0) { p.tile_count[tile] = total; p.tile_slot[tile] = slot; }
         __syncthreads();
+        II2_STAMP(6)          // G: park survivors
     }
+    if (stamps && tid == 0)
+        for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
+#undef II2_STAMP
+}
+
+// packs the parked survivors: tile t's ids go to out[off[t] ...]
+__global__ __launch_bounds__(256) void k_merge_pack(const uint32_t *__restrict__ tmp, const unsigned long long *__restrict__ slot,
+                                                    const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ off, uint32_t n_tiles,
+                                                    uint32_t *__restrict__ out, uint64_t out_cap, uint64_t *__restrict__ d_total) {
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t c = cnt[tile];
+        const uint64_t ob = off[tile];
+        const uint32_t *src = tmp + slot[tile];
+        for (uint32_t q = threadIdx.x; q < c; q += 256u)
+            if (ob + q < out_cap) out[ob + q] = src[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = off[n_tiles];
 }
 
 __global__ void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out) {
@@ -565,10 +594,17 @@ hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, con
     hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
     return hipGetLastError();
 }
+hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s) {
+    if (p.n_tiles == 0) return hipSuccess;
+    const uint32_t g = p.n_tiles < 16384u ? p.n_tiles : 16384u;
+    hipLaunchKernelGGL(k_merge_pack, dim3(g), dim3(256), 0, s, (const uint32_t *)p.tmp, (const unsigned long long *)p.tile_slot,
+                       (const uint32_t *)p.tile_count, tile_off, p.n_tiles, p.out_values, p.out_cap, p.d_total);
+    return hipGetLastError();
+}
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL(k_merge_tiles, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(256), 0, s, p, (const uint4 *)tile_desc);
+    hipLaunchKernelGGL(k_merge_tiles, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
     if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }

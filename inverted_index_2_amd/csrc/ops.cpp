@@ -44,7 +44,7 @@ template <class T> static T *carve(uint8_t *&cursor, size_t count) {
 }
 
 // Core: k SegViews over n_terms aligned term slots -> d_out_off (u64[n_terms+1], may be null),
-// d_out_values.  Blocking (reads back total / overflow / surviving terms).
+// d_out_values.  Blocking (reads back the tile count, then total / surviving terms).
 static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n_terms, const ii2_tomb *tomb,
                       uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
     hipStream_t st = ctx->stream;
@@ -62,97 +62,99 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint32_t nt_max = MERGE_OFFMAX / k - 1u;
     if (nt_max > 1000u) nt_max = 1000u;
     if (nt_max < 1u) nt_max = 1u;
-    p.small_max = cap / 4u;
+    p.small_max = cap / 2u;                 // batched terms; a batch holds < batch_q + small_max <= cap
     p.batch_q = cap - p.small_max;
-    p.wmin = (cap + nt_max - 1u) / nt_max;
-    if (p.wmin > p.small_max) p.wmin = p.small_max;     // k = 64: one term per batch may still exceed nt_max? no: nt <= cap/wmin
-    uint32_t large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : cap / 2u;
+    p.wmin = (cap + nt_max - 1u) / nt_max;  // <= cap / wmin <= nt_max terms per batch
+    if (p.wmin > p.small_max) p.wmin = p.small_max;
+    p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : cap;
 
-    const size_t scan_b = scan_temp_bytes((size_t)T + 1);
-    for (int attempt = 0; attempt < 6; attempt++, large_tile = std::max<uint32_t>(large_tile / 2u, 32u)) {
-        p.large_tile = large_tile;
-        // workspace: planning arrays
-        const size_t n1 = (size_t)T + 1;
-        size_t need = 8 * align_up(n1 * sizeof(uint32_t)) + align_up(n1 * sizeof(uint64_t)) + scan_b + 4096;
-        int rc = ii2_ws_reserve(ctx, need);
-        if (rc) return rc;
-        uint8_t *cur = ctx->ws;
-        uint32_t *d_ub = carve<uint32_t>(cur, n1);
-        uint32_t *d_w = carve<uint32_t>(cur, n1);
-        uint32_t *d_ntl = carve<uint32_t>(cur, n1);
-        uint32_t *d_head = carve<uint32_t>(cur, n1);
-        uint32_t *d_hpre = carve<uint32_t>(cur, n1);
-        uint32_t *d_lpre = carve<uint32_t>(cur, n1);
-        uint32_t *d_tt = carve<uint32_t>(cur, n1);
-        uint32_t *d_cnt = carve<uint32_t>(cur, n1);
-        uint64_t *d_wpre = carve<uint64_t>(cur, n1);
-        void *d_scan = cur;
+    // ---- plan (device): per-term bounds, batches, tiles ----
+    const size_t n1 = (size_t)T + 1;
+    const size_t scan_b = scan_temp_bytes(n1);
+    size_t need = 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) + scan_b + 4096;
+    int rc = ii2_ws_reserve(ctx, need);
+    if (rc) return rc;
+    uint8_t *cur = ctx->ws;
+    uint32_t *d_ub = carve<uint32_t>(cur, n1);
+    uint32_t *d_w = carve<uint32_t>(cur, n1);
+    uint32_t *d_ntl = carve<uint32_t>(cur, n1);
+    uint32_t *d_head = carve<uint32_t>(cur, n1);
+    uint32_t *d_hpre = carve<uint32_t>(cur, n1);
+    uint32_t *d_lpre = carve<uint32_t>(cur, n1);
+    uint32_t *d_tt = carve<uint32_t>(cur, n1);
+    uint32_t *d_cnt = carve<uint32_t>(cur, n1);
+    uint64_t *d_wpre = carve<uint64_t>(cur, n1);
+    uint64_t *d_ubpre = carve<uint64_t>(cur, n1);
+    void *d_scan = cur;
 
-        HIP_TRY(ctx, launch_merge_plan1(p, d_ub, d_w, d_ntl, st));
-        HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_w, d_wpre, n1, st));
-        HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_ntl, d_lpre, n1, st));
-        HIP_TRY(ctx, launch_merge_heads(p, d_ntl, d_wpre, d_head, st));
-        HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
-        HIP_TRY(ctx, launch_merge_term_tile(p, d_ntl, d_head, d_hpre, d_lpre, d_tt, st));
-        uint32_t n_tiles = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&n_tiles, d_tt + T, sizeof n_tiles, hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        p.n_tiles = n_tiles;
+    HIP_TRY(ctx, launch_merge_plan1(p, d_ub, d_w, d_ntl, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_w, d_wpre, n1, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_ub, d_ubpre, n1, st));
+    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_ntl, d_lpre, n1, st));
+    HIP_TRY(ctx, launch_merge_heads(p, d_ntl, d_wpre, d_head, st));
+    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
+    HIP_TRY(ctx, launch_merge_term_tile(p, d_ntl, d_head, d_hpre, d_lpre, d_tt, st));
+    uint32_t n_tiles = 0;
+    uint64_t total_ub = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_tiles, d_tt + T, sizeof n_tiles, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&total_ub, d_ubpre + T, sizeof total_ub, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    p.n_tiles = n_tiles;
+    p.ub_prefix = (const unsigned long long *)d_ubpre;
 
-        // tile descriptors live in the grow-only aux buffer
-        const size_t aux_need = (size_t)n_tiles * 16 + 256;
-        if (aux_need > ctx->aux_cap) {
-            if (ctx->aux) (void)hipFree(ctx->aux);
-            ctx->aux = nullptr;
-            ctx->aux_cap = 0;
-            const size_t want = align_up(aux_need + aux_need / 2, 1 << 16);
-            if (hipMalloc((void **)&ctx->aux, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "tile descriptor allocation failed");
-            ctx->aux_cap = want;
-        }
-        HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, ctx->aux, st));
-
-        rc = ii2_desc_reserve(ctx, (size_t)n_tiles + 1);
-        if (rc) return rc;
-        p.desc = ctx->desc;
-        p.epoch = ii2_next_epoch(ctx);
-        p.out_counts = d_cnt;
-        p.out_values = d_out_values;
-        p.out_cap = out_cap;
-        uint64_t *d_total = ctx->d_mail;            // [0] total, [1] overflow (u32), [2] surviving terms
-        p.d_total = d_total;
-        p.overflow = (uint32_t *)(ctx->d_mail + 1);
-        p.debug = ctx->opt_debug_stamps ? (unsigned long long *)(ctx->d_mail + 8) : nullptr;
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
-        HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
-        // persistent grid: 2 workgroups of ~67 KB LDS per CU are always co-resident
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        ii2_profile_pair(ctx, &e0, &e1);
-        HIP_TRY(ctx, launch_merge_tiles(p, ctx->aux, (uint32_t)ctx->cu_count * 2u, st, e0, e1));
-        HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
-        if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        const uint32_t overflow = (uint32_t)ctx->h_mail[1];
-        if (ctx->opt_debug_stamps) {
-            (void)hipMemcpy(ctx->h_mail + 8, ctx->d_mail + 8, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost);
-            uint32_t td[4] = {9, 9, 9, 9}, tt[2] = {9, 9};
-            (void)hipMemcpy(td, ctx->aux, 16, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(tt, d_tt, 8, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[ii2 merge dbg] tile_desc[0]=%u %u %x %x term_tile[0..1]=%u %u aux=%p ws=%p desc=%p\n", td[0], td[1], td[2], td[3], tt[0], tt[1],
-                    (void *)ctx->aux, (void *)ctx->ws, (void *)ctx->desc);
-            fprintf(stderr, "[ii2 merge dbg] NB|n_in=%llx t0|t1=%llx lo|hi=%llx buf|total=%llx tiles=%u ovf=%u\n", (unsigned long long)ctx->h_mail[8],
-                    (unsigned long long)ctx->h_mail[9], (unsigned long long)ctx->h_mail[10], (unsigned long long)ctx->h_mail[11], n_tiles, overflow);
-        }
-        if (overflow) continue;                     // unbalanced doc-range splitters: re-plan with smaller tiles
-        if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small (content unspecified)");
-        if (stats) {
-            stats->n_out = ctx->h_mail[0];
-            stats->n_terms_out = ctx->h_mail[2];
-            stats->n_tiles = n_tiles;
-        }
-        return II2_OK;
+    // ---- per-tile arrays and the scratch the tiles park their survivors in (grow-only aux buffer) ----
+    const size_t nt1 = (size_t)n_tiles + 1;
+    const size_t scan_t = scan_temp_bytes(nt1);
+    const size_t aux_need = align_up(nt1 * 16) + align_up(nt1 * sizeof(uint32_t)) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
+                            align_up((total_ub + 64) * sizeof(uint32_t)) + 4096;
+    if (aux_need > ctx->aux_cap) {
+        if (ctx->aux) (void)hipFree(ctx->aux);
+        ctx->aux = nullptr;
+        ctx->aux_cap = 0;
+        const size_t want = align_up(aux_need + aux_need / 8, 1 << 20);
+        if (hipMalloc((void **)&ctx->aux, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
+        ctx->aux_cap = want;
     }
-    return fail(ctx, II2_ERANGE, "merge: a term's postings are too clustered for the doc-range tiling");
+    uint8_t *ac = ctx->aux;
+    void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
+    p.tile_count = carve<uint32_t>(ac, nt1);
+    p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
+    uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
+    void *d_scan_t = carve<uint8_t>(ac, scan_t);
+    p.tmp = carve<uint32_t>(ac, total_ub + 64);
+
+    HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, d_tile_desc, st));
+    p.out_counts = d_cnt;
+    p.out_values = d_out_values;
+    p.out_cap = out_cap;
+    p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
+    p.debug = nullptr;
+    if (ctx->opt_debug_stamps) {
+        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)ctx->cu_count * 8 * 8 * sizeof(unsigned long long)) != hipSuccess)
+            return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
+        p.debug = ctx->d_debug;
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
+    HIP_TRY(ctx, hipMemsetAsync(p.tile_count + n_tiles, 0, sizeof(uint32_t), st));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ii2_profile_pair(ctx, &e0, &e1);
+    // 2 workgroups of ~67 KB LDS per CU; each walks tiles w, w+grid, ...
+    HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st, e0, e1));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
+    HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
+    HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
+    if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_tiles == 0) ctx->h_mail[0] = 0;
+    if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small (content unspecified)");
+    if (stats) {
+        stats->n_out = ctx->h_mail[0];
+        stats->n_terms_out = ctx->h_mail[2];
+        stats->n_tiles = n_tiles;
+    }
+    return II2_OK;
 }
 
 static int check_segs(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs) {

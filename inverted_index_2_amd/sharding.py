@@ -1,0 +1,54 @@
+"""How the hot path is spread over the GPUs of a node (one process per GPU).
+
+Merge: shards are independent in the reference (own segments, own tombstones —
+shard.go:19-26, fan-out inverted_index.go:83-103) and shardKey is order-preserving for terms
+of >= 2 bytes (shard.go:371-377), so the 1024 shard keys are cut into `world` contiguous
+ranges.  One conjunctive query: the doc-id space is cut into `world` contiguous ranges.  Either
+way rank-order concatenation of the per-rank results is the global result
+(inverted_index.go:330-339) — that concatenation is the only exchange (ii2_allgatherv)."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+N_SHARD_KEYS = 1024          # 10 bits of the first two term bytes (shard.go:375)
+
+
+def shard_key(term: bytes) -> int:
+    """shard.go:362-378."""
+    if len(term) < 2:
+        return 0
+    return ((term[0] << 8) + term[1]) >> 6
+
+
+def key_range(rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous shard-key range [lo, hi) of a rank."""
+    return rank * N_SHARD_KEYS // world, (rank + 1) * N_SHARD_KEYS // world
+
+
+def owner_of_key(key: int, world: int) -> int:
+    for r in range(world):
+        lo, hi = key_range(r, world)
+        if lo <= key < hi:
+            return r
+    raise ValueError(key)
+
+
+def term_range(rank: int, world: int, n_terms: int) -> Tuple[int, int]:
+    """Contiguous range of aligned term slots of a rank (synthetic workloads: term id order = key order)."""
+    return rank * n_terms // world, (rank + 1) * n_terms // world
+
+
+def doc_range(rank: int, world: int, universe: int) -> Tuple[int, int]:
+    return rank * universe // world, (rank + 1) * universe // world
+
+
+def slice_list_to_docs(ids: np.ndarray, lo: int, hi: int) -> np.ndarray:
+    """The part of an ascending id list that falls in [lo, hi)."""
+    a, b = np.searchsorted(ids, [lo, hi])
+    return ids[a:b]
+
+
+def concat_in_rank_order(parts: Sequence[np.ndarray]) -> np.ndarray:
+    return np.concatenate(list(parts)) if len(parts) else np.empty(0, np.uint32)
