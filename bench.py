@@ -266,7 +266,7 @@ def bench_merge(args, ctx, torch, dist, world, rank):
     }
     if not args.no_cpu_baseline:
         from oracle import oracle as orc
-        ncores = os.cpu_count() or 1
+        ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
         t0 = time.perf_counter()
         w_off, w_vals, _ = orc.merge_segments(offs, vals, removed, threads=ncores)
         cdt = time.perf_counter() - t0

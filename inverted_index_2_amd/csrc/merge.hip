@@ -402,6 +402,50 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
             II2_STAMP(3)      // D: decode
             // ---- E. fold the runs pairwise ----
             uint32_t cur = 0, nruns = k;
+            // One term in the tile (the tiles of large terms — most of the postings): plain two-way merges.
+            // Each thread produces a few consecutive outputs: one merge-path search to find where its
+            // chunk starts in the two runs, then a sequential merge (A first on ties) — a handful of
+            // instructions per posting and level instead of a binary search per posting.
+            while (nt == 1u && nruns > 1u) {
+                const uint32_t *V = sm.vals[cur];
+                const uint32_t *RB = sm.runbase[cur];
+                uint32_t *V2 = sm.vals[cur ^ 1u];
+                const uint32_t npairs = (nruns + 1u) >> 1;
+                const uint32_t VT = (n_in + MT - 1u) / MT;
+                uint32_t o = (uint32_t)tid * VT;
+                const uint32_t oe = o + VT < n_in ? o + VT : n_in;
+                while (o < oe) {
+                    uint32_t ja = 0, jb = npairs;             // pair j with RB[2j] <= o < RB[2j+2]
+                    while (jb - ja > 1u) { const uint32_t jm = (ja + jb) >> 1; if (RB[2u * jm] <= o) ja = jm; else jb = jm; }
+                    const uint32_t ra = 2u * ja, rb = ra + 1u;
+                    const uint32_t abase = RB[ra], bbase = RB[rb];
+                    const uint32_t la = bbase - abase;
+                    const uint32_t lb = rb < nruns ? RB[rb + 1u] - bbase : 0u;
+                    const uint32_t *A = V + abase, *B = V + bbase;
+                    const uint32_t d = o - abase;
+                    uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (A[mid] <= B[d - 1u - mid]) lo = mid + 1u; else hi = mid;
+                    }
+                    uint32_t ia = lo, ib = d - lo;
+                    const uint32_t pend = abase + la + lb;
+                    const uint32_t stop = oe < pend ? oe : pend;
+                    uint32_t va = ia < la ? A[ia] : 0u, vb = ib < lb ? B[ib] : 0u;
+                    for (; o < stop; o++) {
+                        const bool takeA = ib >= lb || (ia < la && va <= vb);
+                        V2[o] = takeA ? va : vb;
+                        if (takeA) { ia++; va = ia < la ? A[ia] : 0u; }
+                        else { ib++; vb = ib < lb ? B[ib] : 0u; }
+                    }
+                }
+                __syncthreads();
+                uint32_t *RB2 = sm.runbase[cur ^ 1u];
+                for (uint32_t r2 = (uint32_t)tid; r2 <= npairs; r2 += MT) RB2[r2] = r2 < npairs ? RB[2u * r2] : n_in;
+                __syncthreads();
+                cur ^= 1u;
+                nruns = npairs;
+            }
             while (nruns > 1u) {
                 const uint32_t *V = sm.vals[cur];
                 const uint16_t *T = sm.tids[cur];
@@ -460,7 +504,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
             uint32_t cnt = 0;
             for (uint32_t e = a; e < b; e++) {
                 const uint32_t v = V[e];
-                bool keep = !(e > 0 && V[e - 1] == v && (T[e - 1] & 1023u) == (T[e] & 1023u));
+                bool keep = !(e > 0 && V[e - 1] == v && (nt == 1u || (T[e - 1] & 1023u) == (T[e] & 1023u)));
                 if (keep && p.tomb) {
                     const uint32_t w = v >> 5;
                     if (w < p.tomb_nwords && ((p.tomb[w] >> (v & 31u)) & 1u)) keep = false;
@@ -470,7 +514,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
             uint32_t tot;
             uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
             for (uint32_t e = a; e < b; e++) {
-                if ((keepmask >> (e - a)) & 1u) { V2[pos] = V[e]; T2[pos] = (uint16_t)(T[e] & 1023u); pos++; }
+                if ((keepmask >> (e - a)) & 1u) { V2[pos] = V[e]; T2[pos] = nt == 1u ? (uint16_t)0 : (uint16_t)(T[e] & 1023u); pos++; }
             }
             *outbuf = cur ^ 1u;
             if (emit_counts) {
