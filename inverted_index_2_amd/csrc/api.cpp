@@ -583,7 +583,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.n_sums = p.n_sums1;
     p.sums = ws_take<uint32_t>(ctx, p.n_sums);
     uint64_t *d_tile_off = nullptr;
-    p.max_grid = (uint32_t)ctx->cu_count * 5u;     // ~29 KB of LDS per workgroup: 5 per CU
+    p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : 5u);   // ~29 KB of LDS per workgroup: 5 per CU
     p.tomb = tomb ? tomb->d_words : nullptr;
     p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
     p.out = d_out;
@@ -662,6 +662,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     const std::string k(name);
     if (k == "intersect.lookback") ctx->opt_intersect_lookback = value;
     else if (k == "intersect.g") ctx->opt_intersect_g = value;
+    else if (k == "intersect.wgs") ctx->opt_intersect_wgs = value;
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "merge.lookback") ctx->opt_merge_lookback = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;

@@ -29,6 +29,7 @@ struct ii2_ctx {
     // options
     int64_t opt_intersect_lookback = 1;
     int64_t opt_intersect_g = 0;        // 0 = auto
+    int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
     int64_t opt_merge_lookback = 1;
     uint8_t *aux = nullptr;             // grow-only: merge tile descriptors

@@ -38,25 +38,46 @@ constexpr uint32_t MAP_BYTES = ISECT_SMAX + 32u;  // byte map origin is rounded 
 // {bl, bh, qlo, qhi}: block range and payload byte range of the phase (tile, j).
 __host__ __device__ constexpr uint32_t desc_stride(uint32_t n) { return 2u + 4u * n; }
 
-// first index i in [lo, hi) with skip[i].first_doc > x, searched 64 ways per round by one wave
-__device__ __forceinline__ uint32_t wave_skip_upper_bound(const ii2_skip *__restrict__ skip, uint32_t lo, uint32_t hi, uint32_t x) {
+// Two upper bounds on one skip table at once, each searched 64 ways per round by the whole wave:
+// r = first index in [0, n) with first_doc > x.  The two probe sequences are independent, so their
+// loads overlap and the pair costs the latency of one search (3 rounds for 250k blocks).
+__device__ __forceinline__ void wave_skip_upper_bound2(const ii2_skip *__restrict__ skip, uint32_t n, uint32_t xa, uint32_t xb,
+                                                       uint32_t &ra, uint32_t &rb) {
     const uint32_t l = (uint32_t)lane_id();
-    while (lo < hi) {
-        const uint32_t span = hi - lo;
-        const uint32_t step = (span + 63u) >> 6;              // >= 1
-        const uint32_t pos = lo + l * step;                   // probe positions, ascending over the lanes
-        const bool in = pos < hi;
-        const bool le = in && skip[pos].first_doc <= x;       // true on a prefix of the lanes (sorted table)
-        const uint32_t cnt = (uint32_t)__popcll(__ballot(le));
-        const uint32_t nin = (uint32_t)__popcll(__ballot(in));
-        // answer lies in (pos[cnt-1], pos[cnt]]
-        const uint32_t nlo = cnt ? lo + (cnt - 1u) * step + 1u : lo;
-        const uint32_t nhi = cnt < nin ? lo + cnt * step : hi;
-        if (step == 1u) return cnt < nin ? lo + cnt : hi;
-        lo = nlo;
-        hi = nhi;
+    uint32_t loa = 0, hia = n, lob = 0, hib = n;
+    bool donea = false, doneb = false;
+    while (!(donea && doneb)) {
+        const uint32_t spa = hia - loa, spb = hib - lob;
+        const uint32_t sta = (spa + 63u) >> 6, stb = (spb + 63u) >> 6;
+        const uint32_t pa = loa + l * sta, pb = lob + l * stb;
+        const bool ina = !donea && pa < hia, inb = !doneb && pb < hib;
+        const uint32_t fa = ina ? skip[pa].first_doc : 0u;
+        const uint32_t fb = inb ? skip[pb].first_doc : 0u;
+        if (!donea) {
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(ina && fa <= xa));
+            const uint32_t nin = (uint32_t)__popcll(__ballot(ina));
+            if (spa == 0u) { donea = true; }
+            else if (sta == 1u) { loa = cnt < nin ? loa + cnt : hia; hia = loa; donea = true; }
+            else {
+                const uint32_t nlo = cnt ? loa + (cnt - 1u) * sta + 1u : loa;
+                hia = cnt < nin ? loa + cnt * sta : hia;
+                loa = nlo;
+            }
+        }
+        if (!doneb) {
+            const uint32_t cnt = (uint32_t)__popcll(__ballot(inb && fb <= xb));
+            const uint32_t nin = (uint32_t)__popcll(__ballot(inb));
+            if (spb == 0u) { doneb = true; }
+            else if (stb == 1u) { lob = cnt < nin ? lob + cnt : hib; hib = lob; doneb = true; }
+            else {
+                const uint32_t nlo = cnt ? lob + (cnt - 1u) * stb + 1u : lob;
+                hib = cnt < nin ? lob + cnt * stb : hib;
+                lob = nlo;
+            }
+        }
     }
-    return lo;
+    ra = loa;
+    rb = lob;
 }
 
 __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
@@ -81,9 +102,10 @@ __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
     }
     const ListView L = p.lists[j];
     // first block that may hold ids >= lo: the last block whose first_doc <= lo
-    const uint32_t ub = wave_skip_upper_bound(L.skip, 0u, L.nblk, lo);
+    uint32_t ub, bh;                            // bh: first block starting after hi
+    wave_skip_upper_bound2(L.skip, L.nblk, lo, hi, ub, bh);
     const uint32_t bl = ub ? ub - 1u : 0u;
-    const uint32_t bh = wave_skip_upper_bound(L.skip, bl, L.nblk, hi);   // first block starting after hi
+    if (bh < bl) bh = bl;
     if (lane_id() == 0) {
         r[2 + 4 * j] = bl;
         r[3 + 4 * j] = bh;
@@ -520,13 +542,13 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
     if (p.n_tiles == 0) return hipSuccess;
     const uint64_t nthr = (uint64_t)p.n_tiles * p.n_lists;
     const uint64_t pthr = std::max<uint64_t>(nthr * 64u, p.n_sums);
+    if (ev0) (void)hipEventRecord(ev0, s);          // the events bracket the whole pass: partition + tiles + expand
     hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
     const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-    if (ev0) (void)hipEventRecord(ev0, s);
     hipLaunchKernelGGL(k_isect_tiles, dim3(grid), dim3(256), 0, s, p);
-    if (ev1) (void)hipEventRecord(ev1, s);
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
+    if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }
 

@@ -30,6 +30,13 @@ for lb in (1, 0):
         alg = seg.info.n_bytes + 8 * seg.info.n_blocks + 4 * n
         print(f"  g={g} {dt*1e6:.1f} us/step  {(a.size+b.size)/dt/1e9:.1f} Gpostings/s  alg {alg/dt/1e12:.3f} TB/s", flush=True)
     ctx.set_option("intersect.g", 0)
+for wgs in (3, 4, 5, 6, 8, 10):
+    ctx.set_option("intersect.wgs", wgs)
+    ctx.intersect_async([(seg, 0), (seg, 1)], None, out, dcnt); ctx.sync()
+    t = time.time()
+    for _ in range(20): ctx.intersect_async([(seg, 0), (seg, 1)], None, out, dcnt)
+    ctx.sync(); print(f"wgs/CU={wgs}: {(time.time()-t)/20*1e6:.1f} us/step", flush=True)
+ctx.set_option("intersect.wgs", 0)
 # per-phase cycle shares (diagnostic path)
 import ctypes as C
 ctx.set_option("debug.stamps", 1)
@@ -38,9 +45,9 @@ nwg = 1280
 buf = (C.c_uint64 * (nwg * 8))()
 ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, nwg * 8))
 arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
-names = ["clear+commit+bar+prefetch", "decode", "bar-after-decode", "finalise", "-", "-", "-", "-"]
+names = ["barrier+prefetch issue", "decode", "bar-after-decode", "finalise", "clear+commit(wait)", "-", "-", "-"]
 tot = arr.sum(axis=1).mean()
 print("mean cycles per WG", tot)
-for i, nm in enumerate(names[:4]):
+for i, nm in enumerate(names[:5]):
     print(f"  {nm:26s} {arr[:, i].mean():10.0f}  {100 * arr[:, i].mean() / tot:5.1f}%")
 ctx.set_option("debug.stamps", 0)
