@@ -165,11 +165,20 @@ def main():
         return
 
     info = seg.info
-    # algorithmic bytes of one launch of the dominant (tile) kernel — DESIGN.md §Roofline:
-    # encoded payload + 8 B per block of skip table + 4 B per result id (+ D/8 tombstone bitmap)
+    # algorithmic bytes of one pass (SURVEY.md §8 d): encoded payload + 8 B per block of
+    # skip table + 4 B per result id (+ D/8 tombstone bitmap).  The HIP events bracket the whole pass
+    # on the library's stream: k_isect_partition + k_isect_tiles (dominant) + k_isect_expand.
     alg_bytes = info.n_bytes + 8 * info.n_blocks + 4 * n_out + (D // 8 if tomb is not None else 0)
     kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
     achieved = alg_bytes / kern_avg_s / 1e9 if kern_n else None
+    # HBM traffic from the PMC passes kept under profiles/ (same command, same workload); null otherwise
+    traffic = None
+    try:
+        if D == 100_000_000 and tomb is None and world == 1:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_intersect.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_pass_corrected"]
+    except OSError:
+        pass
 
     result = {
         "metric": "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline",
@@ -192,8 +201,9 @@ def main():
             "parallelism": "docrange%d" % world, "allgatherv": "timed" if args.gather_timed else "after timed region",
         },
         "roofline": {
-            "bound": "hbm", "kernel": "ii2::k_isect_tiles", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "bound": "hbm", "kernel": "one pass: ii2::k_isect_partition + ii2::k_isect_tiles (dominant) + ii2::k_isect_expand",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
             "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_us": kern_avg_s * 1e6, "launches_timed": int(kern_n),
         },
     }
