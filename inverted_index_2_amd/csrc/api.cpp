@@ -541,6 +541,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     const uint32_t nblk0 = views[0].nblk;
     // tile height: aim the tile's doc span at the LDS byte map; keep >= ~8 tiles per CU
     uint32_t G = 1;
+    double per_block_span = 0;                   // docs per driver block (tile-height heuristics)
     if (ctx->opt_intersect_g > 0) G = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, ISECT_GMAX);
     else if (nblk0 > 1) {
         const ii2_seg *dseg = nullptr;
@@ -561,14 +562,27 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
             dseg->span_cache[didx] = ends;
         }
         const double per_block = (double)(ends.second - ends.first) / (double)(nblk0 - 1);
+        per_block_span = per_block;
         const double g = per_block > 0 ? 0.85 * ISECT_SMAX / per_block : ISECT_GMAX;
         G = g >= ISECT_GMAX ? ISECT_GMAX : g < 1 ? 1u : (uint32_t)g;
         while (G > 1 && nblk0 / G < 8u * (uint32_t)ctx->cu_count) G >>= 1;
     }
+    // wave-level kernels (<= 4 lists): mini-tiles of up to 4 driver blocks, 8 Ki-doc byte map per wave
+    const bool wave = n >= 2 && n <= ISECTW_MAXL && ctx->opt_intersect_wave != 0;
+    if (wave) {
+        uint32_t gw = 4;
+        if (ctx->opt_intersect_g > 0) gw = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, 4);
+        else if (per_block_span > 0) {
+            while (gw > 1 && per_block_span * gw > 0.8 * ISECTW_SMAX) gw >>= 1;
+        }
+        G = gw;
+    }
     p.G = G;
+    p.wave_mode = wave ? 1u : 0u;
     p.n_tiles = (nblk0 + G - 1) / G;
-    const size_t dstride = 2 + 4 * (size_t)n;
-    uint32_t slot_words = (ISECT_SMAX + 32u) / 32u;
+    const size_t dstride = wave ? (16 + 40 * ((size_t)n - 1)) : (2 + 4 * (size_t)n);
+    p.desc_words = (uint32_t)dstride;
+    uint32_t slot_words = wave ? (ISECTW_SMAX + 32u) / 32u : (ISECT_SMAX + 32u) / 32u;
     if (slot_words < G * 256u) slot_words = G * 256u;
     slot_words = (slot_words + 3u) & ~3u;
     p.slot_words = slot_words;
@@ -583,7 +597,8 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.n_sums = p.n_sums1;
     p.sums = ws_take<uint32_t>(ctx, p.n_sums);
     uint64_t *d_tile_off = nullptr;
-    p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : 5u);   // ~29 KB of LDS per workgroup: 5 per CU
+    const uint32_t wgs_default = wave ? 4u : 5u;    // LDS per workgroup: ~37 KB (wave) / ~29 KB
+    p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : wgs_default);
     p.tomb = tomb ? tomb->d_words : nullptr;
     p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
     p.out = d_out;
@@ -663,6 +678,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     if (k == "intersect.lookback") ctx->opt_intersect_lookback = value;
     else if (k == "intersect.g") ctx->opt_intersect_g = value;
     else if (k == "intersect.wgs") ctx->opt_intersect_wgs = value;
+    else if (k == "intersect.wave") ctx->opt_intersect_wave = value;
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "merge.lookback") ctx->opt_merge_lookback = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;

@@ -217,15 +217,16 @@ struct LdsBytes16 {
 // just before its 16 bytes and w = its 16 gap bytes (bytes past the block's end are 0, so the
 // running id simply stops advancing there) and true is returned.  Returns false — for the whole
 // wave, nothing decoded — when any row's block needs the general decoder.
-template <class Load16>
-__device__ __forceinline__ bool decode_rows16(Load16 load16, uint32_t q0, uint32_t q1, uint32_t first_doc, bool row_valid,
-                                              uint32_t &base, uint4 &w) {
+// Second half of the row decode, on bytes that are already in registers (`w` = the 16 bytes at
+// q0 + 16*rl, undefined when that is past q1): masks the tail, checks the fast-path conditions,
+// and turns w into gap bytes + base id.  See decode_rows16.
+__device__ __forceinline__ bool rows16_finish(uint32_t q0, uint32_t q1, uint32_t first_doc, bool row_valid, uint32_t &base, uint4 &w) {
     const uint32_t rl = (uint32_t)lane_id() & 15u;
     const uint32_t len = row_valid ? q1 - q0 : 0u;
     const uint32_t myoff = 16u * rl;
     const uint32_t nb = len > myoff ? (len - myoff < 16u ? len - myoff : 16u) : 0u;
-    w = nb ? load16(q0 + myoff) : make_uint4(0, 0, 0, 0);
-    if (nb < 16u) {     // zero the bytes past the end of the block
+    if (nb == 0u) w = make_uint4(0, 0, 0, 0);
+    else if (nb < 16u) {     // zero the bytes past the end of the block
         const uint32_t n0 = nb < 4u ? nb : 4u, n1 = nb < 4u ? 0u : (nb < 8u ? nb - 4u : 4u);
         const uint32_t n2 = nb < 8u ? 0u : (nb < 12u ? nb - 8u : 4u), n3 = nb < 12u ? 0u : nb - 12u;
         w.x &= n0 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n0)) - 1u);
@@ -242,6 +243,15 @@ __device__ __forceinline__ bool decode_rows16(Load16 load16, uint32_t q0, uint32
     const uint32_t incl = row_incl_scan(s);
     base = first_doc + incl - s;
     return true;
+}
+
+template <class Load16>
+__device__ __forceinline__ bool decode_rows16(Load16 load16, uint32_t q0, uint32_t q1, uint32_t first_doc, bool row_valid,
+                                              uint32_t &base, uint4 &w) {
+    const uint32_t rl = (uint32_t)lane_id() & 15u;
+    const uint32_t len = row_valid ? q1 - q0 : 0u;
+    w = len > 16u * rl ? load16(q0 + 16u * rl) : make_uint4(0, 0, 0, 0);
+    return rows16_finish(q0, q1, first_doc, row_valid, base, w);
 }
 
 // Posting count of a block without decoding ids (1 + terminators).  Wave-uniform result.

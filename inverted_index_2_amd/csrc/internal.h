@@ -30,6 +30,7 @@ struct ii2_ctx {
     int64_t opt_intersect_lookback = 1;
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
+    int64_t opt_intersect_wave = 1;     // use the wave-level kernels when the query has <= 4 lists
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
     int64_t opt_merge_lookback = 1;
     uint8_t *aux = nullptr;             // grow-only: merge tile descriptors
@@ -117,6 +118,8 @@ struct IntersectParams {
     uint32_t *sums;              // [n_sums] partial sums of tile_count: per 64 tiles, then per 4096 tiles
     uint32_t n_sums, n_sums1;    // total entries, entries of the per-64 level
     uint32_t slot_words;
+    uint32_t desc_words;         // words per tile in `ranges`
+    uint32_t wave_mode;          // 1: wave-level kernels (intersect_wave.hip)
     uint32_t max_grid;           // workgroups of the tile kernel (each walks tiles w, w+grid, ...)
 };
 
@@ -148,6 +151,10 @@ hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStrea
 // intersect
 constexpr uint32_t ISECT_GMAX = 16;         // driver blocks per tile (max)
 constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
+constexpr uint32_t ISECTW_SMAX = 8192;      // docs a wave's byte map covers (wave-level kernel)
+constexpr uint32_t ISECTW_ABLK = 12;        // prefetched blocks per other list and mini-tile
+constexpr uint32_t ISECTW_MAXL = 4;         // lists the wave-level kernel handles
+hipError_t launch_intersect_wave(const IntersectParams &p, hipStream_t s);
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // merge / union

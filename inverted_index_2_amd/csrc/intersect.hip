@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
     __shared__ uint32_t stage[ISECT_GMAX * 256u];
     __shared__ uint32_t wsum[4];
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
-    const uint32_t stride = desc_stride(p.n_lists);
+    const uint32_t stride = p.desc_words;
     // workgroup w expands the consecutive tiles [w*per, (w+1)*per): one offset lookup, then a running sum
     const uint32_t per = (p.n_tiles + gridDim.x - 1u) / gridDim.x;
     const uint32_t tbeg = blockIdx.x * per;
@@ -543,9 +543,14 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
     const uint64_t nthr = (uint64_t)p.n_tiles * p.n_lists;
     const uint64_t pthr = std::max<uint64_t>(nthr * 64u, p.n_sums);
     if (ev0) (void)hipEventRecord(ev0, s);          // the events bracket the whole pass: partition + tiles + expand
-    hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
-    const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-    hipLaunchKernelGGL(k_isect_tiles, dim3(grid), dim3(256), 0, s, p);
+    if (p.wave_mode) {
+        hipError_t e = launch_intersect_wave(p, s);
+        if (e != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
+        const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
+        hipLaunchKernelGGL(k_isect_tiles, dim3(grid), dim3(256), 0, s, p);
+    }
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);
