@@ -30,7 +30,7 @@ struct ii2_ctx {
     int64_t opt_intersect_lookback = 1;
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
-    int64_t opt_intersect_wave = 1;     // use the wave-level kernels when the query has <= 4 lists
+    int64_t opt_intersect_wave = 0;     // 1: wave-level kernels for 2..4 lists (measured slower on C2: more, smaller tiles)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
     int64_t opt_merge_lookback = 1;
     uint8_t *aux = nullptr;             // grow-only: merge tile descriptors

@@ -13,13 +13,13 @@ def _check(ctx, lists, removed=None):
     seg = ctx.encode_lists(lists)
     tomb = ctx.tombstones(removed) if removed is not None else None
     want = orc.intersect(lists, np.sort(removed) if removed is not None else ())
-    for lookback in (1, 0):
-        ctx.set_option("intersect.lookback", lookback)
+    for wave in (0, 1):        # workgroup-level tile kernel, wave-level tile kernel (2..4 lists)
+        ctx.set_option("intersect.wave", wave)
         out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
         got = out.download(n)
-        assert n == want.size, (lookback, n, want.size)
-        assert np.array_equal(got, want), lookback
-    ctx.set_option("intersect.lookback", 1)
+        assert n == want.size, (wave, n, want.size)
+        assert np.array_equal(got, want), wave
+    ctx.set_option("intersect.wave", 0)
     # split over two segments as well (lists from different segments)
     if len(lists) >= 2:
         s0, s1 = ctx.encode_lists(lists[:1]), ctx.encode_lists(lists[1:])
