@@ -285,10 +285,10 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
                         for (int k = 0; k < 16; k++) m[k] = sm.map[o[k]];
                         const uint8_t mf = sm.map[of];
                         const uint8_t nx = (uint8_t)(want + 1u);
+                        // no exec-mask juggling: lanes without a match store onto the dummy byte instead
 #pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            if (m[k] == want) sm.map[o[k]] = nx;
-                        if (mf == want) sm.map[of] = nx;
+                        for (int k = 0; k < 16; k++) sm.map[m[k] == want ? o[k] : dummy] = nx;
+                        sm.map[mf == want ? of : dummy] = nx;
                     }
                 };
                 const uint32_t ngroups = (nblk + 3u) >> 2;
