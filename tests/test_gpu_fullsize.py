@@ -1,0 +1,72 @@
+"""GPU: BASELINE.json's configurations at (or near) full size, checked through size-independent
+properties plus an independent CPU computation where it finishes in seconds."""
+import numpy as np
+import pytest
+
+from inverted_index_2_amd import synth
+from oracle import oracle as orc
+from tests.gpu_util import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_full_size_two_term_and(ctx):
+    # configs[1]: 2-term intersection, 100M-doc Zipf postings (ranks 2 and 3), varint decode in-kernel
+    D = 100_000_000
+    a, b = synth.zipf_list(2, D), synth.zipf_list(3, D)
+    seg = ctx.encode_lists([a, b])
+    out, n = ctx.intersect([(seg, 0), (seg, 1)])
+    got = out.download(n)
+    want = np.intersect1d(a, b, assume_unique=True)
+    assert n == want.size
+    assert np.array_equal(got, want)                                   # bit-exact id sequence
+    assert np.all(np.diff(got.astype(np.int64)) > 0)                   # strictly ascending
+    # idempotence / absorption: (A ∩ B) ∩ A == A ∩ B, through the kernels again
+    seg2 = ctx.encode_lists([got, a])
+    out2, n2 = ctx.intersect([(seg2, 0), (seg2, 1)])
+    assert n2 == n and np.array_equal(out2.download(n2), got)
+    # commutativity: the driver choice must not matter
+    out3, n3 = ctx.intersect([(seg, 1), (seg, 0)])
+    assert n3 == n and int(out3.download(n3).astype(np.uint64).sum()) == int(got.astype(np.uint64).sum())
+    # tombstones == set difference with the removed list
+    removed = synth.geometric_postings(0.01, D, synth.term_seed(10**6))
+    out4, n4 = ctx.intersect([(seg, 0), (seg, 1)], tomb=ctx.tombstones(removed))
+    assert np.array_equal(out4.download(n4), np.setdiff1d(want, removed, assume_unique=True))
+
+
+def test_config5_scaled_eight_term_and(ctx):
+    # configs[4] layout on one GPU, 200M docs: ranks {2,4,16,...,16384}, a common core forced into every list
+    D = 200_000_000
+    rng = np.random.default_rng(55)
+    core = np.unique(rng.integers(0, D, 10_000)).astype(np.uint32)
+    lists = [np.union1d(synth.zipf_list(r, D), core).astype(np.uint32) for r in (2, 4, 16, 64, 256, 1024, 4096, 16384)]
+    seg = ctx.encode_lists(lists)
+    out, n = ctx.intersect([(seg, i) for i in range(8)])
+    want = orc.intersect(lists)
+    assert n == want.size and np.array_equal(out.download(n), want)
+    assert np.all(np.isin(core, out.download(n)))                       # the forced core survives
+
+
+def test_config3_scaled_merge_properties(ctx):
+    # configs[2] family: 16-way merge, Zipf term sizes (mean 1000), 10 % duplicated postings, 1 % tombstones
+    T, k = 40_000, 16
+    offs, vals, removed = synth.merge_workload(T, k, 1000.0, 100_000_000)
+    segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+    tomb = ctx.tombstones(removed)
+    out_off, out_vals, st = ctx.merge(segs, tomb)
+    g_off = out_off.download()
+    g_vals = out_vals.download(int(st.n_out))
+    w_off, w_vals, w_terms = orc.merge_segments(offs, vals, removed, threads=8)
+    assert np.array_equal(g_off, w_off) and np.array_equal(g_vals, w_vals) and st.n_terms_out == w_terms
+    # per-term lists ascending and duplicate-free; no tombstoned id survives
+    d = np.diff(g_vals.astype(np.int64))
+    starts = g_off[1:-1].astype(np.int64)
+    inner = np.ones(d.size, bool)
+    inner[starts[(starts > 0) & (starts <= d.size)] - 1] = False
+    assert np.all(d[inner] > 0)
+    assert not np.isin(g_vals[:: max(1, g_vals.size // 2_000_000)], removed).any()
+    # idempotence (cf. shard_test.go:153): merging the merged segment with itself changes nothing
+    merged, _ = ctx.merge_to_segment(segs, tomb)
+    again, st2 = ctx.merge_to_segment([merged, merged])
+    po, v = again.decode()
+    assert np.array_equal(po, w_off) and np.array_equal(v, w_vals)
