@@ -57,28 +57,6 @@ template <class T> static T *ws_take(ii2_ctx *ctx, size_t count) {
     return p;
 }
 
-int ii2_desc_reserve(ii2_ctx *ctx, size_t n) {
-    if (n <= ctx->desc_cap) return II2_OK;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->desc) (void)hipFree(ctx->desc);
-    ctx->desc = nullptr;
-    ctx->desc_cap = 0;
-    size_t want = align_up(n + n / 2, 4096);
-    if (hipMalloc((void **)&ctx->desc, want * sizeof(unsigned long long)) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "descriptor allocation failed");
-    HIP_TRY(ctx, hipMemsetAsync(ctx->desc, 0, want * sizeof(unsigned long long), ctx->stream));
-    ctx->desc_cap = want;
-    return II2_OK;
-}
-uint32_t ii2_next_epoch(ii2_ctx *ctx) {
-    ctx->epoch = (ctx->epoch + 1) & 0x3FFFFFu;
-    if (ctx->epoch == 0) {     // wrapped: forget every old descriptor
-        (void)hipMemsetAsync(ctx->desc, 0, ctx->desc_cap * sizeof(unsigned long long), ctx->stream);
-        ctx->epoch = 1;
-    }
-    return ctx->epoch;
-}
-
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1) {
     if (!ctx->opt_profile_events) return false;
     std::pair<hipEvent_t, hipEvent_t> pr;
@@ -149,7 +127,6 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ii2_comm_destroy_internal(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
-    if (ctx->desc) (void)hipFree(ctx->desc);
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
@@ -353,6 +330,18 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const ui
     HIP_TRY(ctx, hipMemcpyAsync(seg->d_skip, skip, ((uint64_t)nb + 1) * sizeof(ii2_skip), kind, ctx->stream));
     if (seg->n_bytes) HIP_TRY(ctx, hipMemcpyAsync(seg->d_payload, payload, seg->n_bytes, kind, ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + seg->n_bytes, 0, 16, ctx->stream));
+    {   // refuse structurally broken input before any kernel walks it
+        uint32_t *d_bad = (uint32_t *)ctx->d_mail;
+        uint32_t bad = 0;
+        HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, launch_validate_seg(seg->d_blk_off, n_lists, seg->d_skip, nb, seg->n_bytes, d_bad, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad) {
+            // the arrays are not yet owned by a store: seg_release frees them
+            return fail(ctx, II2_EINVAL, "ii2_seg_import: malformed DV1 segment (offsets not monotone / out of range)");
+        }
+    }
     int rc = seg_finish(ctx, seg.get());
     if (rc) return rc;
     *out = seg.release();
@@ -675,12 +664,10 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     const std::string k(name);
-    if (k == "intersect.lookback") ctx->opt_intersect_lookback = value;
-    else if (k == "intersect.g") ctx->opt_intersect_g = value;
+    if (k == "intersect.g") ctx->opt_intersect_g = value;
     else if (k == "intersect.wgs") ctx->opt_intersect_wgs = value;
     else if (k == "intersect.wave") ctx->opt_intersect_wave = value;
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
-    else if (k == "merge.lookback") ctx->opt_merge_lookback = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else return fail(ctx, II2_EINVAL, "unknown option");

@@ -178,6 +178,26 @@ hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, c
     return hipGetLastError();
 }
 
+// structural check of an imported segment: offsets monotone and in range, no block longer than
+// 255 five-byte varints — so that no kernel can be steered outside the payload
+__global__ void k_validate_seg(const uint32_t *__restrict__ blk_off, uint64_t n_lists, const ii2_skip *__restrict__ skip,
+                               uint64_t n_blocks, uint64_t n_bytes, uint32_t *__restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_lists && blk_off[i] > blk_off[i + 1]) atomicOr(bad, 1u);
+    if (i == 0 && (blk_off[0] != 0 || blk_off[n_lists] != n_blocks)) atomicOr(bad, 2u);
+    if (i < n_blocks) {
+        const uint32_t q0 = skip[i].byte_off, q1 = skip[i + 1].byte_off;
+        if (q1 < q0 || q1 - q0 > 255u * 5u || q1 > n_bytes) atomicOr(bad, 4u);
+    }
+}
+
+hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const ii2_skip *skip, uint64_t n_blocks, uint64_t n_bytes,
+                               uint32_t *bad, hipStream_t s) {
+    const uint64_t n = (n_lists > n_blocks ? n_lists : n_blocks) + 1;
+    hipLaunchKernelGGL(k_validate_seg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blk_off, n_lists, skip, n_blocks, n_bytes, bad);
+    return hipGetLastError();
+}
+
 // ---- tombstones -----------------------------------------------------------------------
 // RemovedLists.Values() (removed_list.go:44-54) as a dense bitmap: bit v set <=> v removed.
 __global__ void k_tomb_build(const uint32_t *__restrict__ removed, uint64_t n, uint32_t *__restrict__ words, uint64_t n_words) {

@@ -23,16 +23,11 @@ struct ii2_ctx {
     // small pinned host mailbox for counts read back after a call
     uint64_t *h_mail = nullptr;
     uint64_t *d_mail = nullptr;
-    uint32_t epoch = 0;   // look-back descriptor generation
-    unsigned long long *desc = nullptr;   // look-back descriptors (only ever hold descriptors)
-    size_t desc_cap = 0;
     // options
-    int64_t opt_intersect_lookback = 1;
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_intersect_wave = 0;     // 1: wave-level kernels for 2..4 lists (measured slower on C2: more, smaller tiles)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
-    int64_t opt_merge_lookback = 1;
     uint8_t *aux = nullptr;             // grow-only: merge tile descriptors
     size_t aux_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
@@ -146,6 +141,8 @@ hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, 
 hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, hipStream_t s);
 hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists,
                                 uint32_t *last_doc, hipStream_t s);
+hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const ii2_skip *skip, uint64_t n_blocks, uint64_t n_bytes,
+                               uint32_t *bad, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
 
 // intersect

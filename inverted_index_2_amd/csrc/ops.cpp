@@ -34,8 +34,6 @@ struct DevBuf {
 };
 
 int ii2_ws_reserve(ii2_ctx *ctx, size_t bytes);          // api.cpp
-int ii2_desc_reserve(ii2_ctx *ctx, size_t n);
-uint32_t ii2_next_epoch(ii2_ctx *ctx);
 
 template <class T> static T *carve(uint8_t *&cursor, size_t count) {
     T *p = (T *)cursor;
