@@ -84,3 +84,28 @@ def test_tombstone_bitmap_filters_like_binary_search(ctx):
     seg = ctx.encode_lists([a])
     out, n = ctx.intersect([(seg, 0)], tomb=ctx.tombstones(removed))
     assert np.array_equal(out.download(n), orc.filter_removed(a, np.sort(removed)))
+
+
+def test_import_rejects_malformed_segment(ctx):
+    from inverted_index_2_amd import II2Error
+    a = np.arange(0, 3000, 3, dtype=np.uint32)
+    po = np.array([0, a.size], np.uint64)
+    blk, skip, payload = orc.dv1_encode(po, a)
+    bad = skip.copy()
+    bad["byte_off"][1] = 10_000_000          # points far outside the payload
+    with pytest.raises(II2Error) as e:
+        ctx.import_dv1(a.size, blk, bad, payload)
+    assert e.value.code == -1
+    bad2 = blk.copy()
+    bad2[1] = 999
+    with pytest.raises(II2Error):
+        ctx.import_dv1(a.size, bad2, skip, payload)
+    ctx.import_dv1(a.size, blk, skip, payload)      # the intact one is accepted
+
+
+def test_allgatherv_single_rank_is_a_copy(ctx):
+    a = np.arange(10, 5000, 7, dtype=np.uint32)
+    src = ctx.empty(a.size).upload(a)
+    dst = ctx.empty(a.size + 10)
+    counts = ctx.allgatherv(src, a.size, dst, 1)
+    assert counts == [a.size] and np.array_equal(dst.download(a.size), a)
