@@ -112,7 +112,7 @@ int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
     ctx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_mail, 64 * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_mail, 64 * sizeof(uint64_t)) != hipSuccess) {
+        hipMalloc((void **)&ctx->d_mail, 128 * sizeof(uint64_t)) != hipSuccess) {
         g_create_err = "context resource allocation failed";
         ii2_ctx_destroy(ctx);
         return II2_EHIP;
@@ -128,6 +128,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     ii2_comm_destroy_internal(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->aux2) (void)hipFree(ctx->aux2);
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);

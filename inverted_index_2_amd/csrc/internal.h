@@ -28,8 +28,10 @@ struct ii2_ctx {
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_intersect_wave = 0;     // 1: wave-level kernels for 2..4 lists (measured slower on C2: more, smaller tiles)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
-    uint8_t *aux = nullptr;             // grow-only: merge tile descriptors
+    uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
     size_t aux_cap = 0;
+    uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
+    size_t aux2_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_profile_events = 0;     // bracket the dominant kernel of each call with HIP events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
@@ -170,7 +172,12 @@ struct MergeParams {
     uint32_t wmin;                // minimum packing weight of a term (bounds terms per batch)
     uint32_t batch_q;             // batch id = weight prefix / batch_q
     uint32_t pad0;
-    const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' upper bounds: scratch slot of each term
+    uint32_t seg_b0[MAX_LISTS];       // first block of every segment's term range
+    uint32_t seg_cum[MAX_LISTS + 1];  // prefix of the segments' block counts (global block numbering)
+    const uint32_t *raw;              // pass 1 output: every input list decoded, back to back
+    const unsigned long long *poff;   // [k * (n_terms+1)] position in raw of list (s, t)
+    const uint2 *rng;                 // [n_tiles * k] where list (s, t0) enters / leaves the tile's doc range
+    const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' input counts: scratch slot of each term
     uint32_t *tmp;                // scratch: parked survivors
     uint32_t *tile_count;         // [n_tiles+1] survivors per tile
     unsigned long long *tile_slot;   // [n_tiles] where in tmp the tile parked them
@@ -187,6 +194,11 @@ hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, con
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0 = nullptr,
                               hipEvent_t ev1 = nullptr);
+hipError_t launch_mseg_blocks(const MergeParams &p, uint32_t *out, hipStream_t s);
+hipError_t launch_mdec_counts(const MergeParams &p, uint32_t *counts, hipStream_t s);
+hipError_t launch_mdec_write(const MergeParams &p, const uint64_t *bpo, uint32_t *raw, hipStream_t s);
+hipError_t launch_mpost_off(const MergeParams &p, const uint64_t *bpo, unsigned long long *poff, hipStream_t s);
+hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s);
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 

@@ -7,12 +7,15 @@
 //     empty terms reported with count 0 (shard.go:192-194);
 //   * the multi-term union of PrefixSearch (inverted_index.go:274-292) — one "term", k lists.
 //
-// Work is cut into TILES that fit LDS (<= CAP postings):
+// Pass 1 decodes every input list once, streaming, into a raw u32 scratch array (one wave per
+// DV1 block, all segments in one launch) and derives exact per-(segment, term) offsets.  Pass 2
+// cuts the work into TILES that fit LDS (<= CAP postings):
 //   small terms are packed, in term order, into batches of consecutive terms;
-//   a large term is cut into doc-id ranges by splitters sampled from its longest list.
-// A 256-thread workgroup handles a tile: it decodes the tile's blocks of every segment into
-// LDS as k runs sorted by (term, doc), folds the runs pairwise (log2 k levels; an element
-// finds its place by one binary search in the partner run's list of the same term), then
+//   a large term is cut into doc-id ranges at exact quantiles of its longest list; where each
+//   segment's list enters and leaves a range is found by binary search in the planning pass.
+// A 512-thread workgroup handles a tile: it copies the tile's slices of the k raw lists into
+// LDS as k runs sorted by (term, doc), folds the runs pairwise (log2 k levels; single-term tiles
+// by merge-path + sequential two-way merges, batches by one binary search per element), then
 // drops duplicates and tombstoned ids and compacts.  Tiles are independent: each parks its
 // survivors in a scratch array at the input rank of its first posting; a scan of the tile counts
 // and a packing pass then produce the CSR the reference's writer would have been fed: terms
@@ -24,28 +27,69 @@ namespace ii2 {
 
 constexpr uint32_t MCAP = MERGE_CAP;              // postings per tile
 constexpr uint32_t OFFMAX = MERGE_OFFMAX;         // (nt+1) * k table entries
-constexpr uint32_t TINY_BYTES = 28;               // lane-serial decode for blocks up to this payload
 constexpr uint32_t MT = MERGE_THREADS;            // threads per workgroup of the tile kernel
 constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
 
+// ---- pass 1: decode everything once --------------------------------------------------------
+// global block g of the merge input -> (segment, block of that segment)
+__device__ __forceinline__ uint32_t seg_of_gblock(const MergeParams &p, uint32_t g) {
+    uint32_t lo = 0, hi = p.k;          // seg_cum[lo] <= g < seg_cum[hi]
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (p.seg_cum[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_mdec_counts(MergeParams p, uint32_t *__restrict__ counts) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t total = p.seg_cum[p.k];
+    if (g > total) return;
+    if (g == total) { if (lane_id() == 0) counts[g] = 0; return; }
+    const uint32_t s = seg_of_gblock(p, (uint32_t)g);
+    const SegView sv = p.segs[s];
+    const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
+    const uint32_t c = count_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off);
+    if (lane_id() == 0) counts[g] = c;
+}
+
+__global__ __launch_bounds__(256) void k_mdec_write(MergeParams p, const uint64_t *__restrict__ bpo, uint32_t *__restrict__ raw) {
+    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (g >= p.seg_cum[p.k]) return;
+    const uint32_t s = seg_of_gblock(p, (uint32_t)g);
+    const SegView sv = p.segs[s];
+    const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
+    uint32_t *out = raw + bpo[g];
+    decode_block_wave(GlobalBytes{sv.payload}, sv.skip[b].byte_off, sv.skip[b + 1].byte_off, sv.skip[b].first_doc,
+                      [&](uint32_t ix, uint32_t id) { out[ix] = id; });
+}
+
+// poff[s * (T+1) + t] = position in raw of the first posting of list (s, t)
+__global__ void k_mpost_off(MergeParams p, const uint64_t *__restrict__ bpo, unsigned long long *__restrict__ poff) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n1 = p.n_terms + 1;
+    if (i >= (uint64_t)p.k * n1) return;
+    const uint32_t s = (uint32_t)(i / n1);
+    const uint64_t t = i % n1;
+    poff[i] = bpo[p.seg_cum[s] + (p.segs[s].blk_off[t] - p.seg_b0[s])];
+}
+
+// first block of every segment's term range and the end of it: [2s] = blk_off[0], [2s+1] = blk_off[T]
+__global__ void k_mseg_blocks(MergeParams p, uint32_t *__restrict__ out) {
+    const uint32_t s = threadIdx.x;
+    if (s < p.k) { out[2 * s] = p.segs[s].blk_off[0]; out[2 * s + 1] = p.segs[s].blk_off[p.n_terms]; }
+}
+
 // ---- plan -------------------------------------------------------------------------------
-// upper bound of a term's input postings: min(payload bytes + blocks, 256 per block) (every posting
-// but the first of a block owns >= 1 payload byte)
+// exact input postings of every term, its packing weight, and the tiles of a large term
 __global__ void k_merge_term_ub(MergeParams p, uint32_t *__restrict__ ub, uint32_t *__restrict__ weight,
                                 uint32_t *__restrict__ ntiles_large) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > p.n_terms) return;
     if (t == p.n_terms) { ub[t] = 0; weight[t] = 0; ntiles_large[t] = 0; return; }
+    const uint64_t n1 = p.n_terms + 1;
     uint64_t u = 0;
-    for (uint32_t s = 0; s < p.k; s++) {
-        const SegView sv = p.segs[s];
-        const uint32_t b0 = sv.blk_off[t], b1 = sv.blk_off[t + 1];
-        if (b1 > b0) {
-            const uint64_t by_bytes = (uint64_t)(sv.skip[b1].byte_off - sv.skip[b0].byte_off) + (b1 - b0);
-            const uint64_t by_blocks = (uint64_t)(b1 - b0) * II2_DV1_BLOCK;
-            u += by_bytes < by_blocks ? by_bytes : by_blocks;
-        }
-    }
+    for (uint32_t s = 0; s < p.k; s++) u += p.poff[s * n1 + t + 1] - p.poff[s * n1 + t];
     const uint32_t u32 = u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)u;
     ub[t] = u32;
     if (u32 > p.small_max) {
@@ -93,25 +137,16 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
     const uint64_t tl = lo;
     if (ntl[tl] > 0) {                          // tile j of large term tl
         const uint32_t m = ntl[tl], j = tile - term_tile[tl];
-        // splitters: block first_docs of the term's longest list
-        uint32_t best_s = 0, best_n = 0;
+        // splitters: exact quantiles of the term's longest list (raw ids)
+        const uint64_t n1 = p.n_terms + 1;
+        uint32_t best_s = 0;
+        uint64_t best_n = 0;
         for (uint32_t s = 0; s < p.k; s++) {
-            const uint32_t nb = p.segs[s].blk_off[tl + 1] - p.segs[s].blk_off[tl];
-            if (nb > best_n) { best_n = nb; best_s = s; }
+            const uint64_t len = p.poff[s * n1 + tl + 1] - p.poff[s * n1 + tl];
+            if (len > best_n) { best_n = len; best_s = s; }
         }
-        const SegView sv = p.segs[best_s];
-        const uint32_t B0 = sv.blk_off[tl];
-        // splitter j = doc id at fractional block position j*best_n/m of the longest list
-        // (linear interpolation inside the block, so m may exceed the list's block count)
-        auto splitter = [&](uint32_t jj) -> uint32_t {
-            const uint64_t num = (uint64_t)jj * best_n;
-            const uint32_t b = (uint32_t)(num / m);
-            const uint64_t rem = num % m;
-            const uint32_t f0 = sv.skip[B0 + b].first_doc;
-            const uint32_t f1 = b + 1u < best_n ? sv.skip[B0 + b + 1u].first_doc : sv.last_doc[tl];
-            const uint64_t span = f1 > f0 ? (uint64_t)(f1 - f0) : 0ull;
-            return f0 + (uint32_t)((span * rem) / m);
-        };
+        const uint32_t *lst = p.raw + p.poff[best_s * n1 + tl];
+        auto splitter = [&](uint32_t jj) -> uint32_t { return lst[((uint64_t)jj * best_n) / m]; };
         // tile j covers [S_j, S_{j+1}) with S_0 = 0 and S_m = 2^32; S is non-decreasing in j
         const uint64_t lo64 = j > 0 ? (uint64_t)splitter(j) : 0ull;
         const uint64_t hi64 = j + 1u < m ? (uint64_t)splitter(j + 1u) : (1ull << 32);
@@ -134,30 +169,44 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
     }
 }
 
+// where every segment's list enters and leaves a tile's doc range: rng[tile * k + s] = (first, end)
+// posting index relative to the start of list (s, t0)
+__global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, uint2 *__restrict__ rng) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)p.n_tiles * p.k) return;
+    const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
+    const uint4 td = desc[tile];
+    const uint64_t n1 = p.n_terms + 1;
+    const uint64_t beg = p.poff[s * n1 + td.x], end = p.poff[s * n1 + td.y];
+    const uint32_t len = (uint32_t)(end - beg);
+    uint32_t a = 0, e = len;
+    if (td.z > td.w) { a = 0; e = 0; }                       // empty doc range
+    else if (!(td.z == 0u && td.w == 0xFFFFFFFFu)) {
+        const uint32_t *lst = p.raw + beg;
+        uint32_t lo = 0, hi = len;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] < td.z) lo = mid + 1u; else hi = mid; }
+        a = lo;
+        hi = len;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
+        e = lo;
+    }
+    rng[i] = make_uint2(a, e);
+}
+
 // ---- the tile kernel ----------------------------------------------------------------------
 struct __align__(16) MergeSmem {
     uint32_t vals[2][MCAP];
     uint16_t tids[2][MCAP];             // (run << 10 | term) of each element
     uint32_t offs[2][OFFMAX];           // per run: nt+1 list offsets inside the run
     uint32_t runbase[2][MAX_LISTS + 2];
-    uint32_t sbl[MAX_LISTS];            // first block of each segment's range
-    uint32_t spre[MAX_LISTS + 1];       // prefix of block counts
+    unsigned long long rs[MAX_LISTS];   // position in raw of each run's first posting
+    uint32_t spre[MAX_LISTS + 1];       // run lengths
+    uint32_t sbl_rank[MAX_LISTS];       // postings of each list that precede the range
     uint32_t wsum[MW];
     uint32_t n_in;
     uint32_t rank;                      // input postings of the tile's term(s) that precede the tile's doc range
-    uint32_t nbig;
     uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
 };
-
-// segment that owns tile-local block i
-__device__ __forceinline__ uint32_t seg_of_block(const uint32_t *spre, uint32_t k, uint32_t i) {
-    uint32_t lo = 0, hi = k;            // spre[lo] <= i < spre[hi]
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (spre[mid] <= i) lo = mid; else hi = mid;
-    }
-    return lo;
-}
 
 // block-wide exclusive scan of one value per thread (MT threads); returns exclusive prefix, total in *tot
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *tot) {
@@ -194,212 +243,77 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
         const uint32_t t0 = td.x, t1 = td.y;
         const uint32_t nt = t1 - t0;
         const uint32_t stride = nt + 1u;
-        uint32_t *bcnt = sm.vals[1];                     // [NB+1] block counts / positions (idle ping-pong buffer)
-        uint16_t *bbelow = sm.tids[1];                   // [NB]  ranged: ids below the range per block
-        uint16_t *biglist = sm.tids[1];                  // [NB]  full: blocks that need a whole wave
+        const uint64_t n1 = p.n_terms + 1;
 
-        // ---- steps A-C: blocks of the doc range [dlo, dhi], their posting counts and positions.
-        // Returns false when the range does not fit LDS (n_in > MCAP or too many blocks).
-        auto count_range = [&](uint32_t dlo, uint32_t dhi) -> bool {
-            const bool full = dlo == 0u && dhi == 0xFFFFFFFFu;
+        // ---- step A: the k runs of the doc range [dlo, dhi] — where they start in raw, how long they
+        // are, where they go in LDS.  root: the planning pass already searched the range (rng);
+        // otherwise (a bisected leaf) every segment's list is binary-searched here.
+        // Returns false when the range does not fit LDS.
+        auto load_range = [&](uint32_t dlo, uint32_t dhi, bool root) -> bool {
             __syncthreads();
             if ((uint32_t)tid < k) {
-                const SegView sv = p.segs[tid];
-                const uint32_t B0 = sv.blk_off[t0], B1 = sv.blk_off[t1];
-                uint32_t bl = B0, bh = B1;
-                if (!full && B1 > B0) {
-                    const uint32_t ub = skip_upper_bound(sv.skip, B0, B1, dlo);
-                    bl = ub > B0 ? ub - 1u : B0;
-                    bh = skip_upper_bound(sv.skip, bl, B1, dhi);
+                const uint64_t beg = p.poff[(uint32_t)tid * n1 + t0], end = p.poff[(uint32_t)tid * n1 + t1];
+                const uint32_t len = (uint32_t)(end - beg);
+                uint32_t a = 0, e = len;
+                if (root) { const uint2 r = p.rng[(uint64_t)tile * k + (uint32_t)tid]; a = r.x; e = r.y; }
+                else {
+                    const uint32_t *lst = p.raw + beg;
+                    uint32_t lo = 0, hi = len;
+                    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] < dlo) lo = mid + 1u; else hi = mid; }
+                    a = lo;
+                    hi = len;
+                    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= dhi) lo = mid + 1u; else hi = mid; }
+                    e = lo;
                 }
-                sm.sbl[tid] = bl;
-                sm.spre[tid] = bh - bl;
+                sm.rs[tid] = beg + a;
+                sm.spre[tid] = e - a;
+                sm.sbl_rank[tid] = a;
             }
             __syncthreads();
             if (wv == 0) {
                 const uint32_t c = (uint32_t)l < k ? sm.spre[l] : 0u;
                 const uint32_t incl = wave_incl_scan(c);
-                if ((uint32_t)l < k) sm.spre[l] = incl - c;
-                if (l == 63) sm.spre[k] = incl;
-            }
-            // offs[1][s*stride + t] = tile-local index of the first block of list (s, t0+t)
-            if (full) {
-                for (uint32_t e = (uint32_t)tid; e < k * stride; e += MT) {
-                    const uint32_t s = e / stride, t = e % stride;
-                    sm.offs[1][e] = p.segs[s].blk_off[t0 + t] - p.segs[s].blk_off[t0];
-                }
-            }
-            if (tid == 0) sm.nbig = 0;
-            __syncthreads();
-            const uint32_t NB = sm.spre[k];
-            if (!full) {                                   // ranged tiles hold one term: nt == 1
-                for (uint32_t s = (uint32_t)tid; s < k; s += MT) {
-                    sm.offs[1][s * stride] = 0;
-                    sm.offs[1][s * stride + 1u] = sm.spre[s + 1u] - sm.spre[s];
-                }
-            }
-            II2_STAMP(0)      // A: block ranges, list table
-            if (NB >= MCAP) return false;
-            for (uint32_t i = (uint32_t)tid; i <= NB; i += MT) bcnt[i] = 0;
-            __syncthreads();
-            if (full) {
-                // tiny blocks: one lane per block (all 7 possible dwords fetched at once); others are listed
-                for (uint32_t i = (uint32_t)tid; i < NB; i += MT) {
-                    const uint32_t s = seg_of_block(sm.spre, k, i);
-                    const SegView sv = p.segs[s];
-                    const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
-                    const uint32_t q0 = sv.skip[b].byte_off, q1 = sv.skip[b + 1].byte_off;
-                    const uint32_t len = q1 - q0;
-                    if (len <= TINY_BYTES) {
-                        uint32_t w[7];
-#pragma unroll
-                        for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(sv.payload + q0 + 4u * j) : 0u;
-                        uint32_t c = 1;
-#pragma unroll
-                        for (int j = 0; j < 7; j++) {
-                            const uint32_t nb = len > (uint32_t)(4 * j) ? (len - 4u * j < 4u ? len - 4u * j : 4u) : 0u;
-                            c += count_terminators(w[j], nb);
-                        }
-                        bcnt[i] = c;
-                    } else {
-                        const uint32_t slot = atomicAdd(&sm.nbig, 1u);
-                        biglist[slot] = (uint16_t)i;
-                    }
-                }
-                __syncthreads();
-                const uint32_t nbig = sm.nbig;
-                for (uint32_t z = (uint32_t)wv; z < nbig; z += MW) {
-                    const uint32_t i = biglist[z];
-                    const uint32_t s = seg_of_block(sm.spre, k, i);
-                    const SegView sv = p.segs[s];
-                    const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
-                    const uint32_t c = count_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off);
-                    if (l == 0) bcnt[i] = c;
-                }
-            } else {
-                for (uint32_t i = (uint32_t)wv; i < NB; i += MW) {
-                    const uint32_t s = seg_of_block(sm.spre, k, i);
-                    const SegView sv = p.segs[s];
-                    const uint32_t b = sm.sbl[s] + (i - sm.spre[s]);
-                    uint32_t below = 0, inr = 0;
-                    decode_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off, sv.skip[b].first_doc,
-                                      [&](uint32_t, uint32_t id) {
-                                          below += id < dlo;
-                                          inr += (id >= dlo && id <= dhi);
-                                      });
-                    below = wave_sum(below);
-                    inr = wave_sum(inr);
-                    if (l == 0) { bcnt[i] = inr; bbelow[i] = (uint16_t)below; }
-                }
-            }
-            __syncthreads();
-            II2_STAMP(1)      // B: count pass
-            // block positions (exclusive scan of the counts, in place)
-            {
-                const uint32_t per = (NB + 1u + MT - 1u) / MT;
-                const uint32_t a = (uint32_t)tid * per;
-                uint32_t local = 0;
-                for (uint32_t i = a; i < a + per && i <= NB; i++) local += bcnt[i];
-                uint32_t tot;
-                uint32_t run = block_excl_scan(local, sm.wsum, &tot);
-                for (uint32_t i = a; i < a + per && i <= NB; i++) { const uint32_t c = bcnt[i]; bcnt[i] = run; run += c; }
-                if (tid == 0) sm.n_in = tot;
-            }
-            // input postings of the term that lie before the range: where the tile's output slot starts
-            if (wv == 0) {
-                uint32_t r = 0;
-                if (!full && (uint32_t)l < k) {
-                    const SegView sv = p.segs[l];
-                    r = (sm.sbl[l] - sv.blk_off[t0]) * II2_DV1_BLOCK;
-                    if (sm.spre[l + 1] > sm.spre[l]) r += bbelow[sm.spre[l]];
-                }
-                r = wave_sum(r);
+                if ((uint32_t)l < k) sm.runbase[0][l] = incl - c;
+                if (l == 63) { sm.runbase[0][k] = incl; sm.n_in = incl; }
+                const uint32_t r = wave_sum((uint32_t)l < k ? sm.sbl_rank[l] : 0u);
                 if (l == 0) sm.rank = r;
             }
+            // list offsets inside each run (batches of several terms)
+            if (nt > 1u) {
+                for (uint32_t e = (uint32_t)tid; e < k * stride; e += MT) {
+                    const uint32_t s = e / stride, t = e % stride;
+                    sm.offs[0][e] = (uint32_t)(p.poff[s * n1 + t0 + t] - p.poff[s * n1 + t0]);
+                }
+            }
             __syncthreads();
-            II2_STAMP(2)      // C: positions
+            II2_STAMP(0)      // A: run ranges, list table
             return sm.n_in <= MCAP;
         };
 
-        // ---- steps D-F on a counted range: decode, fold the runs, dedupe + tombstones + compact.
+        // ---- steps D-F on a loaded range: copy the runs into LDS, fold them, dedupe + tombstones + compact.
         // Survivors land in sm.vals[*outbuf][0..return); per-term counts go to out_counts when asked.
-        auto merge_range = [&](uint32_t dlo, uint32_t dhi, uint32_t *outbuf, bool emit_counts, bool atomic_counts) -> uint32_t {
-            const bool full = dlo == 0u && dhi == 0xFFFFFFFFu;
+        auto merge_range = [&](uint32_t *outbuf, bool emit_counts, bool atomic_counts) -> uint32_t {
             const uint32_t n_in = sm.n_in;
-            const uint32_t NB = sm.spre[k];
             *outbuf = 0;
             if (n_in == 0) return 0u;
-            for (uint32_t s = (uint32_t)tid; s <= k; s += MT) sm.runbase[0][s] = s < k ? bcnt[sm.spre[s]] : n_in;
-            __syncthreads();
-            for (uint32_t e = (uint32_t)tid; e < k * stride; e += MT) {
-                const uint32_t s = e / stride;
-                sm.offs[0][e] = bcnt[sm.spre[s] + sm.offs[1][e]] - sm.runbase[0][s];
-            }
-            __syncthreads();
-            // ---- D. decode into vals[0] / tids[0] ----
-            const uint32_t *BI = sm.offs[1];          // block-index form of the list table
-            if (full) {
-                for (uint32_t i = (uint32_t)tid; i < NB; i += MT) {
-                    const uint32_t s = seg_of_block(sm.spre, k, i);
-                    const SegView sv = p.segs[s];
-                    const uint32_t lb = i - sm.spre[s];
-                    const uint32_t b = sm.sbl[s] + lb;
-                    const uint32_t q0 = sv.skip[b].byte_off, q1 = sv.skip[b + 1].byte_off;
-                    const uint32_t len = q1 - q0;
-                    if (len <= TINY_BYTES) {
-                        uint32_t w[7];
-#pragma unroll
-                        for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(sv.payload + q0 + 4u * j) : 0u;
-                        uint32_t ta = 0, tb = nt;      // last t with BI[s][t] <= lb
-                        while (tb - ta > 1u) {
-                            const uint32_t mid = (ta + tb) >> 1;
-                            if (BI[s * stride + mid] <= lb) ta = mid; else tb = mid;
-                        }
-                        const uint16_t tag = (uint16_t)((s << 10) | ta);
-                        uint32_t pos = bcnt[i];
-                        uint32_t cur = sv.skip[b].first_doc;
-                        sm.vals[0][pos] = cur; sm.tids[0][pos] = tag; pos++;
-                        uint32_t acc = 0, sh = 0;
-#pragma unroll
-                        for (int j = 0; j < 28; j++) {
-                            if ((uint32_t)j < len) {
-                                const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                                acc |= (c & 0x7Fu) << sh;
-                                if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
-                                else { cur += acc; sm.vals[0][pos] = cur; sm.tids[0][pos] = tag; pos++; acc = 0; sh = 0; }
-                            }
-                        }
-                    }
-                }
-            }
+            // ---- D. gather the runs into vals[0] (coalesced inside every run) ----
             {
-                const uint32_t nwork = full ? sm.nbig : NB;
-                for (uint32_t z = (uint32_t)wv; z < nwork; z += MW) {
-                    const uint32_t i = full ? (uint32_t)biglist[z] : z;
-                    const uint32_t s = seg_of_block(sm.spre, k, i);
-                    const SegView sv = p.segs[s];
-                    const uint32_t lb = i - sm.spre[s];
-                    const uint32_t b = sm.sbl[s] + lb;
-                    uint32_t ta = 0, tb = nt;
-                    while (tb - ta > 1u) {
-                        const uint32_t mid = (ta + tb) >> 1;
-                        if (BI[s * stride + mid] <= lb) ta = mid; else tb = mid;
+                const uint32_t *RB = sm.runbase[0];
+                for (uint32_t e = (uint32_t)tid; e < n_in; e += MT) {
+                    uint32_t sa = 0, sb = k;              // last run with RB[s] <= e (it is not empty)
+                    while (sb - sa > 1u) { const uint32_t sm_ = (sa + sb) >> 1; if (RB[sm_] <= e) sa = sm_; else sb = sm_; }
+                    const uint32_t i = e - RB[sa];
+                    sm.vals[0][e] = p.raw[sm.rs[sa] + i];
+                    if (nt > 1u) {
+                        const uint32_t *O = sm.offs[0] + sa * stride;
+                        uint32_t ta = 0, tb = nt;         // last term with O[t] <= i
+                        while (tb - ta > 1u) { const uint32_t tm = (ta + tb) >> 1; if (O[tm] <= i) ta = tm; else tb = tm; }
+                        sm.tids[0][e] = (uint16_t)((sa << 10) | ta);
                     }
-                    const uint16_t tag = (uint16_t)((s << 10) | ta);
-                    const uint32_t pos0 = bcnt[i];
-                    const uint32_t below = full ? 0u : (uint32_t)bbelow[i];
-                    decode_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off, sv.skip[b].first_doc,
-                                      [&](uint32_t ix, uint32_t id) {
-                                          if (id >= dlo && id <= dhi) {
-                                              const uint32_t pos = pos0 + ix - below;
-                                              sm.vals[0][pos] = id;
-                                              sm.tids[0][pos] = tag;
-                                          }
-                                      });
                 }
             }
             __syncthreads();
-            II2_STAMP(3)      // D: decode
+            II2_STAMP(3)      // D: gather
             // ---- E. fold the runs pairwise ----
             uint32_t cur = 0, nruns = k;
             // One term in the tile (the tiles of large terms — most of the postings): plain two-way merges.
@@ -545,22 +459,22 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
         const uint32_t dlo = td.z, dhi = td.w;
         const bool root_full = dlo == 0u && dhi == 0xFFFFFFFFu;
         // The tile parks its survivors in the scratch array at the input rank of its first posting
-        // (term slots start at the prefix of the terms' upper bounds), which no other tile can reach:
+        // (term slots start at the prefix of the terms' input counts), which no other tile can reach:
         // survivors never outnumber the inputs that precede the next tile.  A later pass packs them.
         const unsigned long long term_slot = p.ub_prefix[t0];
         unsigned long long slot = term_slot;
         uint32_t total = 0;
         if (dlo <= dhi) {
             uint32_t outbuf = 0;
-            if (count_range(dlo, dhi)) {
-                slot = term_slot + (root_full ? 0u : sm.rank);
-                total = merge_range(dlo, dhi, &outbuf, true, !root_full);
+            const bool fits = load_range(dlo, dhi, true);
+            slot = term_slot + sm.rank;                  // rank of the range start (0 for whole-term tiles)
+            if (fits) {
+                total = merge_range(&outbuf, true, !root_full);
                 const uint32_t *V = sm.vals[outbuf];
                 for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
             } else {
                 // the range holds more than LDS (a term whose lists are clustered differently): bisect the
                 // doc range; leaves are handled in doc order and appended to the tile's slot.
-                bool have_slot = false;
                 uint32_t sp = 1;
                 __syncthreads();
                 if (tid == 0) { sm.stk[0][0] = dlo; sm.stk[0][1] = dhi; }
@@ -568,7 +482,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
                     __syncthreads();
                     const uint32_t lo = sm.stk[sp - 1][0], hi = sm.stk[sp - 1][1];
                     sp--;
-                    if (!count_range(lo, hi)) {
+                    if (!load_range(lo, hi, false)) {
                         // lo < hi here: a single doc id never exceeds k postings
                         const uint32_t mid = lo + ((hi - lo) >> 1);
                         __syncthreads();
@@ -579,9 +493,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
                         sp += 2;
                         continue;
                     }
-                    if (!have_slot) { slot = term_slot + sm.rank; have_slot = true; }   // first (lowest) leaf
                     uint32_t ob2 = 0;
-                    const uint32_t c = merge_range(lo, hi, &ob2, true, true);
+                    const uint32_t c = merge_range(&ob2, true, true);
                     const uint32_t *V = sm.vals[ob2];
                     for (uint32_t q = (uint32_t)tid; q < c; q += MT) p.tmp[slot + total + q] = V[q];
                     total += c;
@@ -619,6 +532,31 @@ __global__ void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint
 }
 
 static unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
+
+hipError_t launch_mseg_blocks(const MergeParams &p, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_mseg_blocks, dim3(1), dim3(64), 0, s, p, out);
+    return hipGetLastError();
+}
+hipError_t launch_mdec_counts(const MergeParams &p, uint32_t *counts, hipStream_t s) {
+    const uint64_t waves = (uint64_t)p.seg_cum[p.k] + 1;
+    hipLaunchKernelGGL(k_mdec_counts, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, counts);
+    return hipGetLastError();
+}
+hipError_t launch_mdec_write(const MergeParams &p, const uint64_t *bpo, uint32_t *raw, hipStream_t s) {
+    const uint64_t waves = p.seg_cum[p.k];
+    if (waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_mdec_write, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, bpo, raw);
+    return hipGetLastError();
+}
+hipError_t launch_mpost_off(const MergeParams &p, const uint64_t *bpo, unsigned long long *poff, hipStream_t s) {
+    hipLaunchKernelGGL(k_mpost_off, dim3(grid_for((uint64_t)p.k * (p.n_terms + 1))), dim3(256), 0, s, p, bpo, poff);
+    return hipGetLastError();
+}
+hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s) {
+    if (p.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_tile_ranges, dim3(grid_for((uint64_t)p.n_tiles * p.k)), dim3(256), 0, s, p, (const uint4 *)desc, (uint2 *)rng);
+    return hipGetLastError();
+}
 
 hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_term_ub, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ub, weight, ntl);

@@ -64,15 +64,48 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.batch_q = cap - p.small_max;
     p.wmin = (cap + nt_max - 1u) / nt_max;  // <= cap / wmin <= nt_max terms per batch
     if (p.wmin > p.small_max) p.wmin = p.small_max;
-    p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : cap;
+    p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : (cap / 4u) * 3u;   // exact counts: leave slack for uneven lists
 
-    // ---- plan (device): per-term bounds, batches, tiles ----
+    // ---- pass 1: decode every input list once into a raw scratch array (grow-only aux buffers) ----
+    auto grow = [&](uint8_t *&buf, size_t &cap, size_t bytes) -> bool {
+        if (bytes <= cap) return true;
+        (void)hipStreamSynchronize(st);
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        const size_t want = align_up(bytes + bytes / 8, 1 << 20);
+        if (hipMalloc((void **)&buf, want) != hipSuccess) return false;
+        cap = want;
+        return true;
+    };
+    {
+        uint32_t *d_sb = (uint32_t *)(ctx->d_mail + 16);
+        uint32_t h_sb[2 * MAX_LISTS];
+        HIP_TRY(ctx, launch_mseg_blocks(p, d_sb, st));
+        HIP_TRY(ctx, hipMemcpyAsync(h_sb, d_sb, 2 * k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        uint64_t cum = 0;
+        for (uint32_t s = 0; s < k; s++) {
+            p.seg_b0[s] = h_sb[2 * s];
+            p.seg_cum[s] = (uint32_t)cum;
+            cum += h_sb[2 * s + 1] - h_sb[2 * s];
+        }
+        if (cum >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many input blocks");
+        p.seg_cum[k] = (uint32_t)cum;
+    }
+    const size_t totalB = p.seg_cum[k];
     const size_t n1 = (size_t)T + 1;
-    const size_t scan_b = scan_temp_bytes(n1);
-    size_t need = 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) + scan_b + 4096;
+    const size_t scan_b = scan_temp_bytes(std::max<size_t>(n1, totalB + 1));
+    // ws: block counts / positions, list offsets, plan arrays
+    size_t need = align_up((totalB + 1) * sizeof(uint32_t)) + align_up((totalB + 1) * sizeof(uint64_t)) +
+                  align_up((size_t)k * n1 * sizeof(uint64_t)) + 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) +
+                  scan_b + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     uint8_t *cur = ctx->ws;
+    uint32_t *d_bcnt = carve<uint32_t>(cur, totalB + 1);
+    uint64_t *d_bpo = carve<uint64_t>(cur, totalB + 1);
+    unsigned long long *d_poff = (unsigned long long *)carve<uint64_t>(cur, (size_t)k * n1);
     uint32_t *d_ub = carve<uint32_t>(cur, n1);
     uint32_t *d_w = carve<uint32_t>(cur, n1);
     uint32_t *d_ntl = carve<uint32_t>(cur, n1);
@@ -85,6 +118,20 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint64_t *d_ubpre = carve<uint64_t>(cur, n1);
     void *d_scan = cur;
 
+    HIP_TRY(ctx, launch_mdec_counts(p, d_bcnt, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_bcnt, d_bpo, totalB + 1, st));
+    uint64_t n_in = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&n_in, d_bpo + totalB, sizeof n_in, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (n_in >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: more than 2^32 input postings in one call");
+    if (!grow(ctx->aux2, ctx->aux2_cap, (n_in + 64) * sizeof(uint32_t))) return fail(ctx, II2_ENOMEM, "merge raw scratch allocation failed");
+    uint32_t *d_raw = (uint32_t *)ctx->aux2;
+    HIP_TRY(ctx, launch_mdec_write(p, d_bpo, d_raw, st));
+    HIP_TRY(ctx, launch_mpost_off(p, d_bpo, d_poff, st));
+    p.raw = d_raw;
+    p.poff = d_poff;
+
+    // ---- plan (device): exact per-term counts, batches, tiles ----
     HIP_TRY(ctx, launch_merge_plan1(p, d_ub, d_w, d_ntl, st));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_w, d_wpre, n1, st));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_ub, d_ubpre, n1, st));
@@ -93,35 +140,29 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
     HIP_TRY(ctx, launch_merge_term_tile(p, d_ntl, d_head, d_hpre, d_lpre, d_tt, st));
     uint32_t n_tiles = 0;
-    uint64_t total_ub = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&n_tiles, d_tt + T, sizeof n_tiles, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(&total_ub, d_ubpre + T, sizeof total_ub, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     p.n_tiles = n_tiles;
     p.ub_prefix = (const unsigned long long *)d_ubpre;
 
-    // ---- per-tile arrays and the scratch the tiles park their survivors in (grow-only aux buffer) ----
+    // ---- per-tile arrays and the scratch the tiles park their survivors in ----
     const size_t nt1 = (size_t)n_tiles + 1;
     const size_t scan_t = scan_temp_bytes(nt1);
     const size_t aux_need = align_up(nt1 * 16) + align_up(nt1 * sizeof(uint32_t)) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
-                            align_up((total_ub + 64) * sizeof(uint32_t)) + 4096;
-    if (aux_need > ctx->aux_cap) {
-        if (ctx->aux) (void)hipFree(ctx->aux);
-        ctx->aux = nullptr;
-        ctx->aux_cap = 0;
-        const size_t want = align_up(aux_need + aux_need / 8, 1 << 20);
-        if (hipMalloc((void **)&ctx->aux, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
-        ctx->aux_cap = want;
-    }
+                            align_up(nt1 * k * sizeof(uint2)) + align_up((n_in + 64) * sizeof(uint32_t)) + 4096;
+    if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
     void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
     p.tile_count = carve<uint32_t>(ac, nt1);
     p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
     uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
     void *d_scan_t = carve<uint8_t>(ac, scan_t);
-    p.tmp = carve<uint32_t>(ac, total_ub + 64);
+    uint2 *d_rng = carve<uint2>(ac, nt1 * k);
+    p.tmp = carve<uint32_t>(ac, n_in + 64);
 
     HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, d_tile_desc, st));
+    HIP_TRY(ctx, launch_merge_tile_ranges(p, d_tile_desc, d_rng, st));
+    p.rng = d_rng;
     p.out_counts = d_cnt;
     p.out_values = d_out_values;
     p.out_cap = out_cap;
