@@ -189,6 +189,8 @@ static void seg_release(ii2_seg *s) {
         if (s->d_payload) (void)hipFree(s->d_payload);
     }
     if (s->d_last_doc) (void)hipFree(s->d_last_doc);
+    if (s->d_cnt) (void)hipFree(s->d_cnt);
+    if (s->d_blk_list) (void)hipFree(s->d_blk_list);
     delete s;
 }
 
@@ -201,7 +203,12 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
     }
     if (hipMalloc((void **)&seg->d_last_doc, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
-    HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_last_doc, ctx->stream));
+    if (hipMalloc((void **)&seg->d_cnt, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&seg->d_blk_list, (seg->n_blocks + 1) * sizeof(uint32_t)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    HIP_TRY(ctx, hipMemsetAsync(seg->d_blk_list, 0xFF, (seg->n_blocks + 1) * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_cnt, seg->d_blk_list, seg->d_last_doc,
+                                      ctx->stream));
     seg->h_blk_off.resize(seg->n_lists + 1);
     HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -345,6 +352,15 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const ui
     }
     int rc = seg_finish(ctx, seg.get());
     if (rc) return rc;
+    {   // block fill rule (every block full but a list's last): the merge places decoded blocks by it
+        uint32_t *d_bad = (uint32_t *)ctx->d_mail;
+        uint32_t bad = 0;
+        HIP_TRY(ctx, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, launch_validate_counts(seg->d_blk_off, seg->d_blk_list, seg->d_skip, seg->d_payload, nb, d_bad, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad) return fail(ctx, II2_EINVAL, "ii2_seg_import: malformed DV1 segment (a block that is not its list's last must hold 256 postings)");
+    }
     *out = seg.release();
     return II2_OK;
 }

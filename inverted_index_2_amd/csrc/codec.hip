@@ -150,31 +150,35 @@ hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, 
     return hipGetLastError();
 }
 
-// last doc id of every list: one wave decodes the list's last block
+// per list: last doc id, posting count, and the owner entry of each of its blocks — one wave
+// decodes the list's last block (all other blocks hold exactly II2_DV1_BLOCK postings)
 __global__ __launch_bounds__(256) void k_list_last_doc(const uint32_t *__restrict__ blk_off, const ii2_skip *__restrict__ skip,
                                                        const uint8_t *__restrict__ payload, uint64_t n_lists,
+                                                       uint32_t *__restrict__ cnt, uint32_t *__restrict__ blk_list,
                                                        uint32_t *__restrict__ last_doc) {
     const uint64_t li = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (li >= n_lists) return;
     const uint32_t b0 = blk_off[li], b1 = blk_off[li + 1];
-    if (b1 == b0) { if (lane_id() == 0) last_doc[li] = 0; return; }
+    if (b1 == b0) { if (lane_id() == 0) { last_doc[li] = 0; cnt[li] = 0; } return; }
+    for (uint32_t b = b0 + (uint32_t)lane_id(); b < b1; b += 64u) blk_list[b] = (uint32_t)li;
     const uint32_t b = b1 - 1u;
     uint32_t mx_ix = 0, mx_id = skip[b].first_doc;
-    decode_block_wave(payload, skip[b].byte_off, skip[b + 1].byte_off, skip[b].first_doc,
-                      [&](uint32_t ix, uint32_t id) { if (ix >= mx_ix) { mx_ix = ix; mx_id = id; } });
+    const uint32_t c = decode_block_wave(payload, skip[b].byte_off, skip[b + 1].byte_off, skip[b].first_doc,
+                                         [&](uint32_t ix, uint32_t id) { if (ix >= mx_ix) { mx_ix = ix; mx_id = id; } });
     // the lane holding the highest posting index has the last id
     uint32_t best_ix = mx_ix, best_id = mx_id;
     for (int d = 32; d >= 1; d >>= 1) {
         const uint32_t oi = (uint32_t)__shfl_xor((int)best_ix, d, 64), od = (uint32_t)__shfl_xor((int)best_id, d, 64);
         if (oi > best_ix) { best_ix = oi; best_id = od; }
     }
-    if (lane_id() == 0) last_doc[li] = best_id;
+    if (lane_id() == 0) { last_doc[li] = best_id; cnt[li] = (b1 - b0 - 1u) * II2_DV1_BLOCK + c; }
 }
 
-hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists,
-                                uint32_t *last_doc, hipStream_t s) {
+hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists, uint32_t *cnt,
+                                uint32_t *blk_list, uint32_t *last_doc, hipStream_t s) {
     if (n_lists == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_list_last_doc, dim3((unsigned)((n_lists + 3) / 4)), dim3(256), 0, s, blk_off, skip, payload, n_lists, last_doc);
+    hipLaunchKernelGGL(k_list_last_doc, dim3((unsigned)((n_lists + 3) / 4)), dim3(256), 0, s, blk_off, skip, payload, n_lists, cnt, blk_list,
+                       last_doc);
     return hipGetLastError();
 }
 
@@ -195,6 +199,26 @@ hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const 
                                uint32_t *bad, hipStream_t s) {
     const uint64_t n = (n_lists > n_blocks ? n_lists : n_blocks) + 1;
     hipLaunchKernelGGL(k_validate_seg, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blk_off, n_lists, skip, n_blocks, n_bytes, bad);
+    return hipGetLastError();
+}
+
+// every block but a list's last must hold exactly II2_DV1_BLOCK postings, the last one 1..II2_DV1_BLOCK:
+// the merge places decoded blocks by that rule.  One wave per block (import is a one-time cost).
+__global__ __launch_bounds__(256) void k_validate_counts(const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_list,
+                                                         const ii2_skip *__restrict__ skip, const uint8_t *__restrict__ payload,
+                                                         uint64_t n_blocks, uint32_t *__restrict__ bad) {
+    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= n_blocks) return;
+    const uint32_t li = blk_list[b];
+    const uint32_t c = count_block_wave(payload, skip[b].byte_off, skip[b + 1].byte_off);
+    const bool last = (uint32_t)b + 1u == blk_off[li + 1];
+    if (lane_id() == 0 && (c > II2_DV1_BLOCK || (!last && c != II2_DV1_BLOCK))) atomicOr(bad, 8u);
+}
+
+hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_list, const ii2_skip *skip, const uint8_t *payload,
+                                  uint64_t n_blocks, uint32_t *bad, hipStream_t s) {
+    if (n_blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_validate_counts, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, s, blk_off, blk_list, skip, payload, n_blocks, bad);
     return hipGetLastError();
 }
 

@@ -254,6 +254,62 @@ __device__ __forceinline__ bool decode_rows16(Load16 load16, uint32_t q0, uint32
     return rows16_finish(q0, q1, first_doc, row_valid, base, w);
 }
 
+// General row decoder: one block per 16-lane row, 16 payload bytes per lane and pass (256 per row
+// and pass), any gap widths.  Each lane walks its 16 bytes serially (its position inside a varint
+// comes from the four bytes before them), the row scans the lanes' sums and posting counts, then
+// every lane emits the postings that end inside its bytes: emit(idx_in_block, doc_id), posting 0
+// by the row's lane 0.  All 64 lanes must call; rows without a block pass row_valid = false.
+// Reads up to 16 bytes past q1 (segments carry that padding).
+template <class Emit>
+__device__ __forceinline__ void decode_rows16_any(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1, uint32_t first_doc,
+                                                  bool row_valid, Emit emit) {
+    const uint32_t rl = (uint32_t)lane_id() & 15u;
+    const int row_last = lane_id() | 15;
+    const uint32_t len = row_valid ? q1 - q0 : 0u;
+    if (row_valid && rl == 0u) emit(0u, first_doc);
+    uint32_t run_id = first_doc, run_ix = 1u;
+    for (uint32_t off = 0; __ballot(off < len) != 0ull; off += 256u) {
+        const uint32_t my = off + 16u * rl;
+        const uint32_t nb = my < len ? (len - my < 16u ? len - my : 16u) : 0u;
+        uint4 w4 = make_uint4(0, 0, 0, 0);
+        uint32_t prev = 0;
+        if (nb) {
+            __builtin_memcpy(&w4, payload + q0 + my, 16);
+            if (my) prev = load_u32_unaligned(payload + q0 + my - 4u);
+        }
+        uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+        if (nb < 16u) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t n = nb > 4u * j ? (nb - 4u * j < 4u ? nb - 4u * j : 4u) : 0u;
+                w[j] &= n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
+            }
+        }
+        // continuation bytes pending right before my first byte (varints are <= 5 bytes)
+        uint32_t sh = 7u * ((uint32_t)__clz((int)~(prev | 0x7F7F7F7Fu)) >> 3);
+        uint32_t val[16];
+        uint32_t sum = 0, tmask = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+            sum += (c & 0x7Fu) << sh;
+            if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
+            else { sh = 0u; tmask |= 1u << i; }
+            val[i] = sum;
+        }
+        tmask &= (1u << nb) - 1u;           // nb <= 16
+        const uint32_t cnt = (uint32_t)__popc(tmask);
+        const uint32_t isum = row_incl_scan(sum), icnt = row_incl_scan(cnt);
+        const uint32_t base = run_id + isum - sum;
+        uint32_t ix = run_ix + icnt - cnt;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if ((tmask >> i) & 1u) { emit(ix, base + val[i]); ix++; }
+        run_id += (uint32_t)__shfl((int)isum, row_last, 64);
+        run_ix += (uint32_t)__shfl((int)icnt, row_last, 64);
+    }
+}
+
 // Posting count of a block without decoding ids (1 + terminators).  Wave-uniform result.
 __device__ __forceinline__ uint32_t count_block_wave(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1) {
     const int l = lane_id();

@@ -60,6 +60,8 @@ struct ii2_seg {
     ii2_skip *d_skip = nullptr;      // [n_blocks+1]
     uint8_t *d_payload = nullptr;    // [n_bytes + 16]
     uint32_t *d_last_doc = nullptr;  // [n_lists] last doc id of each list (0 for an empty list)
+    uint32_t *d_cnt = nullptr;       // [n_lists] postings of each list
+    uint32_t *d_blk_list = nullptr;  // [n_blocks] list owning each block (0xFFFFFFFF: none of this view's lists)
     std::vector<uint32_t> h_blk_off; // host mirror of d_blk_off
     // per list: first_doc of its first and of its last block (tile-height heuristic), fetched once
     mutable std::unordered_map<uint64_t, std::pair<uint32_t, uint32_t>> span_cache;
@@ -90,10 +92,13 @@ struct ListView {
 };
 
 struct SegView {
-    const uint32_t *blk_off;
+    const uint32_t *blk_off;    // [n_terms+1] first block of each aligned term slot
     const ii2_skip *skip;
     const uint8_t *payload;
-    const uint32_t *last_doc;   // [n_lists] last doc id of each list (same indexing as blk_off)
+    const uint32_t *cnt;        // [n_terms] postings of each list (same indexing as blk_off)
+    const uint32_t *blk_list;   // [n_blocks of the store] list that owns each block, in the segment's own numbering
+    uint32_t list_base;         // blk_off / cnt point at this list of the segment (blk_list[b] - list_base = term slot)
+    uint32_t pad;
 };
 
 constexpr uint32_t MAX_LISTS = II2_MAX_LISTS;
@@ -141,8 +146,10 @@ hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64
                             uint32_t *values, hipStream_t s);
 hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, uint64_t n_lists, uint64_t *post_off, hipStream_t s);
 hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, hipStream_t s);
-hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists,
+hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists, uint32_t *cnt, uint32_t *blk_list,
                                 uint32_t *last_doc, hipStream_t s);
+hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_list, const ii2_skip *skip, const uint8_t *payload,
+                                  uint64_t n_blocks, uint32_t *bad, hipStream_t s);
 hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const ii2_skip *skip, uint64_t n_blocks, uint64_t n_bytes,
                                uint32_t *bad, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
@@ -160,8 +167,18 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
 constexpr uint32_t MERGE_CAP = 4096;        // postings per tile (LDS)
 constexpr uint32_t MERGE_OFFMAX = 2176;     // (terms per batch + 1) * k  must fit
 constexpr uint32_t MERGE_THREADS = 512;     // threads per workgroup of the tile kernel
-struct MergeParams {
+// pass 1 (decode) sees the segments; the plan and the tile kernels only see what pass 1 decoded
+struct MergeSegs {
     SegView segs[MAX_LISTS];
+    uint32_t k;
+    uint32_t pad0;
+    uint64_t n_terms;
+    uint32_t seg_b0[MAX_LISTS];       // first block of every segment's term range
+    uint32_t seg_cum[MAX_LISTS + 1];  // prefix of the segments' block counts (global block numbering)
+};
+static_assert(sizeof(MergeSegs) <= 4000, "MergeSegs is passed by value as a kernel argument");
+
+struct MergeParams {
     uint32_t k;
     uint32_t n_tiles;
     uint64_t n_terms;
@@ -172,8 +189,6 @@ struct MergeParams {
     uint32_t wmin;                // minimum packing weight of a term (bounds terms per batch)
     uint32_t batch_q;             // batch id = weight prefix / batch_q
     uint32_t pad0;
-    uint32_t seg_b0[MAX_LISTS];       // first block of every segment's term range
-    uint32_t seg_cum[MAX_LISTS + 1];  // prefix of the segments' block counts (global block numbering)
     const uint32_t *raw;              // pass 1 output: every input list decoded, back to back
     const unsigned long long *poff;   // [k * (n_terms+1)] position in raw of list (s, t)
     const uint2 *rng;                 // [n_tiles * k] where list (s, t0) enters / leaves the tile's doc range
@@ -194,10 +209,10 @@ hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, con
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0 = nullptr,
                               hipEvent_t ev1 = nullptr);
-hipError_t launch_mseg_blocks(const MergeParams &p, uint32_t *out, hipStream_t s);
-hipError_t launch_mdec_counts(const MergeParams &p, uint32_t *counts, hipStream_t s);
-hipError_t launch_mdec_write(const MergeParams &p, const uint64_t *bpo, uint32_t *raw, hipStream_t s);
-hipError_t launch_mpost_off(const MergeParams &p, const uint64_t *bpo, unsigned long long *poff, hipStream_t s);
+hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *out, hipStream_t s);
+hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s);
+hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, uint32_t *big_g, unsigned long long *big_pos,
+                             uint32_t *nbig, uint32_t grid_rows, hipStream_t s);
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s);
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);

@@ -32,7 +32,7 @@ constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
 
 // ---- pass 1: decode everything once --------------------------------------------------------
 // global block g of the merge input -> (segment, block of that segment)
-__device__ __forceinline__ uint32_t seg_of_gblock(const MergeParams &p, uint32_t g) {
+__device__ __forceinline__ uint32_t seg_of_gblock(const MergeSegs &p, uint32_t g) {
     uint32_t lo = 0, hi = p.k;          // seg_cum[lo] <= g < seg_cum[hi]
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -41,43 +41,100 @@ __device__ __forceinline__ uint32_t seg_of_gblock(const MergeParams &p, uint32_t
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_mdec_counts(MergeParams p, uint32_t *__restrict__ counts) {
-    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t total = p.seg_cum[p.k];
-    if (g > total) return;
-    if (g == total) { if (lane_id() == 0) counts[g] = 0; return; }
-    const uint32_t s = seg_of_gblock(p, (uint32_t)g);
-    const SegView sv = p.segs[s];
-    const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
-    const uint32_t c = count_block_wave(sv.payload, sv.skip[b].byte_off, sv.skip[b + 1].byte_off);
-    if (lane_id() == 0) counts[g] = c;
-}
-
-__global__ __launch_bounds__(256) void k_mdec_write(MergeParams p, const uint64_t *__restrict__ bpo, uint32_t *__restrict__ raw) {
-    const uint64_t g = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (g >= p.seg_cum[p.k]) return;
-    const uint32_t s = seg_of_gblock(p, (uint32_t)g);
-    const SegView sv = p.segs[s];
-    const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
-    uint32_t *out = raw + bpo[g];
-    decode_block_wave(GlobalBytes{sv.payload}, sv.skip[b].byte_off, sv.skip[b + 1].byte_off, sv.skip[b].first_doc,
-                      [&](uint32_t ix, uint32_t id) { out[ix] = id; });
-}
-
-// poff[s * (T+1) + t] = position in raw of the first posting of list (s, t)
-__global__ void k_mpost_off(MergeParams p, const uint64_t *__restrict__ bpo, unsigned long long *__restrict__ poff) {
+// lc[s * (T+1) + t] = postings of list (s, t) (0 for t == T); its exclusive scan is poff
+__global__ void k_mlist_counts(MergeSegs p, uint32_t *__restrict__ lc) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t n1 = p.n_terms + 1;
     if (i >= (uint64_t)p.k * n1) return;
     const uint32_t s = (uint32_t)(i / n1);
     const uint64_t t = i % n1;
-    poff[i] = bpo[p.seg_cum[s] + (p.segs[s].blk_off[t] - p.seg_b0[s])];
+    lc[i] = t < p.n_terms ? p.segs[s].cnt[t] : 0u;
 }
 
 // first block of every segment's term range and the end of it: [2s] = blk_off[0], [2s+1] = blk_off[T]
-__global__ void k_mseg_blocks(MergeParams p, uint32_t *__restrict__ out) {
+__global__ void k_mseg_blocks(MergeSegs p, uint32_t *__restrict__ out) {
     const uint32_t s = threadIdx.x;
     if (s < p.k) { out[2 * s] = p.segs[s].blk_off[0]; out[2 * s + 1] = p.segs[s].blk_off[p.n_terms]; }
+}
+
+// Every block but a list's last holds II2_DV1_BLOCK postings, so block j of list (s, t) decodes to
+// raw[poff[s, t] + 256 j ...].  Most lists of a Zipf index are tiny (a handful of postings per segment
+// and term): blocks with up to TINY_BYTES of payload are decoded one per LANE from registers (all seven
+// possible dwords fetched at once); the others are appended to a list and decoded one per 16-lane ROW.
+constexpr uint32_t TINY_BYTES = 28;
+
+__global__ __launch_bounds__(256) void k_mdec_lane(MergeSegs p, const unsigned long long *__restrict__ poff, uint32_t *__restrict__ raw,
+                                                    uint32_t *__restrict__ big_g, unsigned long long *__restrict__ big_pos,
+                                                    uint32_t *__restrict__ nbig) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool big = false;
+    unsigned long long pos = 0;
+    if (g < p.seg_cum[p.k]) {
+        const uint32_t s = seg_of_gblock(p, (uint32_t)g);
+        const SegView sv = p.segs[s];
+        const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
+        const uint32_t t = sv.blk_list[b] - sv.list_base;
+        if (t < p.n_terms) {
+            pos = poff[(uint64_t)s * (p.n_terms + 1) + t] + (unsigned long long)(b - sv.blk_off[t]) * II2_DV1_BLOCK;
+            const ii2_skip e0 = sv.skip[b];
+            const uint32_t q0 = e0.byte_off, len = sv.skip[b + 1].byte_off - q0;
+            if (len <= TINY_BYTES) {
+                uint32_t w[7];
+#pragma unroll
+                for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(sv.payload + q0 + 4u * j) : 0u;
+                uint32_t *out = raw + pos;
+                uint32_t cur = e0.first_doc, acc = 0, sh = 0;
+                *out++ = cur;
+#pragma unroll
+                for (int j = 0; j < 28; j++) {
+                    if ((uint32_t)j < len) {
+                        const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                        acc += (c & 0x7Fu) << sh;
+                        if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
+                        else { cur += acc; *out++ = cur; acc = 0; sh = 0; }
+                    }
+                }
+            } else big = true;
+        }
+    }
+    // wave-aggregated append of the blocks left for the row kernel
+    const unsigned long long m = __ballot(big);
+    if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane_id() == leader) base = atomicAdd(nbig, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (big) {
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+            big_g[at] = (uint32_t)g;
+            big_pos[at] = pos;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__restrict__ raw, const uint32_t *__restrict__ big_g,
+                                                    const unsigned long long *__restrict__ big_pos, const uint32_t *__restrict__ nbig) {
+    const uint32_t n = *nbig;
+    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    for (uint64_t z = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; __ballot(z < n) != 0ull; z += stride) {
+        const bool rv = z < n;
+        uint32_t q0 = 0, q1 = 0, first = 0;
+        uint32_t *out = raw;
+        const uint8_t *pl = nullptr;     // rows of one wave may read different segments
+        if (rv) {
+            const uint32_t g = big_g[z];
+            const uint32_t s = seg_of_gblock(p, g);
+            const SegView sv = p.segs[s];
+            const uint32_t b = p.seg_b0[s] + (g - p.seg_cum[s]);
+            const ii2_skip e0 = sv.skip[b];
+            q0 = e0.byte_off;
+            q1 = sv.skip[b + 1].byte_off;
+            first = e0.first_doc;
+            out = raw + big_pos[z];
+            pl = sv.payload;
+        }
+        decode_rows16_any(pl, q0, q1, first, rv, [&](uint32_t ix, uint32_t id) { out[ix] = id; });
+    }
 }
 
 // ---- plan -------------------------------------------------------------------------------
@@ -533,23 +590,23 @@ __global__ void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint
 
 static unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-hipError_t launch_mseg_blocks(const MergeParams &p, uint32_t *out, hipStream_t s) {
+hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *out, hipStream_t s) {
     hipLaunchKernelGGL(k_mseg_blocks, dim3(1), dim3(64), 0, s, p, out);
     return hipGetLastError();
 }
-hipError_t launch_mdec_counts(const MergeParams &p, uint32_t *counts, hipStream_t s) {
-    const uint64_t waves = (uint64_t)p.seg_cum[p.k] + 1;
-    hipLaunchKernelGGL(k_mdec_counts, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, counts);
+hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s) {
+    hipLaunchKernelGGL(k_mlist_counts, dim3(grid_for((uint64_t)p.k * (p.n_terms + 1))), dim3(256), 0, s, p, lc);
     return hipGetLastError();
 }
-hipError_t launch_mdec_write(const MergeParams &p, const uint64_t *bpo, uint32_t *raw, hipStream_t s) {
-    const uint64_t waves = p.seg_cum[p.k];
-    if (waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mdec_write, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, bpo, raw);
-    return hipGetLastError();
-}
-hipError_t launch_mpost_off(const MergeParams &p, const uint64_t *bpo, unsigned long long *poff, hipStream_t s) {
-    hipLaunchKernelGGL(k_mpost_off, dim3(grid_for((uint64_t)p.k * (p.n_terms + 1))), dim3(256), 0, s, p, bpo, poff);
+hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, uint32_t *big_g, unsigned long long *big_pos,
+                             uint32_t *nbig, uint32_t grid_rows, hipStream_t s) {
+    const uint64_t total = p.seg_cum[p.k];
+    if (total == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(nbig, 0, sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_mdec_lane, dim3(grid_for(total)), dim3(256), 0, s, p, poff, raw, big_g, big_pos, nbig);
+    hipLaunchKernelGGL(k_mdec_rows, dim3(grid_rows), dim3(256), 0, s, p, raw, (const uint32_t *)big_g, (const unsigned long long *)big_pos,
+                       (const uint32_t *)nbig);
     return hipGetLastError();
 }
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s) {

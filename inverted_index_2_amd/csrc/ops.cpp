@@ -50,7 +50,11 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     if (T >= (1ull << 31) - 2) return fail(ctx, II2_ERANGE, "too many term slots");
     MergeParams p;
     std::memset(&p, 0, sizeof p);
-    for (uint32_t s = 0; s < k; s++) p.segs[s] = views[s];
+    MergeSegs ms;
+    std::memset(&ms, 0, sizeof ms);
+    for (uint32_t s = 0; s < k; s++) ms.segs[s] = views[s];
+    ms.k = k;
+    ms.n_terms = T;
     p.k = k;
     p.n_terms = T;
     p.tomb = tomb ? tomb->d_words : nullptr;
@@ -81,31 +85,34 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     {
         uint32_t *d_sb = (uint32_t *)(ctx->d_mail + 16);
         uint32_t h_sb[2 * MAX_LISTS];
-        HIP_TRY(ctx, launch_mseg_blocks(p, d_sb, st));
+        HIP_TRY(ctx, launch_mseg_blocks(ms, d_sb, st));
         HIP_TRY(ctx, hipMemcpyAsync(h_sb, d_sb, 2 * k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         uint64_t cum = 0;
         for (uint32_t s = 0; s < k; s++) {
-            p.seg_b0[s] = h_sb[2 * s];
-            p.seg_cum[s] = (uint32_t)cum;
+            ms.seg_b0[s] = h_sb[2 * s];
+            ms.seg_cum[s] = (uint32_t)cum;
             cum += h_sb[2 * s + 1] - h_sb[2 * s];
         }
         if (cum >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many input blocks");
-        p.seg_cum[k] = (uint32_t)cum;
+        ms.seg_cum[k] = (uint32_t)cum;
     }
-    const size_t totalB = p.seg_cum[k];
+    const size_t totalB = ms.seg_cum[k];
     const size_t n1 = (size_t)T + 1;
-    const size_t scan_b = scan_temp_bytes(std::max<size_t>(n1, totalB + 1));
-    // ws: block counts / positions, list offsets, plan arrays
-    size_t need = align_up((totalB + 1) * sizeof(uint32_t)) + align_up((totalB + 1) * sizeof(uint64_t)) +
-                  align_up((size_t)k * n1 * sizeof(uint64_t)) + 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) +
+    const size_t nl = (size_t)k * n1;
+    const size_t scan_b = scan_temp_bytes(std::max<size_t>(nl + 1, totalB + 1));
+    // ws: list counts / offsets, the list of non-tiny blocks, plan arrays
+    size_t need = align_up((totalB + 1) * sizeof(uint32_t)) + align_up((totalB + 1) * sizeof(uint64_t)) + align_up(nl * sizeof(uint32_t)) +
+                  align_up(nl * sizeof(uint64_t)) + 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) +
                   scan_b + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     uint8_t *cur = ctx->ws;
-    uint32_t *d_bcnt = carve<uint32_t>(cur, totalB + 1);
-    uint64_t *d_bpo = carve<uint64_t>(cur, totalB + 1);
-    unsigned long long *d_poff = (unsigned long long *)carve<uint64_t>(cur, (size_t)k * n1);
+    uint32_t *d_big_g = carve<uint32_t>(cur, totalB + 1);
+    unsigned long long *d_big_pos = (unsigned long long *)carve<uint64_t>(cur, totalB + 1);
+    uint32_t *d_nbig = (uint32_t *)(ctx->d_mail + 100);
+    uint32_t *d_lc = carve<uint32_t>(cur, nl);
+    unsigned long long *d_poff = (unsigned long long *)carve<uint64_t>(cur, nl);
     uint32_t *d_ub = carve<uint32_t>(cur, n1);
     uint32_t *d_w = carve<uint32_t>(cur, n1);
     uint32_t *d_ntl = carve<uint32_t>(cur, n1);
@@ -118,16 +125,16 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint64_t *d_ubpre = carve<uint64_t>(cur, n1);
     void *d_scan = cur;
 
-    HIP_TRY(ctx, launch_mdec_counts(p, d_bcnt, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_bcnt, d_bpo, totalB + 1, st));
+    // list (s, t) goes to raw[poff[s, t] ...]: the segments know their lists' posting counts
+    HIP_TRY(ctx, launch_mlist_counts(ms, d_lc, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_lc, (uint64_t *)d_poff, nl, st));
     uint64_t n_in = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_in, d_bpo + totalB, sizeof n_in, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&n_in, d_poff + (nl - 1), sizeof n_in, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (n_in >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: more than 2^32 input postings in one call");
     if (!grow(ctx->aux2, ctx->aux2_cap, (n_in + 64) * sizeof(uint32_t))) return fail(ctx, II2_ENOMEM, "merge raw scratch allocation failed");
     uint32_t *d_raw = (uint32_t *)ctx->aux2;
-    HIP_TRY(ctx, launch_mdec_write(p, d_bpo, d_raw, st));
-    HIP_TRY(ctx, launch_mpost_off(p, d_bpo, d_poff, st));
+    HIP_TRY(ctx, launch_mdec_write(ms, d_poff, d_raw, d_big_g, d_big_pos, d_nbig, (uint32_t)ctx->cu_count * 8u, st));
     p.raw = d_raw;
     p.poff = d_poff;
 
@@ -213,7 +220,7 @@ static int merge_unlocked(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, 
     std::vector<SegView> views(k);
     uint64_t n_in = 0;
     for (uint32_t s = 0; s < k; s++) {
-        views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_last_doc};
+        views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt, segs[s]->d_blk_list, 0u, 0u};
         n_in += segs[s]->n_postings;
     }
     ii2_merge_stats local;
@@ -269,7 +276,7 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
         const uint64_t li = list_idx ? list_idx[i] : 0;
         if (!segs[i] || segs[i]->ctx != ctx || li >= segs[i]->n_lists) return fail(ctx, II2_EINVAL, "ii2_union: bad list");
         // a one-term view of the segment: blk_off shifted to the list
-        views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_last_doc + li};
+        views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_cnt + li, segs[i]->d_blk_list, (uint32_t)li, 0u};
         any |= segs[i]->h_blk_off[li + 1] > segs[i]->h_blk_off[li];
     }
     if (!any) { *count = 0; return II2_OK; }
