@@ -191,7 +191,7 @@ struct MergeParams {
     uint32_t pad0;
     const uint32_t *raw;              // pass 1 output: every input list decoded, back to back
     const unsigned long long *poff;   // [k * (n_terms+1)] position in raw of list (s, t)
-    const uint2 *rng;                 // [n_tiles * k] where list (s, t0) enters / leaves the tile's doc range
+    const uint4 *rng;                 // [2 * n_tiles * k] the slice of list (s, t0) inside the tile's doc range (k_merge_tile_ranges)
     const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' input counts: scratch slot of each term
     uint32_t *tmp;                // scratch: parked survivors
     uint32_t *tile_count;         // [n_tiles+1] survivors per tile

@@ -29,6 +29,9 @@ constexpr uint32_t MCAP = MERGE_CAP;              // postings per tile
 constexpr uint32_t OFFMAX = MERGE_OFFMAX;         // (nt+1) * k table entries
 constexpr uint32_t MT = MERGE_THREADS;            // threads per workgroup of the tile kernel
 constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
+constexpr uint32_t NBK = 4096;                    // buckets of the single-term fold (8 per thread)
+constexpr uint32_t BKT_LIMIT = 24;                // fullest bucket the bucket fold accepts
+static_assert(NBK == 8u * MT && NBK + 4u <= 2u * OFFMAX, "bucket counters alias the list-offset table");
 
 // ---- pass 1: decode everything once --------------------------------------------------------
 // global block g of the merge input -> (segment, block of that segment)
@@ -226,9 +229,10 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
     }
 }
 
-// where every segment's list enters and leaves a tile's doc range: rng[tile * k + s] = (first, end)
-// posting index relative to the start of list (s, t0)
-__global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, uint2 *__restrict__ rng) {
+// where every segment's list enters and leaves a tile's doc range: rng[2 * (tile * k + s)] =
+// (position in raw of the first posting inside the range: lo, hi; postings inside; postings of list (s, t0) before it),
+// rng[.. + 1] = (first doc, last doc of the slice, -, -)
+__global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, uint4 *__restrict__ rng) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)p.n_tiles * p.k) return;
     const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
@@ -236,10 +240,10 @@ __global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ des
     const uint64_t n1 = p.n_terms + 1;
     const uint64_t beg = p.poff[s * n1 + td.x], end = p.poff[s * n1 + td.y];
     const uint32_t len = (uint32_t)(end - beg);
+    const uint32_t *lst = p.raw + beg;
     uint32_t a = 0, e = len;
     if (td.z > td.w) { a = 0; e = 0; }                       // empty doc range
     else if (!(td.z == 0u && td.w == 0xFFFFFFFFu)) {
-        const uint32_t *lst = p.raw + beg;
         uint32_t lo = 0, hi = len;
         while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] < td.z) lo = mid + 1u; else hi = mid; }
         a = lo;
@@ -247,7 +251,9 @@ __global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ des
         while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
         e = lo;
     }
-    rng[i] = make_uint2(a, e);
+    const uint64_t rs = beg + a;
+    rng[2 * i] = make_uint4((uint32_t)rs, (uint32_t)(rs >> 32), e - a, a);
+    rng[2 * i + 1] = e > a ? make_uint4(lst[a], lst[e - 1u], 0u, 0u) : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------
@@ -259,7 +265,10 @@ struct __align__(16) MergeSmem {
     unsigned long long rs[MAX_LISTS];   // position in raw of each run's first posting
     uint32_t spre[MAX_LISTS + 1];       // run lengths
     uint32_t sbl_rank[MAX_LISTS];       // postings of each list that precede the range
+    uint32_t rmin[MAX_LISTS], rmax[MAX_LISTS];   // first / last doc of each run (single-term tiles)
     uint32_t wsum[MW];
+    uint32_t wmax[MW];
+    uint32_t vmin, vmax;                // doc range the tile's postings really span
     uint32_t n_in;
     uint32_t rank;                      // input postings of the tile's term(s) that precede the tile's doc range
     uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
@@ -308,23 +317,34 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
         // Returns false when the range does not fit LDS.
         auto load_range = [&](uint32_t dlo, uint32_t dhi, bool root) -> bool {
             __syncthreads();
+            if (nt == 1u && k > 1u) {       // bucket counters of the single-term fold (they live in the unused list-offset table)
+                uint4 *z = reinterpret_cast<uint4 *>(&sm.offs[0][0]);
+                for (uint32_t i = (uint32_t)tid; i < (NBK + 4u) / 4u; i += MT) z[i] = make_uint4(0, 0, 0, 0);
+            }
             if ((uint32_t)tid < k) {
-                const uint64_t beg = p.poff[(uint32_t)tid * n1 + t0], end = p.poff[(uint32_t)tid * n1 + t1];
-                const uint32_t len = (uint32_t)(end - beg);
-                uint32_t a = 0, e = len;
-                if (root) { const uint2 r = p.rng[(uint64_t)tile * k + (uint32_t)tid]; a = r.x; e = r.y; }
-                else {
+                if (root) {
+                    const uint4 r0 = p.rng[2u * ((uint64_t)tile * k + (uint32_t)tid)], r1 = p.rng[2u * ((uint64_t)tile * k + (uint32_t)tid) + 1u];
+                    sm.rs[tid] = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
+                    sm.spre[tid] = r0.z;
+                    sm.sbl_rank[tid] = r0.w;
+                    sm.rmin[tid] = r1.x;
+                    sm.rmax[tid] = r1.y;
+                } else {
+                    const uint64_t beg = p.poff[(uint32_t)tid * n1 + t0], end = p.poff[(uint32_t)tid * n1 + t1];
+                    const uint32_t len = (uint32_t)(end - beg);
                     const uint32_t *lst = p.raw + beg;
                     uint32_t lo = 0, hi = len;
                     while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] < dlo) lo = mid + 1u; else hi = mid; }
-                    a = lo;
+                    const uint32_t a = lo;
                     hi = len;
                     while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= dhi) lo = mid + 1u; else hi = mid; }
-                    e = lo;
+                    const uint32_t e = lo;
+                    sm.rs[tid] = beg + a;
+                    sm.spre[tid] = e - a;
+                    sm.sbl_rank[tid] = a;
+                    sm.rmin[tid] = e > a ? lst[a] : 0xFFFFFFFFu;
+                    sm.rmax[tid] = e > a ? lst[e - 1u] : 0u;
                 }
-                sm.rs[tid] = beg + a;
-                sm.spre[tid] = e - a;
-                sm.sbl_rank[tid] = a;
             }
             __syncthreads();
             if (wv == 0) {
@@ -334,6 +354,13 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
                 if (l == 63) { sm.runbase[0][k] = incl; sm.n_in = incl; }
                 const uint32_t r = wave_sum((uint32_t)l < k ? sm.sbl_rank[l] : 0u);
                 if (l == 0) sm.rank = r;
+                uint32_t mn = (uint32_t)l < k ? sm.rmin[l] : 0xFFFFFFFFu, mx = (uint32_t)l < k ? sm.rmax[l] : 0u;
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint32_t on = (uint32_t)__shfl_xor((int)mn, d, 64), ox = (uint32_t)__shfl_xor((int)mx, d, 64);
+                    mn = on < mn ? on : mn;
+                    mx = ox > mx ? ox : mx;
+                }
+                if (l == 0) { sm.vmin = mn; sm.vmax = mx; }
             }
             // list offsets inside each run (batches of several terms)
             if (nt > 1u) {
@@ -353,26 +380,107 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
             const uint32_t n_in = sm.n_in;
             *outbuf = 0;
             if (n_in == 0) return 0u;
+            // Single-term tiles (the tiles of large terms — most of the postings) are folded by a bucket sort:
+            // a monotone map of the doc id onto NBK buckets, slot inside the bucket from an LDS counter,
+            // then every posting ranks itself among the few that share its bucket.  Docs clustered so that a
+            // bucket overflows BKT_LIMIT send the tile to the pairwise merge below instead.
+            const bool bucketed = nt == 1u && k > 1u;
+            uint32_t *bkt = &sm.offs[0][0];
+            const uint32_t vmin = sm.vmin;
+            const float binv = (float)NBK / ((float)(sm.vmax - vmin) + 1.0f);
+            auto bucket_of = [&](uint32_t v) -> uint32_t {
+                const uint32_t b = (uint32_t)((float)(v - vmin) * binv);
+                return b < NBK - 1u ? b : NBK - 1u;
+            };
             // ---- D. gather the runs into vals[0] (coalesced inside every run) ----
+            // MCAP = 8 * MT: eight postings per thread, all global loads issued before the first LDS write
             {
                 const uint32_t *RB = sm.runbase[0];
-                for (uint32_t e = (uint32_t)tid; e < n_in; e += MT) {
-                    uint32_t sa = 0, sb = k;              // last run with RB[s] <= e (it is not empty)
-                    while (sb - sa > 1u) { const uint32_t sm_ = (sa + sb) >> 1; if (RB[sm_] <= e) sa = sm_; else sb = sm_; }
-                    const uint32_t i = e - RB[sa];
-                    sm.vals[0][e] = p.raw[sm.rs[sa] + i];
-                    if (nt > 1u) {
-                        const uint32_t *O = sm.offs[0] + sa * stride;
-                        uint32_t ta = 0, tb = nt;         // last term with O[t] <= i
-                        while (tb - ta > 1u) { const uint32_t tm = (ta + tb) >> 1; if (O[tm] <= i) ta = tm; else tb = tm; }
-                        sm.tids[0][e] = (uint16_t)((sa << 10) | ta);
+                uint32_t gv[8], gsa[8], gi[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
+                    gv[j] = 0; gsa[j] = 0; gi[j] = 0;
+                    if (e < n_in) {
+                        uint32_t sa = 0, sb = k;              // last run with RB[s] <= e (it is not empty)
+                        while (sb - sa > 1u) { const uint32_t sm_ = (sa + sb) >> 1; if (RB[sm_] <= e) sa = sm_; else sb = sm_; }
+                        gsa[j] = sa;
+                        gi[j] = e - RB[sa];
+                        gv[j] = p.raw[sm.rs[sa] + gi[j]];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
+                    if (e < n_in) {
+                        const uint32_t v = gv[j];
+                        sm.vals[0][e] = v;
+                        if (bucketed) sm.tids[0][e] = (uint16_t)atomicAdd(&bkt[bucket_of(v)], 1u);
+                        if (nt > 1u) {
+                            const uint32_t *O = sm.offs[0] + gsa[j] * stride;
+                            const uint32_t i = gi[j];
+                            uint32_t ta = 0, tb = nt;         // last term with O[t] <= i
+                            while (tb - ta > 1u) { const uint32_t tm = (ta + tb) >> 1; if (O[tm] <= i) ta = tm; else tb = tm; }
+                            sm.tids[0][e] = (uint16_t)((gsa[j] << 10) | ta);
+                        }
                     }
                 }
             }
             __syncthreads();
             II2_STAMP(3)      // D: gather
-            // ---- E. fold the runs pairwise ----
+            // ---- E. fold the runs ----
             uint32_t cur = 0, nruns = k;
+            if (bucketed) {
+                // exclusive scan of the bucket counters in place (8 per thread) and the fullest bucket
+                uint32_t c[8], sum = 0, mxc = 0;
+                {
+                    const uint4 a4 = *reinterpret_cast<const uint4 *>(&bkt[8u * (uint32_t)tid]);
+                    const uint4 b4 = *reinterpret_cast<const uint4 *>(&bkt[8u * (uint32_t)tid + 4u]);
+                    c[0] = a4.x; c[1] = a4.y; c[2] = a4.z; c[3] = a4.w; c[4] = b4.x; c[5] = b4.y; c[6] = b4.z; c[7] = b4.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { sum += c[j]; mxc = c[j] > mxc ? c[j] : mxc; }
+                for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mxc, d, 64); mxc = o > mxc ? o : mxc; }
+                if (l == 0) sm.wmax[wv] = mxc;
+                uint32_t tot_;
+                uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
+                mxc = 0;
+                for (int w = 0; w < (int)MW; w++) mxc = sm.wmax[w] > mxc ? sm.wmax[w] : mxc;
+                if (mxc <= BKT_LIMIT) {
+                    uint32_t ex[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { ex[j] = run; run += c[j]; }
+                    *reinterpret_cast<uint4 *>(&bkt[8u * (uint32_t)tid]) = make_uint4(ex[0], ex[1], ex[2], ex[3]);
+                    *reinterpret_cast<uint4 *>(&bkt[8u * (uint32_t)tid + 4u]) = make_uint4(ex[4], ex[5], ex[6], ex[7]);
+                    if (tid == (int)MT - 1) bkt[NBK] = run;
+                    __syncthreads();
+                    // scatter into bucket order
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
+                        if (e < n_in) {
+                            const uint32_t v = sm.vals[0][e];
+                            sm.vals[1][bkt[bucket_of(v)] + sm.tids[0][e]] = v;
+                        }
+                    }
+                    __syncthreads();
+                    // rank inside the bucket (equal ids keep their bucket order: the dedupe below wants them adjacent)
+#pragma unroll 4
+                    for (uint32_t q = (uint32_t)tid; q < n_in; q += MT) {
+                        const uint32_t v = sm.vals[1][q];
+                        const uint32_t b = bucket_of(v);
+                        const uint32_t lo = bkt[b], hi = bkt[b + 1u];
+                        uint32_t r = 0;
+                        for (uint32_t m = lo; m < hi; m++) {
+                            const uint32_t u = sm.vals[1][m];
+                            r += (u < v || (u == v && m < q)) ? 1u : 0u;
+                        }
+                        sm.vals[0][lo + r] = v;
+                    }
+                    __syncthreads();
+                    nruns = 1u;
+                }
+            }
             // One term in the tile (the tiles of large terms — most of the postings): plain two-way merges.
             // Each thread produces a few consecutive outputs: one merge-path search to find where its
             // chunk starts in the two runs, then a sequential merge (A first on ties) — a handful of
@@ -468,27 +576,52 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
             const uint16_t *T = sm.tids[cur];
             uint32_t *V2 = sm.vals[cur ^ 1u];
             uint16_t *T2 = sm.tids[cur ^ 1u];
-            const uint32_t per = (n_in + MT - 1u) / MT;
-            const uint32_t a = (uint32_t)tid * per;
-            const uint32_t b = a + per < n_in ? a + per : n_in;
-            uint32_t keepmask = 0;               // per <= 16: one bit per element
-            uint32_t cnt = 0;
-            for (uint32_t e = a; e < b; e++) {
-                const uint32_t v = V[e];
-                bool keep = !(e > 0 && V[e - 1] == v && (nt == 1u || (T[e - 1] & 1023u) == (T[e] & 1023u)));
-                if (keep && p.tomb) {
-                    const uint32_t w = v >> 5;
-                    if (w < p.tomb_nwords && ((p.tomb[w] >> (v & 31u)) & 1u)) keep = false;
+            // eight consecutive postings per thread (MCAP = 8 * MT), read as vectors; the tombstone words
+            // of all eight are fetched before any is tested
+            const uint32_t a = 8u * (uint32_t)tid;
+            uint32_t fv[8], ft[8];
+            uint32_t keepmask = 0, cnt = 0;
+            if (a < n_in) {
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(&V[a]), v1 = *reinterpret_cast<const uint4 *>(&V[a + 4u]);
+                fv[0] = v0.x; fv[1] = v0.y; fv[2] = v0.z; fv[3] = v0.w; fv[4] = v1.x; fv[5] = v1.y; fv[6] = v1.z; fv[7] = v1.w;
+                uint32_t pv = a ? V[a - 1u] : ~fv[0], pt = 0;
+                if (nt > 1u) {
+                    const uint4 t4 = *reinterpret_cast<const uint4 *>(&T[a]);
+                    ft[0] = t4.x & 1023u; ft[1] = (t4.x >> 16) & 1023u; ft[2] = t4.y & 1023u; ft[3] = (t4.y >> 16) & 1023u;
+                    ft[4] = t4.z & 1023u; ft[5] = (t4.z >> 16) & 1023u; ft[6] = t4.w & 1023u; ft[7] = (t4.w >> 16) & 1023u;
+                    pt = a ? (T[a - 1u] & 1023u) : 0u;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) ft[j] = 0;
                 }
-                if (keep) { keepmask |= 1u << (e - a); cnt++; }
+                uint32_t tw[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t w = fv[j] >> 5;
+                    tw[j] = (p.tomb && a + (uint32_t)j < n_in && w < p.tomb_nwords) ? p.tomb[w] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const bool dup = fv[j] == pv && ft[j] == pt && (a + (uint32_t)j) > 0u;
+                    const bool keep = a + (uint32_t)j < n_in && !dup && !((tw[j] >> (fv[j] & 31u)) & 1u);
+                    if (keep) { keepmask |= 1u << j; cnt++; }
+                    pv = fv[j];
+                    pt = ft[j];
+                }
             }
             uint32_t tot;
             uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
-            for (uint32_t e = a; e < b; e++) {
-                if ((keepmask >> (e - a)) & 1u) { V2[pos] = V[e]; T2[pos] = nt == 1u ? (uint16_t)0 : (uint16_t)(T[e] & 1023u); pos++; }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if ((keepmask >> j) & 1u) { V2[pos] = fv[j]; T2[pos] = (uint16_t)ft[j]; pos++; }
             }
             *outbuf = cur ^ 1u;
-            if (emit_counts) {
+            if (emit_counts && nt == 1u) {
+                if (tid == 0 && tot) {
+                    if (atomic_counts) atomicAdd(&p.out_counts[t0], tot);
+                    else p.out_counts[t0] = tot;
+                }
+            } else if (emit_counts) {
                 // per-term survivor counts from the boundaries of the compacted array
                 uint32_t *tstart = sm.offs[0], *tend = sm.offs[1];
                 __syncthreads();
@@ -611,7 +744,7 @@ hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff,
 }
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s) {
     if (p.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_tile_ranges, dim3(grid_for((uint64_t)p.n_tiles * p.k)), dim3(256), 0, s, p, (const uint4 *)desc, (uint2 *)rng);
+    hipLaunchKernelGGL(k_merge_tile_ranges, dim3(grid_for((uint64_t)p.n_tiles * p.k)), dim3(256), 0, s, p, (const uint4 *)desc, (uint4 *)rng);
     return hipGetLastError();
 }
 

@@ -156,7 +156,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const size_t nt1 = (size_t)n_tiles + 1;
     const size_t scan_t = scan_temp_bytes(nt1);
     const size_t aux_need = align_up(nt1 * 16) + align_up(nt1 * sizeof(uint32_t)) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
-                            align_up(nt1 * k * sizeof(uint2)) + align_up((n_in + 64) * sizeof(uint32_t)) + 4096;
+                            align_up(nt1 * k * 2 * sizeof(uint4)) + align_up((n_in + 64) * sizeof(uint32_t)) + 4096;
     if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
     void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
@@ -164,7 +164,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
     uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
     void *d_scan_t = carve<uint8_t>(ac, scan_t);
-    uint2 *d_rng = carve<uint2>(ac, nt1 * k);
+    uint4 *d_rng = carve<uint4>(ac, nt1 * k * 2);
     p.tmp = carve<uint32_t>(ac, n_in + 64);
 
     HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, d_tile_desc, st));
