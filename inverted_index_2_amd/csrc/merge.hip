@@ -479,6 +479,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
                     }
                     __syncthreads();
                     nruns = 1u;
+                    II2_STAMP(1)      // E1: bucket fold
                 }
             }
             // One term in the tile (the tiles of large terms — most of the postings): plain two-way merges.
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
                 cur ^= 1u;
                 nruns = npairs;
             }
+            II2_STAMP(2)      // E2: pairwise merge of a single term (bucket overflow)
             while (nruns > 1u) {
                 const uint32_t *V = sm.vals[cur];
                 const uint16_t *T = sm.tids[cur];
