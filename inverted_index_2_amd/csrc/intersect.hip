@@ -171,10 +171,16 @@ __device__ __forceinline__ uint32_t bytes_eq_mask(uint32_t w, uint32_t n4) {
     return (((z >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
 
+// bit 7 of every byte of w -> 4-bit mask (bit k = byte k)
+__device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
+    return ((((w & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu;
+}
+
 __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
     __shared__ IsectSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t n = p.n_lists;
+    const bool shiftenc = n <= 8u;
     const uint32_t stride = desc_stride(n);
     Prefetch pf;
     pf.r0 = make_uint4(0, 0, 0, 0); pf.r1 = pf.r0; pf.sk.first_doc = 0; pf.sk.byte_off = 0;
@@ -240,16 +246,28 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
                 II2_STAMP(0)      // clear + commit + barrier + prefetch issue
                 const uint32_t nblk = d.bh - d.bl;
                 const uint8_t want = (uint8_t)j;
+                // n <= 8 (shift code): the driver writes 1 << (8 - n) and every further list shifts the bytes it
+                // hits left by one, so a doc of all n lists ends at 0x80 and nothing else reaches bit 7 — no
+                // compare per posting and a one-AND test when the map is finalised.  n > 8: counting code
+                // (driver 1, list j turns j into j + 1).
+                const uint8_t s0 = shiftenc ? (uint8_t)(1u << (8u - n)) : (uint8_t)1;
                 // driver: plain stores of 1.  list j: read the four candidate bytes, then bump the ones at j.
                 auto mark4 = [&](uint32_t, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
                     const uint32_t o0 = id0 - mlo, o1 = id1 - mlo, o2 = id2 - mlo, o3 = id3 - mlo;
                     const bool v0 = (mask & 1u) && o0 <= mspan, v1 = (mask & 2u) && o1 <= mspan;
                     const bool v2 = (mask & 4u) && o2 <= mspan, v3 = (mask & 8u) && o3 <= mspan;
                     if (want == 0) {
-                        if (v0) sm.map[o0] = 1;
-                        if (v1) sm.map[o1] = 1;
-                        if (v2) sm.map[o2] = 1;
-                        if (v3) sm.map[o3] = 1;
+                        if (v0) sm.map[o0] = s0;
+                        if (v1) sm.map[o1] = s0;
+                        if (v2) sm.map[o2] = s0;
+                        if (v3) sm.map[o3] = s0;
+                    } else if (shiftenc) {
+                        const uint8_t m0 = v0 ? sm.map[o0] : (uint8_t)0, m1 = v1 ? sm.map[o1] : (uint8_t)0;
+                        const uint8_t m2 = v2 ? sm.map[o2] : (uint8_t)0, m3 = v3 ? sm.map[o3] : (uint8_t)0;
+                        if (v0) sm.map[o0] = (uint8_t)(m0 << 1);
+                        if (v1) sm.map[o1] = (uint8_t)(m1 << 1);
+                        if (v2) sm.map[o2] = (uint8_t)(m2 << 1);
+                        if (v3) sm.map[o3] = (uint8_t)(m3 << 1);
                     } else {
                         const uint8_t m0 = v0 ? sm.map[o0] : (uint8_t)0xFE, m1 = v1 ? sm.map[o1] : (uint8_t)0xFE;
                         const uint8_t m2 = v2 ? sm.map[o2] : (uint8_t)0xFE, m3 = v3 ? sm.map[o3] : (uint8_t)0xFE;
@@ -277,8 +295,17 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
                     const uint32_t of = (rv && rl == 0u && f < dummy) ? f : dummy;
                     if (want == 0) {
 #pragma unroll
-                        for (int k = 0; k < 16; k++) sm.map[o[k]] = 1;
-                        sm.map[of] = 1;
+                        for (int k = 0; k < 16; k++) sm.map[o[k]] = s0;
+                        sm.map[of] = s0;
+                    } else if (shiftenc) {
+                        uint8_t m[16];
+#pragma unroll
+                        for (int k = 0; k < 16; k++) m[k] = sm.map[o[k]];
+                        const uint8_t mf = sm.map[of];
+                        // bytes hit twice (zero-gap padding repeats the lane's last id) were read before any write: same value
+#pragma unroll
+                        for (int k = 0; k < 16; k++) sm.map[o[k]] = (uint8_t)(m[k] << 1);
+                        sm.map[of] = (uint8_t)(mf << 1);
                     } else {
                         uint8_t m[16];
 #pragma unroll
@@ -337,9 +364,14 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
             for (uint32_t wi = (uint32_t)tid; wi < nwords; wi += 256u) {
                 const uint4 a = *reinterpret_cast<const uint4 *>(&sm.map[32u * wi]);
                 const uint4 b = *reinterpret_cast<const uint4 *>(&sm.map[32u * wi + 16u]);
-                uint32_t word = bytes_eq_mask(a.x, n4) | (bytes_eq_mask(a.y, n4) << 4) | (bytes_eq_mask(a.z, n4) << 8) |
-                                (bytes_eq_mask(a.w, n4) << 12) | (bytes_eq_mask(b.x, n4) << 16) | (bytes_eq_mask(b.y, n4) << 20) |
-                                (bytes_eq_mask(b.z, n4) << 24) | (bytes_eq_mask(b.w, n4) << 28);
+                uint32_t word;
+                if (shiftenc)
+                    word = bytes_msb_mask(a.x) | (bytes_msb_mask(a.y) << 4) | (bytes_msb_mask(a.z) << 8) | (bytes_msb_mask(a.w) << 12) |
+                           (bytes_msb_mask(b.x) << 16) | (bytes_msb_mask(b.y) << 20) | (bytes_msb_mask(b.z) << 24) | (bytes_msb_mask(b.w) << 28);
+                else
+                    word = bytes_eq_mask(a.x, n4) | (bytes_eq_mask(a.y, n4) << 4) | (bytes_eq_mask(a.z, n4) << 8) |
+                           (bytes_eq_mask(a.w, n4) << 12) | (bytes_eq_mask(b.x, n4) << 16) | (bytes_eq_mask(b.y, n4) << 20) |
+                           (bytes_eq_mask(b.z, n4) << 24) | (bytes_eq_mask(b.w, n4) << 28);
                 if (wi == nwords - 1u && (mspan & 31u) != 31u) word &= (2u << (mspan & 31u)) - 1u;   // drop the dummy byte and beyond
                 if (p.tomb) {
                     const uint32_t tw = (mlo >> 5) + wi;
