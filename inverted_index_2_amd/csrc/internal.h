@@ -211,8 +211,9 @@ hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint3
                               hipEvent_t ev1 = nullptr);
 hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *out, hipStream_t s);
 hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s);
-hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, uint32_t *big_g, unsigned long long *big_pos,
-                             uint32_t *nbig, uint32_t grid_rows, hipStream_t s);
+hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s);
+hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
+                             uint32_t grid_rows, hipStream_t s);
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s);
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);

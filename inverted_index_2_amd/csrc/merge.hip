@@ -66,57 +66,76 @@ __global__ void k_mseg_blocks(MergeSegs p, uint32_t *__restrict__ out) {
 // possible dwords fetched at once); the others are appended to a list and decoded one per 16-lane ROW.
 constexpr uint32_t TINY_BYTES = 28;
 
-__global__ __launch_bounds__(256) void k_mdec_lane(MergeSegs p, const unsigned long long *__restrict__ poff, uint32_t *__restrict__ raw,
-                                                    uint32_t *__restrict__ big_g, unsigned long long *__restrict__ big_pos,
-                                                    uint32_t *__restrict__ nbig) {
+// which (segment, list, block) a global block is, where it decodes to, and whether it is left to the row kernel
+struct BlkRef { bool valid, big; uint32_t s, q0, q1, first; unsigned long long pos; };
+__device__ __forceinline__ BlkRef blk_ref(const MergeSegs &p, const unsigned long long *__restrict__ poff, uint64_t g, bool want_pos) {
+    BlkRef r;
+    r.valid = false; r.big = false; r.s = 0; r.q0 = 0; r.q1 = 0; r.first = 0; r.pos = 0;
+    if (g >= p.seg_cum[p.k]) return r;
+    const uint32_t s = seg_of_gblock(p, (uint32_t)g);
+    const SegView sv = p.segs[s];
+    const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
+    const uint32_t t = sv.blk_list[b] - sv.list_base;
+    if (t >= p.n_terms) return r;
+    const ii2_skip e0 = sv.skip[b];
+    r.valid = true;
+    r.s = s;
+    r.q0 = e0.byte_off;
+    r.q1 = sv.skip[b + 1].byte_off;
+    r.first = e0.first_doc;
+    r.big = r.q1 - r.q0 > TINY_BYTES;
+    if (want_pos) r.pos = poff[(uint64_t)s * (p.n_terms + 1) + t] + (unsigned long long)(b - sv.blk_off[t]) * II2_DV1_BLOCK;
+    return r;
+}
+
+// non-tiny blocks per workgroup of k_mdec_lane (their scan gives every workgroup its slice of the work list:
+// one address sustains only ~90 atomics/us, far too few for an append per wave)
+__global__ __launch_bounds__(256) void k_mbig_count(MergeSegs p, uint32_t *__restrict__ wgcnt) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool big = false;
-    unsigned long long pos = 0;
-    if (g < p.seg_cum[p.k]) {
-        const uint32_t s = seg_of_gblock(p, (uint32_t)g);
-        const SegView sv = p.segs[s];
-        const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
-        const uint32_t t = sv.blk_list[b] - sv.list_base;
-        if (t < p.n_terms) {
-            pos = poff[(uint64_t)s * (p.n_terms + 1) + t] + (unsigned long long)(b - sv.blk_off[t]) * II2_DV1_BLOCK;
-            const ii2_skip e0 = sv.skip[b];
-            const uint32_t q0 = e0.byte_off, len = sv.skip[b + 1].byte_off - q0;
-            if (len <= TINY_BYTES) {
-                uint32_t w[7];
+    const BlkRef r = blk_ref(p, nullptr, g, false);
+    const int c = __syncthreads_count(r.big ? 1 : 0);
+    if (threadIdx.x == 0) wgcnt[blockIdx.x] = (uint32_t)c;
+}
+
+__global__ __launch_bounds__(256) void k_mdec_lane(MergeSegs p, const unsigned long long *__restrict__ poff, uint32_t *__restrict__ raw,
+                                                    const uint32_t *__restrict__ wgbase, uint4 *__restrict__ ent0, uint2 *__restrict__ ent1) {
+    __shared__ uint32_t wcnt[4];
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const BlkRef r = blk_ref(p, poff, g, true);
+    if (r.valid && !r.big) {
+        const uint32_t len = r.q1 - r.q0;
+        const uint8_t *pl = p.segs[r.s].payload + r.q0;
+        uint32_t w[7];
 #pragma unroll
-                for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(sv.payload + q0 + 4u * j) : 0u;
-                uint32_t *out = raw + pos;
-                uint32_t cur = e0.first_doc, acc = 0, sh = 0;
-                *out++ = cur;
+        for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(pl + 4u * j) : 0u;
+        uint32_t *out = raw + r.pos;
+        uint32_t cur = r.first, acc = 0, sh = 0;
+        *out++ = cur;
 #pragma unroll
-                for (int j = 0; j < 28; j++) {
-                    if ((uint32_t)j < len) {
-                        const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                        acc += (c & 0x7Fu) << sh;
-                        if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
-                        else { cur += acc; *out++ = cur; acc = 0; sh = 0; }
-                    }
-                }
-            } else big = true;
+        for (int j = 0; j < 28; j++) {
+            if ((uint32_t)j < len) {
+                const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                acc += (c & 0x7Fu) << sh;
+                if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
+                else { cur += acc; *out++ = cur; acc = 0; sh = 0; }
+            }
         }
     }
-    // wave-aggregated append of the blocks left for the row kernel
-    const unsigned long long m = __ballot(big);
-    if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane_id() == leader) base = atomicAdd(nbig, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        if (big) {
-            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-            big_g[at] = (uint32_t)g;
-            big_pos[at] = pos;
-        }
+    // work list entries of the blocks left to the row kernel, in block order
+    const unsigned long long m = __ballot(r.big);
+    const int wv = (int)threadIdx.x >> 6;
+    if (lane_id() == 0) wcnt[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (r.big) {
+        uint32_t at = wgbase[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        for (int w2 = 0; w2 < wv; w2++) at += wcnt[w2];
+        ent0[at] = make_uint4((uint32_t)r.pos, (uint32_t)(r.pos >> 32), r.q0, r.q1);
+        ent1[at] = make_uint2(r.first, r.s);
     }
 }
 
-__global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__restrict__ raw, const uint32_t *__restrict__ big_g,
-                                                    const unsigned long long *__restrict__ big_pos, const uint32_t *__restrict__ nbig) {
+__global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__restrict__ raw, const uint4 *__restrict__ ent0,
+                                                    const uint2 *__restrict__ ent1, const uint32_t *__restrict__ nbig) {
     const uint32_t n = *nbig;
     const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 4;
     for (uint64_t z = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; __ballot(z < n) != 0ull; z += stride) {
@@ -125,16 +144,13 @@ __global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__rest
         uint32_t *out = raw;
         const uint8_t *pl = nullptr;     // rows of one wave may read different segments
         if (rv) {
-            const uint32_t g = big_g[z];
-            const uint32_t s = seg_of_gblock(p, g);
-            const SegView sv = p.segs[s];
-            const uint32_t b = p.seg_b0[s] + (g - p.seg_cum[s]);
-            const ii2_skip e0 = sv.skip[b];
-            q0 = e0.byte_off;
-            q1 = sv.skip[b + 1].byte_off;
-            first = e0.first_doc;
-            out = raw + big_pos[z];
-            pl = sv.payload;
+            const uint4 e0 = ent0[z];
+            const uint2 e1 = ent1[z];
+            q0 = e0.z;
+            q1 = e0.w;
+            first = e1.x;
+            out = raw + ((unsigned long long)e0.x | ((unsigned long long)e0.y << 32));
+            pl = p.segs[e1.y].payload;
         }
         decode_rows16_any(pl, q0, q1, first, rv, [&](uint32_t ix, uint32_t id) { out[ix] = id; });
     }
@@ -733,15 +749,19 @@ hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s) 
     hipLaunchKernelGGL(k_mlist_counts, dim3(grid_for((uint64_t)p.k * (p.n_terms + 1))), dim3(256), 0, s, p, lc);
     return hipGetLastError();
 }
-hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, uint32_t *big_g, unsigned long long *big_pos,
-                             uint32_t *nbig, uint32_t grid_rows, hipStream_t s) {
+hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s) {
     const uint64_t total = p.seg_cum[p.k];
     if (total == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(nbig, 0, sizeof(uint32_t), s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_mdec_lane, dim3(grid_for(total)), dim3(256), 0, s, p, poff, raw, big_g, big_pos, nbig);
-    hipLaunchKernelGGL(k_mdec_rows, dim3(grid_rows), dim3(256), 0, s, p, raw, (const uint32_t *)big_g, (const unsigned long long *)big_pos,
-                       (const uint32_t *)nbig);
+    hipLaunchKernelGGL(k_mbig_count, dim3(grid_for(total)), dim3(256), 0, s, p, wgcnt);
+    return hipGetLastError();
+}
+hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
+                             uint32_t grid_rows, hipStream_t s) {
+    const uint64_t total = p.seg_cum[p.k];
+    if (total == 0) return hipSuccess;
+    const unsigned nwg = grid_for(total);
+    hipLaunchKernelGGL(k_mdec_lane, dim3(nwg), dim3(256), 0, s, p, poff, raw, wgbase, (uint4 *)ent0, (uint2 *)ent1);
+    hipLaunchKernelGGL(k_mdec_rows, dim3(grid_rows), dim3(256), 0, s, p, raw, (const uint4 *)ent0, (const uint2 *)ent1, wgbase + nwg);
     return hipGetLastError();
 }
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s) {

@@ -102,15 +102,18 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const size_t nl = (size_t)k * n1;
     const size_t scan_b = scan_temp_bytes(std::max<size_t>(nl + 1, totalB + 1));
     // ws: list counts / offsets, the list of non-tiny blocks, plan arrays
-    size_t need = align_up((totalB + 1) * sizeof(uint32_t)) + align_up((totalB + 1) * sizeof(uint64_t)) + align_up(nl * sizeof(uint32_t)) +
+    const size_t nwg = (totalB + 255) / 256;
+    size_t need = align_up((totalB + 1) * sizeof(uint4)) + align_up((totalB + 1) * sizeof(uint2)) + 2 * align_up((nwg + 1) * sizeof(uint32_t)) +
+                  align_up(nl * sizeof(uint32_t)) +
                   align_up(nl * sizeof(uint64_t)) + 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) +
                   scan_b + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     uint8_t *cur = ctx->ws;
-    uint32_t *d_big_g = carve<uint32_t>(cur, totalB + 1);
-    unsigned long long *d_big_pos = (unsigned long long *)carve<uint64_t>(cur, totalB + 1);
-    uint32_t *d_nbig = (uint32_t *)(ctx->d_mail + 100);
+    uint4 *d_ent0 = carve<uint4>(cur, totalB + 1);        // work list of the non-tiny blocks (row decoder)
+    uint2 *d_ent1 = carve<uint2>(cur, totalB + 1);
+    uint32_t *d_wgcnt = carve<uint32_t>(cur, nwg + 1);
+    uint32_t *d_wgbase = carve<uint32_t>(cur, nwg + 1);
     uint32_t *d_lc = carve<uint32_t>(cur, nl);
     unsigned long long *d_poff = (unsigned long long *)carve<uint64_t>(cur, nl);
     uint32_t *d_ub = carve<uint32_t>(cur, n1);
@@ -134,7 +137,10 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     if (n_in >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: more than 2^32 input postings in one call");
     if (!grow(ctx->aux2, ctx->aux2_cap, (n_in + 64) * sizeof(uint32_t))) return fail(ctx, II2_ENOMEM, "merge raw scratch allocation failed");
     uint32_t *d_raw = (uint32_t *)ctx->aux2;
-    HIP_TRY(ctx, launch_mdec_write(ms, d_poff, d_raw, d_big_g, d_big_pos, d_nbig, (uint32_t)ctx->cu_count * 8u, st));
+    HIP_TRY(ctx, hipMemsetAsync(d_wgcnt + nwg, 0, sizeof(uint32_t), st));
+    HIP_TRY(ctx, launch_mbig_count(ms, d_wgcnt, st));
+    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_wgcnt, d_wgbase, nwg + 1, st));
+    HIP_TRY(ctx, launch_mdec_write(ms, d_poff, d_raw, d_wgbase, d_ent0, d_ent1, (uint32_t)ctx->cu_count * 8u, st));
     p.raw = d_raw;
     p.poff = d_poff;
 
