@@ -281,6 +281,8 @@ struct __align__(16) MergeSmem {
     unsigned long long rs[MAX_LISTS];   // position in raw of each run's first posting
     uint32_t spre[MAX_LISTS + 1];       // run lengths
     uint32_t sbl_rank[MAX_LISTS];       // postings of each list that precede the range
+    uint2 tterm[MT];                    // batches: per term {smallest doc, float bits of buckets per doc}
+    uint16_t ttb[MT + 2];               // batches: per term its first bucket = its first position after the fold
     uint32_t rmin[MAX_LISTS], rmax[MAX_LISTS];   // first / last doc of each run (single-term tiles)
     uint32_t wsum[MW];
     uint32_t wmax[MW];
@@ -304,7 +306,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return pre + incl - v;
 }
 
-__global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
+__global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
     __shared__ MergeSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t k = p.k;
@@ -336,6 +338,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
             if (nt == 1u && k > 1u) {       // bucket counters of the single-term fold (they live in the unused list-offset table)
                 uint4 *z = reinterpret_cast<uint4 *>(&sm.offs[0][0]);
                 for (uint32_t i = (uint32_t)tid; i < (NBK + 4u) / 4u; i += MT) z[i] = make_uint4(0, 0, 0, 0);
+            } else if (k > 1u) {            // batches: 4096 16-bit bucket counters in the second list-offset table
+                reinterpret_cast<uint4 *>(&sm.offs[1][0])[tid] = make_uint4(0, 0, 0, 0);
             }
             if ((uint32_t)tid < k) {
                 if (root) {
@@ -496,6 +500,119 @@ __global__ __launch_bounds__(MERGE_THREADS) void k_merge_tiles(MergeParams p, co
                     __syncthreads();
                     nruns = 1u;
                     II2_STAMP(1)      // E1: bucket fold
+                }
+            }
+            // Batches of several terms: the same bucket sort with one bucket per posting, shared out among the
+            // terms in proportion to their sizes — term t owns buckets [ttb[t], ttb[t+1]) (= its positions
+            // after the fold) and maps its own doc range onto them, so the bucket order is the (term, doc) order.
+            if (nt > 1u && k > 1u && nt <= MT) {
+                const uint32_t *O = sm.offs[0];
+                const uint32_t *RB = sm.runbase[0];
+                uint32_t *c32 = &sm.offs[1][0];                 // two 16-bit counters per word
+                {
+                    uint32_t n_t = 0, mn = 0xFFFFFFFFu, mx = 0u;
+                    if ((uint32_t)tid < nt) {
+                        for (uint32_t r = 0; r < k; r++) {
+                            const uint32_t o0 = O[r * stride + (uint32_t)tid], o1 = O[r * stride + (uint32_t)tid + 1u];
+                            if (o1 > o0) {
+                                n_t += o1 - o0;
+                                const uint32_t f = sm.vals[0][RB[r] + o0], la = sm.vals[0][RB[r] + o1 - 1u];
+                                mn = f < mn ? f : mn;
+                                mx = la > mx ? la : mx;
+                            }
+                        }
+                    }
+                    uint32_t tot_;
+                    const uint32_t tb = block_excl_scan(n_t, sm.wsum, &tot_);
+                    if ((uint32_t)tid < nt) {
+                        sm.ttb[tid] = (uint16_t)tb;
+                        sm.tterm[tid] = make_uint2(mn, __float_as_uint(n_t ? (float)n_t / ((float)(mx - mn) + 1.0f) : 0.0f));
+                    }
+                    if (tid == 0) sm.ttb[nt] = (uint16_t)n_in;
+                    __syncthreads();
+                }
+                auto bucket_mt = [&](uint32_t t, uint32_t v) -> uint32_t {
+                    const uint32_t tb = sm.ttb[t], nb = sm.ttb[t + 1u] - tb;
+                    const uint2 te = sm.tterm[t];
+                    const uint32_t b = (uint32_t)((float)(v - te.x) * __uint_as_float(te.y));
+                    return tb + (b < nb - 1u ? b : nb - 1u);
+                };
+                auto base_of = [&](uint32_t b) -> uint32_t { return (c32[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu; };
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
+                    if (e < n_in) {
+                        const uint32_t t = sm.tids[0][e] & 1023u;
+                        const uint32_t b = bucket_mt(t, sm.vals[0][e]);
+                        const uint32_t sh = 16u * (b & 1u);
+                        uint32_t slot = (atomicAdd(&c32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                        slot = slot < 63u ? slot : 63u;           // a fuller bucket sends the tile to the pairwise fold anyway
+                        sm.tids[0][e] = (uint16_t)((slot << 10) | t);
+                    }
+                }
+                __syncthreads();
+                // exclusive scan of the counters in place (8 per thread) and the fullest bucket
+                uint32_t c[8], sum = 0, mxc = 0;
+                {
+                    const uint4 w4 = reinterpret_cast<const uint4 *>(c32)[tid];
+                    c[0] = w4.x & 0xFFFFu; c[1] = w4.x >> 16; c[2] = w4.y & 0xFFFFu; c[3] = w4.y >> 16;
+                    c[4] = w4.z & 0xFFFFu; c[5] = w4.z >> 16; c[6] = w4.w & 0xFFFFu; c[7] = w4.w >> 16;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { sum += c[j]; mxc = c[j] > mxc ? c[j] : mxc; }
+                for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mxc, d, 64); mxc = o > mxc ? o : mxc; }
+                if (l == 0) sm.wmax[wv] = mxc;
+                uint32_t tot_;
+                uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
+                mxc = 0;
+                for (int w = 0; w < (int)MW; w++) mxc = sm.wmax[w] > mxc ? sm.wmax[w] : mxc;
+                if (mxc <= BKT_LIMIT) {
+                    uint32_t ex[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { ex[j] = run; run += c[j]; }
+                    reinterpret_cast<uint4 *>(c32)[tid] = make_uint4(ex[0] | (ex[1] << 16), ex[2] | (ex[3] << 16), ex[4] | (ex[5] << 16), ex[6] | (ex[7] << 16));
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
+                        if (e < n_in) {
+                            const uint32_t v = sm.vals[0][e];
+                            const uint32_t tag = sm.tids[0][e];
+                            const uint32_t dst = base_of(bucket_mt(tag & 1023u, v)) + (tag >> 10);
+                            sm.vals[1][dst] = v;
+                            sm.tids[1][dst] = (uint16_t)(tag & 1023u);
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll 4
+                    for (uint32_t q = (uint32_t)tid; q < n_in; q += MT) {
+                        const uint32_t v = sm.vals[1][q];
+                        const uint32_t t = sm.tids[1][q];
+                        const uint32_t b = bucket_mt(t, v);
+                        const uint32_t lo = base_of(b), hi = b + 1u < MCAP ? base_of(b + 1u) : n_in;
+                        uint32_t r = 0;
+                        for (uint32_t m = lo; m < hi; m++) {
+                            const uint32_t u = sm.vals[1][m];
+                            r += (u < v || (u == v && m < q)) ? 1u : 0u;
+                        }
+                        sm.vals[0][lo + r] = v;
+                        sm.tids[0][lo + r] = (uint16_t)t;
+                    }
+                    __syncthreads();
+                    nruns = 1u;
+                } else {
+                    // clustered docs: back to (run, term) tags for the pairwise fold
+                    __syncthreads();
+                    for (uint32_t e = (uint32_t)tid; e < n_in; e += MT) {
+                        uint32_t sa = 0, sb = k;
+                        while (sb - sa > 1u) { const uint32_t sm_ = (sa + sb) >> 1; if (RB[sm_] <= e) sa = sm_; else sb = sm_; }
+                        const uint32_t i = e - RB[sa];
+                        const uint32_t *Os = O + sa * stride;
+                        uint32_t ta = 0, tb2 = nt;
+                        while (tb2 - ta > 1u) { const uint32_t tm = (ta + tb2) >> 1; if (Os[tm] <= i) ta = tm; else tb2 = tm; }
+                        sm.tids[0][e] = (uint16_t)((sa << 10) | ta);
+                    }
+                    __syncthreads();
                 }
             }
             // One term in the tile (the tiles of large terms — most of the postings): plain two-way merges.

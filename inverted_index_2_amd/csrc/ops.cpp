@@ -62,7 +62,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const uint32_t cap = MERGE_CAP;
     // terms per batch are bounded by the list-offset table: (nt + 1) * k <= MERGE_OFFMAX
     uint32_t nt_max = MERGE_OFFMAX / k - 1u;
-    if (nt_max > 1000u) nt_max = 1000u;
+    if (nt_max > 500u) nt_max = 500u;       // <= MERGE_THREADS terms per batch (one thread per term in the tile kernel)
     if (nt_max < 1u) nt_max = 1u;
     p.small_max = cap / 2u;                 // batched terms; a batch holds < batch_q + small_max <= cap
     p.batch_q = cap - p.small_max;
