@@ -450,6 +450,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
             II2_STAMP(3)      // D: gather
             // ---- E. fold the runs ----
             uint32_t cur = 0, nruns = k;
+            bool flagged = false;          // the bucket folds already marked duplicates and tombstoned ids (bit 15 of the tag)
             if (bucketed) {
                 // exclusive scan of the bucket counters in place (8 per thread) and the fullest bucket
                 uint32_t c[8], sum = 0, mxc = 0;
@@ -490,15 +491,20 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t v = sm.vals[1][q];
                         const uint32_t b = bucket_of(v);
                         const uint32_t lo = bkt[b], hi = bkt[b + 1u];
-                        uint32_t r = 0;
+                        const uint32_t tw = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb[v >> 5] : 0u;   // in flight during the loop
+                        uint32_t r = 0, dup = 0;
                         for (uint32_t m = lo; m < hi; m++) {
                             const uint32_t u = sm.vals[1][m];
-                            r += (u < v || (u == v && m < q)) ? 1u : 0u;
+                            const uint32_t eq = (u == v && m < q) ? 1u : 0u;
+                            r += (u < v ? 1u : 0u) + eq;
+                            dup |= eq;
                         }
                         sm.vals[0][lo + r] = v;
+                        sm.tids[0][lo + r] = (uint16_t)((dup | ((tw >> (v & 31u)) & 1u)) << 15);   // dead: duplicate or tombstoned
                     }
                     __syncthreads();
                     nruns = 1u;
+                    flagged = true;
                     II2_STAMP(1)      // E1: bucket fold
                 }
             }
@@ -590,16 +596,20 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t t = sm.tids[1][q];
                         const uint32_t b = bucket_mt(t, v);
                         const uint32_t lo = base_of(b), hi = b + 1u < MCAP ? base_of(b + 1u) : n_in;
-                        uint32_t r = 0;
+                        const uint32_t tw = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb[v >> 5] : 0u;   // in flight during the loop
+                        uint32_t r = 0, dup = 0;
                         for (uint32_t m = lo; m < hi; m++) {
                             const uint32_t u = sm.vals[1][m];
-                            r += (u < v || (u == v && m < q)) ? 1u : 0u;
+                            const uint32_t eq = (u == v && m < q) ? 1u : 0u;
+                            r += (u < v ? 1u : 0u) + eq;
+                            dup |= eq;
                         }
                         sm.vals[0][lo + r] = v;
-                        sm.tids[0][lo + r] = (uint16_t)t;
+                        sm.tids[0][lo + r] = (uint16_t)(t | ((dup | ((tw >> (v & 31u)) & 1u)) << 15));   // bit 15: duplicate or tombstoned
                     }
                     __syncthreads();
                     nruns = 1u;
+                    flagged = true;
                 } else {
                     // clustered docs: back to (run, term) tags for the pairwise fold
                     __syncthreads();
@@ -716,7 +726,19 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
             const uint32_t a = 8u * (uint32_t)tid;
             uint32_t fv[8], ft[8];
             uint32_t keepmask = 0, cnt = 0;
-            if (a < n_in) {
+            if (a < n_in && flagged) {
+                const uint4 v0 = *reinterpret_cast<const uint4 *>(&V[a]), v1 = *reinterpret_cast<const uint4 *>(&V[a + 4u]);
+                fv[0] = v0.x; fv[1] = v0.y; fv[2] = v0.z; fv[3] = v0.w; fv[4] = v1.x; fv[5] = v1.y; fv[6] = v1.z; fv[7] = v1.w;
+                const uint4 t4 = *reinterpret_cast<const uint4 *>(&T[a]);
+                // bit 15 of every 16-bit tag -> one bit per posting
+                const uint32_t dead = ((t4.x >> 15) & 1u) | ((t4.x >> 30) & 2u) | (((t4.y >> 15) & 1u) << 2) | (((t4.y >> 30) & 2u) << 2) |
+                                      (((t4.z >> 15) & 1u) << 4) | (((t4.z >> 30) & 2u) << 4) | (((t4.w >> 15) & 1u) << 6) | (((t4.w >> 30) & 2u) << 6);
+                const uint32_t have = n_in - a >= 8u ? 0xFFu : ((1u << (n_in - a)) - 1u);
+                keepmask = ~dead & have;
+                cnt = (uint32_t)__popc(keepmask);
+#pragma unroll
+                for (int j = 0; j < 8; j++) ft[j] = 0;
+            } else if (a < n_in) {
                 const uint4 v0 = *reinterpret_cast<const uint4 *>(&V[a]), v1 = *reinterpret_cast<const uint4 *>(&V[a + 4u]);
                 fv[0] = v0.x; fv[1] = v0.y; fv[2] = v0.z; fv[3] = v0.w; fv[4] = v1.x; fv[5] = v1.y; fv[6] = v1.z; fv[7] = v1.w;
                 uint32_t pv = a ? V[a - 1u] : ~fv[0], pt = 0;
@@ -746,15 +768,33 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
             }
             uint32_t tot;
             uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
+            const uint32_t pos0 = pos;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if ((keepmask >> j) & 1u) { V2[pos] = fv[j]; T2[pos] = (uint16_t)ft[j]; pos++; }
+                if ((keepmask >> j) & 1u) { V2[pos] = fv[j]; if (!flagged) T2[pos] = (uint16_t)ft[j]; pos++; }
             }
             *outbuf = cur ^ 1u;
             if (emit_counts && nt == 1u) {
                 if (tid == 0 && tot) {
                     if (atomic_counts) atomicAdd(&p.out_counts[t0], tot);
                     else p.out_counts[t0] = tot;
+                }
+            } else if (emit_counts && flagged) {
+                // term t sat at [ttb[t], ttb[t+1]) before the compaction: survivors = difference of the keep prefix there
+                uint2 *kp = reinterpret_cast<uint2 *>(&sm.offs[0][0]);
+                kp[tid] = make_uint2(pos0, keepmask);
+                __syncthreads();
+                if ((uint32_t)tid < nt) {
+                    auto kept_before = [&](uint32_t x) -> uint32_t {
+                        if (x >= MCAP) return tot;
+                        const uint2 e = kp[x >> 3];
+                        return e.x + (uint32_t)__popc(e.y & ((1u << (x & 7u)) - 1u));
+                    };
+                    const uint32_t c = kept_before(sm.ttb[tid + 1]) - kept_before(sm.ttb[tid]);
+                    if (c) {
+                        if (atomic_counts) atomicAdd(&p.out_counts[t0 + (uint32_t)tid], c);
+                        else p.out_counts[t0 + (uint32_t)tid] = c;
+                    }
                 }
             } else if (emit_counts) {
                 // per-term survivor counts from the boundaries of the compacted array
