@@ -227,7 +227,10 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
         const uint64_t lo64 = j > 0 ? (uint64_t)splitter(j) : 0ull;
         const uint64_t hi64 = j + 1u < m ? (uint64_t)splitter(j + 1u) : (1ull << 32);
         uint32_t dlo, dhi;
-        if (hi64 <= lo64) { dlo = 1u; dhi = 0u; }             // empty range
+        if (hi64 <= lo64) {                                   // empty range (dlo > dhi); dhi + 1 still is the upper splitter
+            if (hi64 > 0) { dlo = (uint32_t)hi64; dhi = (uint32_t)(hi64 - 1ull); }
+            else { dlo = 1u; dhi = 0u; }
+        }
         else { dlo = (uint32_t)lo64; dhi = (uint32_t)(hi64 - 1ull); }
         desc[tile] = make_uint4((uint32_t)tl, (uint32_t)tl + 1u, dlo, dhi);
     } else {
@@ -245,10 +248,25 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
     }
 }
 
+// ends[tile * k + s] = postings of list (s, t0) with doc <= the tile's upper bound (large-term tiles only)
+__global__ void k_merge_tile_ends(MergeParams p, const uint4 *__restrict__ desc, uint32_t *__restrict__ ends) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)p.n_tiles * p.k) return;
+    const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
+    const uint4 td = desc[tile];
+    if (td.z == 0u && td.w == 0xFFFFFFFFu) return;           // whole lists: nothing to search
+    const uint64_t n1 = p.n_terms + 1;
+    const uint64_t beg = p.poff[s * n1 + td.x], end = p.poff[s * n1 + td.y];
+    const uint32_t *lst = p.raw + beg;
+    uint32_t lo = 0, hi = (uint32_t)(end - beg);
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
+    ends[i] = lo;
+}
+
 // where every segment's list enters and leaves a tile's doc range: rng[2 * (tile * k + s)] =
 // (position in raw of the first posting inside the range: lo, hi; postings inside; postings of list (s, t0) before it),
-// rng[.. + 1] = (first doc, last doc of the slice, -, -)
-__global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, uint4 *__restrict__ rng) {
+// rng[.. + 1] = (first doc, last doc of the slice, -, -).  A range starts where the previous tile of the term ended.
+__global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, const uint32_t *__restrict__ ends, uint4 *__restrict__ rng) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)p.n_tiles * p.k) return;
     const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
@@ -260,12 +278,8 @@ __global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ des
     uint32_t a = 0, e = len;
     if (td.z > td.w) { a = 0; e = 0; }                       // empty doc range
     else if (!(td.z == 0u && td.w == 0xFFFFFFFFu)) {
-        uint32_t lo = 0, hi = len;
-        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] < td.z) lo = mid + 1u; else hi = mid; }
-        a = lo;
-        hi = len;
-        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
-        e = lo;
+        e = ends[i];
+        a = td.z == 0u ? 0u : ends[i - p.k];                 // td.z > 0: the tile before belongs to the same term and ends at td.z - 1
     }
     const uint64_t rs = beg + a;
     rng[2 * i] = make_uint4((uint32_t)rs, (uint32_t)(rs >> 32), e - a, a);
@@ -921,9 +935,11 @@ hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff,
     hipLaunchKernelGGL(k_mdec_rows, dim3(grid_rows), dim3(256), 0, s, p, raw, (const uint4 *)ent0, (const uint2 *)ent1, wgbase + nwg);
     return hipGetLastError();
 }
-hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, void *rng, hipStream_t s) {
+hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, uint32_t *ends, void *rng, hipStream_t s) {
     if (p.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_tile_ranges, dim3(grid_for((uint64_t)p.n_tiles * p.k)), dim3(256), 0, s, p, (const uint4 *)desc, (uint4 *)rng);
+    const unsigned g = grid_for((uint64_t)p.n_tiles * p.k);
+    hipLaunchKernelGGL(k_merge_tile_ends, dim3(g), dim3(256), 0, s, p, (const uint4 *)desc, ends);
+    hipLaunchKernelGGL(k_merge_tile_ranges, dim3(g), dim3(256), 0, s, p, (const uint4 *)desc, (const uint32_t *)ends, (uint4 *)rng);
     return hipGetLastError();
 }
 

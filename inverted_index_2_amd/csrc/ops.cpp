@@ -162,7 +162,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const size_t nt1 = (size_t)n_tiles + 1;
     const size_t scan_t = scan_temp_bytes(nt1);
     const size_t aux_need = align_up(nt1 * 16) + align_up(nt1 * sizeof(uint32_t)) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
-                            align_up(nt1 * k * 2 * sizeof(uint4)) + align_up((n_in + 64) * sizeof(uint32_t)) + 4096;
+                            align_up(nt1 * k * 2 * sizeof(uint4)) + align_up(nt1 * k * sizeof(uint32_t)) + align_up((n_in + 64) * sizeof(uint32_t)) + 4096;
     if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
     void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
@@ -171,10 +171,11 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
     void *d_scan_t = carve<uint8_t>(ac, scan_t);
     uint4 *d_rng = carve<uint4>(ac, nt1 * k * 2);
+    uint32_t *d_ends = carve<uint32_t>(ac, nt1 * k);
     p.tmp = carve<uint32_t>(ac, n_in + 64);
 
     HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, d_tile_desc, st));
-    HIP_TRY(ctx, launch_merge_tile_ranges(p, d_tile_desc, d_rng, st));
+    HIP_TRY(ctx, launch_merge_tile_ranges(p, d_tile_desc, d_ends, d_rng, st));
     p.rng = d_rng;
     p.out_counts = d_cnt;
     p.out_values = d_out_values;
