@@ -85,21 +85,21 @@ __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
     const uint32_t n = p.n_lists;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < p.n_sums) p.sums[gid] = 0;                      // level sums of the tile counts (filled by the tile kernel)
-    if (gw >= (uint64_t)p.n_tiles * n) return;
-    const uint32_t t = (uint32_t)(gw / n), j = (uint32_t)(gw % n);
+    // n - 1 waves per tile (one per non-driver list); the first of them also writes the driver's descriptor
+    const uint32_t m = n > 1u ? n - 1u : 1u;
+    if (gw >= (uint64_t)p.n_tiles * m) return;
+    const uint32_t t = (uint32_t)(gw / m), j = (uint32_t)(gw % m) + 1u;
     const ListView d = p.lists[0];
     const uint32_t b0 = t * p.G;
     const uint32_t b1 = b0 + p.G < d.nblk ? b0 + p.G : d.nblk;
     const uint32_t lo = d.skip[b0].first_doc;
     const uint32_t hi = b1 < d.nblk ? d.skip[b1].first_doc - 1u : *d.last_doc;
     uint32_t *r = p.ranges + (uint64_t)t * desc_stride(n);
-    if (j == 0) {
-        if (lane_id() == 0) {
-            r[0] = lo; r[1] = hi;
-            r[2] = b0; r[3] = b1; r[4] = d.skip[b0].byte_off; r[5] = d.skip[b1].byte_off;
-        }
-        return;
+    if (j == 1u && lane_id() == 0) {
+        r[0] = lo; r[1] = hi;
+        r[2] = b0; r[3] = b1; r[4] = d.skip[b0].byte_off; r[5] = d.skip[b1].byte_off;
     }
+    if (j >= n) return;                         // single-list query
     const ListView L = p.lists[j];
     // first block that may hold ids >= lo: the last block whose first_doc <= lo
     uint32_t ub, bh;                            // bh: first block starting after hi
@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
 
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
-    const uint64_t nthr = (uint64_t)p.n_tiles * p.n_lists;
+    const uint64_t nthr = (uint64_t)p.n_tiles * (p.n_lists > 1u ? p.n_lists - 1u : 1u);
     const uint64_t pthr = std::max<uint64_t>(nthr * 64u, p.n_sums);
     if (ev0) (void)hipEventRecord(ev0, s);          // the events bracket the whole pass: partition + tiles + expand
     if (p.wave_mode) {
