@@ -152,7 +152,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    ctx.set_option("profile.events", 1)
+    ctx.set_option("profile.events", 8)      # every 8th pass is bracketed by HIP events (a pair idles the stream ~10 us)
     ctx.profile_read()
     sync_all()
     t0 = time.perf_counter()

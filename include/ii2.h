@@ -185,9 +185,10 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);
 /* With option "debug.stamps"=1 the intersect kernel sums, per workgroup, the shader cycles spent
  * in each part of its tile loop; this copies those counters (8 words per workgroup) out. */
 int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words);
-/* With option "profile.events"=1 every call brackets its dominant kernel (the intersect / merge tile
- * kernel) with HIP events on the ctx stream; this waits for the stream and returns the summed device
- * time and the number of launches since the previous read. */
+/* With option "profile.events"=N (N > 0) every Nth call brackets its pass (intersect: partition + tiles +
+ * expand; merge: the tile kernel) with HIP events on the ctx stream — a timed event pair idles the stream
+ * for ~10 us, so sample (N = 8) when the calls themselves are being timed; this waits for the stream and
+ * returns the summed device time and the number of bracketed launches since the previous read. */
 int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches);
 
 #ifdef __cplusplus

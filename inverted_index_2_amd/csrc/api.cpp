@@ -58,7 +58,8 @@ template <class T> static T *ws_take(ii2_ctx *ctx, size_t count) {
 }
 
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1) {
-    if (!ctx->opt_profile_events) return false;
+    if (ctx->opt_profile_events <= 0) return false;
+    if (ctx->prof_calls++ % (uint64_t)ctx->opt_profile_events != 0) return false;   // a timed event pair costs ~10 us of stream idle time
     std::pair<hipEvent_t, hipEvent_t> pr;
     if (!ctx->prof_pool.empty()) { pr = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
     else if (hipEventCreate(&pr.first) != hipSuccess || hipEventCreate(&pr.second) != hipSuccess) return false;

@@ -33,7 +33,8 @@ struct ii2_ctx {
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
     size_t aux2_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
-    int64_t opt_profile_events = 0;     // bracket the dominant kernel of each call with HIP events
+    int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
+    uint64_t prof_calls = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;     // reusable pairs
     unsigned long long *d_debug = nullptr;
