@@ -606,6 +606,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     uint64_t *d_tile_off = nullptr;
     const uint32_t wgs_default = wave ? 4u : 5u;    // LDS per workgroup: ~37 KB (wave) / ~29 KB
     p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : wgs_default);
+    p.bitmap_mode = ctx->opt_intersect_bitmap ? 1u : 0u;
     p.tomb = tomb ? tomb->d_words : nullptr;
     p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
     p.out = d_out;
@@ -688,6 +689,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
+    else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

@@ -33,6 +33,7 @@ struct ii2_ctx {
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
     size_t aux2_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
+    int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
@@ -124,6 +125,7 @@ struct IntersectParams {
     uint32_t desc_words;         // words per tile in `ranges`
     uint32_t wave_mode;          // 1: wave-level kernels (intersect_wave.hip)
     uint32_t max_grid;           // workgroups of the tile kernel (each walks tiles w, w+grid, ...)
+    uint32_t bitmap_mode;        // 1: very dense tiles use per-list bitmaps (option intersect.bitmap)
 };
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;

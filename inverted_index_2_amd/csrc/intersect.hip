@@ -135,6 +135,7 @@ struct __align__(16) IsectSmem {
     uint32_t ncand;
     uint32_t pad;
 };
+constexpr uint32_t BM_MAXL = 7;            // lists a bitmap-mode tile can hold (7 x 522 words fit the map)
 constexpr uint32_t GALLOP_SUB = 8;         // driver blocks the gallop path handles per round
 static_assert(GALLOP_SUB * 256u * 5u <= MAP_BYTES, "gallop candidates + flags must fit the byte map");
 
@@ -176,7 +177,7 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
     return ((((w & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
 
-__global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
+__global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     __shared__ IsectSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t n = p.n_lists;
@@ -219,7 +220,152 @@ __global__ __launch_bounds__(256) void k_isect_tiles(IntersectParams p) {
         const ListView drv = p.lists[0];
         uint32_t *slot = p.tmp + (uint64_t)tile * p.slot_words;     // this tile's bitmap words / id list
 
-        if (span < ISECT_SMAX) {
+        // Very dense tiles (every phase: full blocks of single-byte gaps, at most ~3 docs per posting) keep one
+        // BITMAP per list instead of the byte map: a lane turns four gap bytes into a 32-bit mask in registers
+        // ((M << gap) | 1, one instruction per posting) and ORs it into its list's bitmap with two LDS atomics per
+        // four postings; the result is the AND of the bitmaps.  Purely a fast path: any block is still decoded right.
+        bool bm = span < ISECT_SMAX && n <= BM_MAXL && p.bitmap_mode != 0u;
+        for (uint32_t j = 0; j < n && bm; j++) {
+            const uint32_t nb = D[3 + 4 * j] - D[2 + 4 * j], bytes = D[5 + 4 * j] - D[4 + 4 * j];
+            bm = nb > 0u && bytes == 255u * nb && (uint64_t)bytes * 13u >= (uint64_t)span * 4u;
+        }
+        if (bm) {
+            // ================= bitmap path =================
+            const uint32_t mlo = lo & ~31u;
+            const uint32_t mspan = hi - mlo;
+            const uint32_t nwords = (mspan >> 5) + 1u;
+            constexpr uint32_t GU = 128u;                    // guard bits below and above the tile's range
+            const uint32_t bstride = nwords + 9u;            // words per list bitmap: 4 guard + nwords + 4 guard + 1 spill
+            const uint32_t lim = mspan + 252u;               // highest (guard-shifted) position ever written
+            uint32_t *bmw = reinterpret_cast<uint32_t *>(sm.map);
+            for (uint32_t i = (uint32_t)tid; 4u * i < n * bstride; i += 256u)
+                reinterpret_cast<uint4 *>(bmw)[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t j = 0; j < n; j++) {
+                const ListView L = p.lists[j];
+                const Phase d = {D[2 + 4 * j], D[3 + 4 * j], D[4 + 4 * j], D[5 + 4 * j]};
+                const bool staged = can_stage(d);
+                if (j == n - 1u && has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
+                if (staged) prefetch_commit(sm, pf, d, tid);
+                II2_STAMP(4)
+                lds_barrier();
+                if (j + 1u < n) {
+                    const Phase dn = {D[6 + 4 * j], D[7 + 4 * j], D[8 + 4 * j], D[9 + 4 * j]};
+                    if (can_stage(dn)) prefetch_issue(pf, dn, p.lists[j + 1u], tid);
+                } else if (has_next) {
+                    const uint32_t *DN = sm.desc[(it + 1u) & 1u];
+                    const Phase dn = {DN[2], DN[3], DN[4], DN[5]};
+                    if (DN[1] - DN[0] < ISECT_SMAX && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
+                }
+                II2_STAMP(0)
+                const uint32_t nblk = d.bh - d.bl;
+                uint32_t *bmj = bmw + j * bstride;
+                auto setbit = [&](uint32_t id, bool valid) {
+                    const uint32_t pos = id - mlo + GU;
+                    if (valid && pos <= lim) atomicOr(&bmj[pos >> 5], 1u << (pos & 31u));
+                };
+                auto mark4b = [&](uint32_t, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                    setbit(id0, mask & 1u); setbit(id1, mask & 2u); setbit(id2, mask & 4u); setbit(id3, mask & 8u);
+                };
+                const uint32_t rl = (uint32_t)l & 15u, row = (uint32_t)l >> 4;
+                auto mark16b = [&](uint32_t base, const uint4 &w, bool rv, uint32_t first_doc) {
+                    const uint32_t u = base - mlo + GU;              // (guard-shifted) position of the posting before my bytes
+                    const bool ok = rv && u <= mspan + GU;           // else the lane lies wholly outside the tile's range
+                    const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+                    uint32_t ss[4];
+#pragma unroll
+                    for (int g = 0; g < 4; g++) ss[g] = __builtin_amdgcn_sad_u8(ww[g], 0u, 0u);
+                    const uint32_t smax = max(max(ss[0], ss[1]), max(ss[2], ss[3]));
+                    const bool fast = ok && smax <= 31u;             // four postings fit one 32-bit mask
+                    const uint32_t seed = fast ? 1u : 0u;
+                    uint32_t q = u;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        const uint32_t x = ww[g];
+                        uint32_t M = (seed << ((x >> 24) & 31u)) | seed;        // postings 3, 2 of the group
+                        M = (M << ((x >> 16) & 31u)) | seed;                    // posting 1
+                        M = (M << ((x >> 8) & 31u)) | seed;                     // posting 0 (bit 0)
+                        uint32_t P = q + (x & 0xFFu);
+                        P = P < lim ? P : lim;
+                        q += ss[g];
+                        const unsigned long long MM = (unsigned long long)M << (P & 31u);
+                        uint32_t *dst = bmj + (P >> 5);
+                        atomicOr(dst, (uint32_t)MM);
+                        atomicOr(dst + 1, (uint32_t)(MM >> 32));
+                    }
+                    const bool slow = ok && !fast;
+                    if (__ballot(slow) != 0ull) {
+                        uint32_t pp = u;
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            pp += (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                            if (slow && pp <= lim) atomicOr(&bmj[pp >> 5], 1u << (pp & 31u));
+                        }
+                    }
+                    setbit(first_doc, rv && rl == 0u);
+                };
+                const uint32_t ngroups = (nblk + 3u) >> 2;
+                if (staged) {
+                    const uint32_t base16 = d.qlo & ~15u;
+                    for (uint32_t g = (uint32_t)wv; g < ngroups; g += 4u) {
+                        const uint32_t bi = 4u * g + row;
+                        const bool rv = bi < nblk;
+                        ii2_skip e0 = {0u, 0u}, e1 = {0u, 0u};
+                        if (rv) { e0 = sm.skipbuf[bi]; e1 = sm.skipbuf[bi + 1u]; }
+                        uint32_t base;
+                        uint4 w;
+                        if (decode_rows16(LdsBytes16{sm.raw}, e0.byte_off - base16, e1.byte_off - base16, e0.first_doc, rv, base, w)) {
+                            mark16b(base, w, rv, e0.first_doc);
+                        } else {
+                            for (uint32_t i = 4u * g; i < 4u * g + 4u && i < nblk; i++) {
+                                const ii2_skip f0 = sm.skipbuf[i], f1 = sm.skipbuf[i + 1u];
+                                decode_block_wave4(LdsBytes{sm.raw}, f0.byte_off - base16, f1.byte_off - base16, f0.first_doc, mark4b);
+                            }
+                        }
+                    }
+                } else {
+                    for (uint32_t g = (uint32_t)wv; g < ngroups; g += 4u) {
+                        const uint32_t bi = 4u * g + row;
+                        const bool rv = bi < nblk;
+                        ii2_skip e0 = {0u, 0u}, e1 = {0u, 0u};
+                        if (rv) { e0 = L.skip[d.bl + bi]; e1 = L.skip[d.bl + bi + 1u]; }
+                        uint32_t base;
+                        uint4 w;
+                        if (decode_rows16(GlobalBytes16{L.payload}, e0.byte_off, e1.byte_off, e0.first_doc, rv, base, w)) {
+                            mark16b(base, w, rv, e0.first_doc);
+                        } else {
+                            for (uint32_t b = d.bl + 4u * g; b < d.bl + 4u * g + 4u && b < d.bh; b++)
+                                decode_block_wave4(GlobalBytes{L.payload}, L.skip[b].byte_off, L.skip[b + 1].byte_off,
+                                                   L.skip[b].first_doc, mark4b);
+                        }
+                    }
+                }
+                II2_STAMP(1)
+                lds_barrier();
+                II2_STAMP(2)
+            }
+            // finalise: AND of the list bitmaps, tombstones cleared, survivors counted
+            uint32_t mine = 0;
+            for (uint32_t wi = (uint32_t)tid; wi < nwords; wi += 256u) {
+                uint32_t word = bmw[GU / 32u + wi];
+                for (uint32_t j = 1; j < n; j++) word &= bmw[j * bstride + GU / 32u + wi];
+                if (wi == nwords - 1u && (mspan & 31u) != 31u) word &= (2u << (mspan & 31u)) - 1u;
+                if (p.tomb) {
+                    const uint32_t tw = (mlo >> 5) + wi;
+                    if (tw < p.tomb_nwords) word &= ~p.tomb[tw];
+                }
+                slot[wi] = word;
+                mine += (uint32_t)__popc(word);
+            }
+            mine = wave_sum(mine);
+            if (l == 0) sm.wcnt[wv] = mine;
+            lds_barrier();
+            if (tid == 0) {
+                const uint32_t c = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
+                p.tile_count[tile] = c;
+                if (c) atomicAdd(&p.sums[tile >> 6], c);
+            }
+            II2_STAMP(3)
+        } else if (span < ISECT_SMAX) {
             // ================= byte-map path =================
             const uint32_t mlo = lo & ~31u;                  // map origin: 32-doc aligned
             const uint32_t mspan = hi - mlo;                 // last valid map offset
