@@ -20,6 +20,10 @@ def _check(ctx, lists, removed=None):
         assert n == want.size, (wave, n, want.size)
         assert np.array_equal(got, want), wave
     ctx.set_option("intersect.wave", 0)
+    ctx.set_option("intersect.bitmap", 0)      # very dense tiles: per-list bitmaps (default) vs the byte map
+    out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
+    ctx.set_option("intersect.bitmap", 1)
+    assert n == want.size and np.array_equal(out.download(n), want)
     # split over two segments as well (lists from different segments)
     if len(lists) >= 2:
         s0, s1 = ctx.encode_lists(lists[:1]), ctx.encode_lists(lists[1:])
@@ -111,3 +115,33 @@ def test_config2_scaled_properties(ctx):
     D = 10_000_000
     a, b = synth.zipf_list(2, D), synth.zipf_list(3, D)
     _check(ctx, [a, b])
+
+
+def _gap_list(rng, n, gaps, probs, start=0):
+    g = rng.choice(np.asarray(gaps, np.int64), size=n, p=probs)
+    return (start + np.cumsum(g)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("k", [2, 3, 5, 7, 8])
+def test_bitmap_mode_very_dense(ctx, k):
+    """Lists dense enough for the bitmap tile path (full blocks of one-byte gaps, <= ~3 docs per posting);
+    7 lists is the most a bitmap tile holds, 8 falls back to the byte map."""
+    rng = np.random.default_rng(900 + k)
+    lists = [_gap_list(rng, 300_000, [1, 2, 3, 4, 5], [0.35, 0.3, 0.2, 0.1, 0.05], start=int(rng.integers(0, 50))) for _ in range(k)]
+    _check(ctx, lists)
+    _check(ctx, lists, removed=rng.integers(0, 700_000, 20_000).astype(np.uint32))
+
+
+def test_bitmap_mode_gap_outliers(ctx):
+    """Dense lists with outliers: gaps of 31/32 (the 32-bit mask limit of a group of four), runs of 127s that push a
+    lane past its window, and a partial last block — the slow lanes and the generic block decoder of the bitmap path."""
+    rng = np.random.default_rng(77)
+    a = _gap_list(rng, 400_000, [1, 2, 7, 8, 9, 10, 31, 32, 127], [0.5, 0.3, 0.04, 0.04, 0.04, 0.04, 0.02, 0.01, 0.01])
+    b = _gap_list(rng, 500_000, [1, 2, 3, 29, 30, 33, 100], [0.45, 0.3, 0.2, 0.02, 0.01, 0.01, 0.01], start=3)
+    c = _gap_list(rng, 350_123, [1, 2, 3, 127], [0.4, 0.35, 0.2, 0.05], start=11)
+    _check(ctx, [a, b])
+    _check(ctx, [a, b, c], removed=a[::5].copy())
+    # a long stretch of 127-gaps inside an otherwise dense list: lanes wholly outside the other list's tile ranges
+    d = np.concatenate([np.arange(1, 200_000, 2), 200_000 + 127 * np.arange(1, 3000), 600_000 + np.arange(0, 200_000, 3)]).astype(np.uint32)
+    _check(ctx, [d, np.arange(0, 800_001, 1, dtype=np.uint32)])
+    _check(ctx, [np.arange(0, 800_001, 2, dtype=np.uint32), d])
