@@ -310,6 +310,14 @@ def bench_merge(args, ctx, torch, dist, world, rank):
     nblk = sum(s.info.n_blocks for s in segs)
     alg = enc + 8 * nblk + 4 * k * (T + 1) + args.docs // 8 + 4 * st.n_out + 4 * (T + 1)
     kavg = kern_ms / max(kern_n, 1) * 1e-3
+    # HBM traffic of one merge (all its kernels) from the PMC passes kept under profiles/ (same command, default sizes)
+    traffic = None
+    try:
+        if T == 200_000 and k == 16 and args.merge_mean == 1000.0 and args.docs == 100_000_000 and world == 1:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_merge.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_pass_corrected"]
+    except OSError:
+        pass
     result = {
         "metric": "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline",
         "value": n_in * world * args.steps / dt, "unit": "postings/s", "n_gpus": world, "steps": args.steps,
@@ -319,7 +327,7 @@ def bench_merge(args, ctx, torch, dist, world, rank):
                                % (k, T, args.merge_mean), "postings_in_per_gpu": n_in, "postings_out_per_gpu": int(st.n_out),
                    "tiles": int(st.n_tiles), "parallelism": "terms%d" % world},
         "roofline": {"bound": "hbm", "kernel": "ii2::k_merge_tiles", "achieved": alg / kavg / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg / kavg / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": alg / kavg / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(alg), "kernel_avg_us": kavg * 1e6, "launches_timed": int(kern_n)},
     }
     if not args.no_cpu_baseline:

@@ -482,12 +482,16 @@ int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where
     if (!t) return II2_ENOMEM;
     t->ctx = ctx;
     t->n_words = n ? (uint64_t)(mx >> 5) + 1 : 0;
-    if (hipMalloc((void **)&t->d_words, (t->n_words + 4) * sizeof(uint32_t)) != hipSuccess) {
+    // bitmap, then its summary (1 bit per 16 docs = per half bitmap word) in the same allocation
+    const uint64_t words_padded = (t->n_words + 4 + 3) & ~3ull;
+    const uint64_t n_sum = (t->n_words + 15) / 16 + 1;
+    if (hipMalloc((void **)&t->d_words, (words_padded + n_sum) * sizeof(uint32_t)) != hipSuccess) {
         delete t;
         return fail(ctx, II2_ENOMEM, "tombstone bitmap allocation failed");
     }
-    hipError_t e = hipMemsetAsync(t->d_words, 0, (t->n_words + 4) * sizeof(uint32_t), ctx->stream);
-    if (e == hipSuccess) e = launch_tomb_build(d_rem, n, t->d_words, t->n_words, ctx->stream);
+    t->d_summary = t->d_words + words_padded;
+    hipError_t e = hipMemsetAsync(t->d_words, 0, (words_padded + n_sum) * sizeof(uint32_t), ctx->stream);
+    if (e == hipSuccess) e = launch_tomb_build(d_rem, n, t->d_words, t->n_words, t->d_summary, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipFree(t->d_words);

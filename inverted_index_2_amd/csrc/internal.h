@@ -72,6 +72,7 @@ struct ii2_seg {
 struct ii2_tomb {
     ii2_ctx *ctx = nullptr;
     uint32_t *d_words = nullptr;
+    uint32_t *d_summary = nullptr;   // bit g set <=> some doc of [16g, 16g+16) is removed (same allocation as d_words)
     uint64_t n_words = 0;   // bitmap covers doc ids [0, 32*n_words)
 };
 
@@ -148,7 +149,7 @@ hipError_t launch_dec_block_counts(const ii2_skip *skip, const uint8_t *payload,
 hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, const uint64_t *bpo,
                             uint32_t *values, hipStream_t s);
 hipError_t launch_gather_post_off(const uint32_t *blk_off, const uint64_t *bpo, uint64_t n_lists, uint64_t *post_off, hipStream_t s);
-hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, hipStream_t s);
+hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, uint32_t *summary, hipStream_t s);
 hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, uint64_t n_lists, uint32_t *cnt, uint32_t *blk_list,
                                 uint32_t *last_doc, hipStream_t s);
 hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_list, const ii2_skip *skip, const uint8_t *payload,
@@ -186,6 +187,7 @@ struct MergeParams {
     uint32_t n_tiles;
     uint64_t n_terms;
     const uint32_t *tomb;
+    const uint32_t *tomb_summary;  // 1 bit per 16 docs: most bit tests stop at this small, L2-resident array
     uint32_t tomb_nwords;
     uint32_t small_max;           // terms with a larger upper bound get their own doc-range tiles
     uint32_t large_tile;          // target upper bound per large-term tile

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t v = sm.vals[1][q];
                         const uint32_t b = bucket_of(v);
                         const uint32_t lo = bkt[b], hi = bkt[b + 1u];
-                        const uint32_t tw = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb[v >> 5] : 0u;   // in flight during the loop
+                        const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
                         uint32_t r = 0, dup = 0;
                         for (uint32_t m = lo; m < hi; m++) {
                             const uint32_t u = sm.vals[1][m];
@@ -514,7 +514,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                             dup |= eq;
                         }
                         sm.vals[0][lo + r] = v;
-                        sm.tids[0][lo + r] = (uint16_t)((dup | ((tw >> (v & 31u)) & 1u)) << 15);   // dead: duplicate or tombstoned
+                        uint32_t dead = dup;
+                        if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
+                        sm.tids[0][lo + r] = (uint16_t)(dead << 15);   // dead: duplicate or tombstoned
                     }
                     __syncthreads();
                     nruns = 1u;
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t t = sm.tids[1][q];
                         const uint32_t b = bucket_mt(t, v);
                         const uint32_t lo = base_of(b), hi = b + 1u < MCAP ? base_of(b + 1u) : n_in;
-                        const uint32_t tw = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb[v >> 5] : 0u;   // in flight during the loop
+                        const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
                         uint32_t r = 0, dup = 0;
                         for (uint32_t m = lo; m < hi; m++) {
                             const uint32_t u = sm.vals[1][m];
@@ -619,7 +621,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                             dup |= eq;
                         }
                         sm.vals[0][lo + r] = v;
-                        sm.tids[0][lo + r] = (uint16_t)(t | ((dup | ((tw >> (v & 31u)) & 1u)) << 15));   // bit 15: duplicate or tombstoned
+                        uint32_t dead = dup;
+                        if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
+                        sm.tids[0][lo + r] = (uint16_t)(t | (dead << 15));   // bit 15: duplicate or tombstoned
                     }
                     __syncthreads();
                     nruns = 1u;
@@ -769,7 +773,8 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
                     const uint32_t w = fv[j] >> 5;
-                    tw[j] = (p.tomb && a + (uint32_t)j < n_in && w < p.tomb_nwords) ? p.tomb[w] : 0u;
+                    tw[j] = 0u;
+                    if (p.tomb && a + (uint32_t)j < n_in && w < p.tomb_nwords && ((p.tomb_summary[fv[j] >> 9] >> ((fv[j] >> 4) & 31u)) & 1u)) tw[j] = p.tomb[w];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) {

@@ -58,6 +58,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.k = k;
     p.n_terms = T;
     p.tomb = tomb ? tomb->d_words : nullptr;
+    p.tomb_summary = tomb ? tomb->d_summary : nullptr;
     p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
     const uint32_t cap = MERGE_CAP;
     // terms per batch are bounded by the list-offset table: (nt + 1) * k <= MERGE_OFFMAX

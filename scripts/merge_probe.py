@@ -8,7 +8,7 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 ctx = Context(0)
 t = time.time(); offs, vals, removed = synth.merge_workload(T, k, 1000.0, 100_000_000); print("gen", time.time() - t, flush=True)
 segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
-tomb = ctx.tombstones(removed)
+tomb = ctx.tombstones(removed) if os.environ.get("NO_TOMB") != "1" else None
 n_in = sum(int(o[-1]) for o in offs)
 out_off = ctx.empty(T + 1, np.uint64); out_vals = ctx.empty(n_in)
 _, _, st = ctx.merge(segs, tomb, out_off, out_vals)
