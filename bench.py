@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--tombstones", action="store_true", help="apply a 1%% tombstone bitmap during the intersection")
     ap.add_argument("--gather-timed", action="store_true", help="include the RCCL all-gatherv in every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-timeout", type=int, default=120, help="seconds the post-timing all-gatherv may take (N > 1)")
     ap.add_argument("--merge-terms", type=int, default=200_000, help="merge workload: aligned terms")
     ap.add_argument("--merge-segments", type=int, default=16)
     ap.add_argument("--merge-mean", type=float, default=1000.0)
@@ -112,19 +113,27 @@ def main():
         raise SystemExit(f"rank {rank}: GPU intersection differs from the numpy cross-check")
 
     gather_out = None
-    gather_impl = None
-    if world > 1:
+    gstate = {"impl": None}
+
+    def init_comm():
+        # the library's own RCCL communicator (ii2_comm_*); torch's communicator only carries the unique id
+        nonlocal gather_out
+        if gstate["impl"] is not None:
+            return
         gather_out = ctx.empty((min(a.size, b.size) + 512) * world)
         try:
             uid = [comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(uid, src=0)
             ctx.comm_init(world, rank, uid[0])
-            gather_impl = "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv)"
+            gstate["impl"] = "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv)"
         except Exception as e:  # noqa: BLE001 — keep the scaling run alive; the exchange then goes through torch (RCCL too)
-            gather_impl = "torch.distributed.all_gather fallback (%s)" % type(e).__name__
+            gstate["impl"] = "torch.distributed.all_gather fallback (%s)" % type(e).__name__
+
+    if world > 1 and args.gather_timed:
+        init_comm()
 
     def gather_all():
-        if gather_impl.startswith("ii2_"):
+        if gstate["impl"].startswith("ii2_"):
             return ctx.allgatherv(out, n_out, gather_out, world)
         # fallback: padded all_gather through torch's RCCL communicator, then pack on the host side of the check
         cap = min(a.size, b.size) + 512
@@ -191,24 +200,6 @@ def main():
         pipelined = {"streams": 2, "value": n_in * args.steps / pdt, "unit": "postings/s", "ms_per_step": pdt / args.steps * 1e3}
         ctx2.close()
 
-    # the exchange step, once, outside the timed region: rank-order concatenation of the results
-    gather_ms = None
-    total_out = n_out
-    if world > 1:
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
-        counts = gather_all()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        total_out = sum(counts)
-        allv = gather_out.download(total_out)
-        if not (np.all(np.diff(allv.astype(np.int64)) > 0) and np.array_equal(allv[sum(counts[:rank]):sum(counts[:rank + 1])], got)):
-            raise SystemExit(f"rank {rank}: all-gatherv result is not the rank-order concatenation")
-
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
     info = seg.info
     # algorithmic bytes of one pass (SURVEY.md §8 d): encoded payload + 8 B per block of
     # skip table + 4 B per result id (+ D/8 tombstone bitmap).  The HIP events bracket the whole pass
@@ -254,12 +245,38 @@ def main():
     }
     if pipelined is not None:
         result["pipelined"] = pipelined
-    if gather_ms is not None:
+    # the exchange step, once, outside the timed region: rank-order concatenation of the results.  The timed
+    # figures above are already final; a watchdog keeps a stuck exchange from taking the whole scaling run with it.
+    if world > 1:
+        import threading
+
+        def on_timeout():
+            if rank == 0:
+                result["allgatherv_impl"] = "skipped: the exchange did not finish within %d s" % args.gather_timeout
+                print(json.dumps(result), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(args.gather_timeout, on_timeout)
+        timer.daemon = True
+        timer.start()
+        init_comm()
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        counts = gather_all()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        total_out = sum(counts)
+        allv = gather_out.download(total_out)
+        if not (np.all(np.diff(allv.astype(np.int64)) > 0) and np.array_equal(allv[sum(counts[:rank]):sum(counts[:rank + 1])], got)):
+            raise SystemExit(f"rank {rank}: all-gatherv result is not the rank-order concatenation")
+        timer.cancel()
+        if rank != 0:
+            dist.destroy_process_group()
+            return
         result["allgatherv_ms"] = gather_ms
-        result["allgatherv_impl"] = gather_impl
+        result["allgatherv_impl"] = gstate["impl"]
         result["allgatherv_ids"] = int(total_out)
-    if not args.no_cpu_baseline:
-        reps = 10
+    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 figure
+        reps = 30                                      # ~12 s of single-thread CPU work
         v, res, per = cpu_baseline_intersect([a, b], removed, reps)
         if not np.array_equal(res, got):
             raise SystemExit("GPU result differs from the oracle")
