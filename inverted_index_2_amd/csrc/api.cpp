@@ -588,7 +588,18 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         }
         G = gw;
     }
+    // dense queries of up to 4 lists: the bitmap tile kernel, all phases of a tile staged together (12 KB)
+    bool bm2 = !wave && n <= ISECTB_MAXL && ctx->opt_intersect_bm2 != 0 && ctx->opt_intersect_g <= 0 && nblk0 > 1 &&
+               per_block_span > 0 && per_block_span <= 3.25 * II2_DV1_BLOCK;
+    if (bm2) {
+        double ratio = 0;                                  // payload bytes of a tile per driver block, in blocks
+        for (uint32_t i = 0; i < n; i++) ratio += (double)views[i].nblk / (double)nblk0;
+        const uint32_t gb = (uint32_t)(11000.0 / (255.0 * ratio + 255.0 * 0.15 * n));
+        if (gb < 4u) bm2 = false;
+        else if (gb < G) G = gb;
+    }
     p.G = G;
+    p.bm2 = bm2 ? 1u : 0u;
     p.wave_mode = wave ? 1u : 0u;
     p.n_tiles = (nblk0 + G - 1) / G;
     const size_t dstride = wave ? (16 + 40 * ((size_t)n - 1)) : (2 + 4 * (size_t)n);
@@ -598,7 +609,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     slot_words = (slot_words + 3u) & ~3u;
     p.slot_words = slot_words;
     size_t need = align_up((size_t)p.n_tiles * dstride * sizeof(uint32_t)) + align_up((size_t)p.n_tiles * slot_words * sizeof(uint32_t)) +
-                  align_up(((size_t)p.n_tiles + 1) * sizeof(uint32_t)) + align_up(((size_t)p.n_tiles / 64 + p.n_tiles / 4096 + 4) * sizeof(uint32_t)) + 4096;
+                  2 * align_up(((size_t)p.n_tiles + 2) * sizeof(uint32_t)) + align_up(((size_t)p.n_tiles / 64 + p.n_tiles / 4096 + 4) * sizeof(uint32_t)) + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     p.ranges = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * dstride);
@@ -607,6 +618,16 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.n_sums1 = p.n_tiles / 64 + 1;
     p.n_sums = p.n_sums1;
     p.sums = ws_take<uint32_t>(ctx, p.n_sums);
+    p.defer = ws_take<uint32_t>(ctx, (size_t)p.n_tiles + 1);
+    p.n_defer = (uint32_t *)(ctx->d_mail + 96);
+    {
+        size_t per_cu = (160u * 1024u) / bm2_lds_bytes(n);
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        if (ctx->opt_intersect_wgs > 0) per_cu = (size_t)ctx->opt_intersect_wgs;
+        p.bm2_grid = (uint32_t)(ctx->cu_count * per_cu);
+        p.defer_grid = (uint32_t)ctx->cu_count * 2u;
+    }
     uint64_t *d_tile_off = nullptr;
     const uint32_t wgs_default = wave ? 4u : 5u;    // LDS per workgroup: ~37 KB (wave) / ~29 KB
     p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : wgs_default);
@@ -694,6 +715,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
+    else if (k == "intersect.bm2") ctx->opt_intersect_bm2 = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

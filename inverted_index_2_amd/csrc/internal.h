@@ -33,6 +33,7 @@ struct ii2_ctx {
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
     size_t aux2_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
+    int64_t opt_intersect_bm2 = 0;      // 1: dense queries of <= 4 lists go to the bitmap tile kernel first (measured slower: off)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
@@ -105,6 +106,8 @@ struct SegView {
 };
 
 constexpr uint32_t MAX_LISTS = II2_MAX_LISTS;
+constexpr uint32_t ISECTB_MAXL = 4;          // lists the bitmap tile kernel (intersect_bm.hip) takes
+size_t bm2_lds_bytes(uint32_t n_lists);      // its dynamic LDS per workgroup
 
 struct IntersectParams {
     ListView lists[MAX_LISTS];   // lists[0] is the driver (fewest blocks)
@@ -127,6 +130,11 @@ struct IntersectParams {
     uint32_t wave_mode;          // 1: wave-level kernels (intersect_wave.hip)
     uint32_t max_grid;           // workgroups of the tile kernel (each walks tiles w, w+grid, ...)
     uint32_t bitmap_mode;        // 1: very dense tiles use per-list bitmaps (option intersect.bitmap)
+    uint32_t defer_mode;         // 1: k_isect_tiles handles only the tiles listed in defer[0 .. *n_defer)
+    uint32_t bm2;                // 1: the bitmap kernel (intersect_bm.hip) runs first and defers what it cannot take
+    uint32_t *defer;             // [n_tiles] tiles left by the bitmap kernel
+    uint32_t *n_defer;           // their number (zeroed by the partition kernel)
+    uint32_t bm2_grid, defer_grid;   // workgroups of the bitmap kernel / of the clean-up launch of k_isect_tiles
 };
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
@@ -165,6 +173,7 @@ constexpr uint32_t ISECTW_SMAX = 8192;      // docs a wave's byte map covers (wa
 constexpr uint32_t ISECTW_ABLK = 12;        // prefetched blocks per other list and mini-tile
 constexpr uint32_t ISECTW_MAXL = 4;         // lists the wave-level kernel handles
 hipError_t launch_intersect_wave(const IntersectParams &p, hipStream_t s);
+hipError_t launch_intersect_bm(const IntersectParams &p, uint32_t grid, hipStream_t s);
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // merge / union

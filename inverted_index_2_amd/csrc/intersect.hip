@@ -85,6 +85,10 @@ __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
     const uint32_t n = p.n_lists;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < p.n_sums) p.sums[gid] = 0;                      // level sums of the tile counts (filled by the tile kernel)
+    if (p.bm2) {                                              // the bitmap kernel adds its counts per wave and lists what it skips
+        if (gid < p.n_tiles) p.tile_count[gid] = 0;
+        if (gid == 0) *p.n_defer = 0;
+    }
     // n - 1 waves per tile (one per non-driver list); the first of them also writes the driver's descriptor
     const uint32_t m = n > 1u ? n - 1u : 1u;
     if (gw >= (uint64_t)p.n_tiles * m) return;
@@ -177,6 +181,8 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
     return ((((w & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
 
+// DEFER: work off the tiles the bitmap kernel (intersect_bm.hip) left behind instead of all tiles
+template <bool DEFER>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     __shared__ IsectSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
@@ -186,8 +192,11 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     Prefetch pf;
     pf.r0 = make_uint4(0, 0, 0, 0); pf.r1 = pf.r0; pf.sk.first_doc = 0; pf.sk.byte_off = 0;
 
-    uint32_t tile = blockIdx.x;
-    if (tile >= p.n_tiles) return;
+    // work items: all tiles, or (after the bitmap kernel) the tiles it left for this kernel
+    const uint32_t n_items = DEFER ? *p.n_defer : p.n_tiles;
+    uint32_t item = blockIdx.x;
+    if (item >= n_items) return;
+    uint32_t tile = DEFER ? p.defer[item] : item;
     // diagnostics only: thread 0 sums the cycles spent in each part of the tile loop
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
@@ -208,12 +217,13 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
         if (D[1] - D[0] < ISECT_SMAX && can_stage(d0)) prefetch_issue(pf, d0, p.lists[0], tid);
     }
 
-    for (uint32_t it = 0; tile < p.n_tiles; it++, tile += gridDim.x) {
+    for (uint32_t it = 0; item < n_items; it++) {
         const uint32_t *D = sm.desc[it & 1u];
         const uint32_t lo = D[0], hi = D[1];
         const uint32_t span = hi - lo;
-        const uint32_t next_tile = tile + gridDim.x;
-        const bool has_next = next_tile < p.n_tiles;
+        const uint32_t next_item = item + gridDim.x;
+        const bool has_next = next_item < n_items;
+        const uint32_t next_tile = DEFER ? (has_next ? p.defer[next_item] : 0u) : next_item;
         // descriptors of this workgroup's next tile: one word per thread, in flight during the tile
         uint32_t dreg = 0;
         if (has_next && (uint32_t)tid < stride) dreg = p.ranges[(uint64_t)next_tile * stride + tid];
@@ -635,6 +645,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             }
         }
         lds_barrier();        // map / wcnt are reused by the next tile
+        item = next_item;
+        tile = next_tile;
     }
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
@@ -719,15 +731,24 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
     const uint64_t nthr = (uint64_t)p.n_tiles * (p.n_lists > 1u ? p.n_lists - 1u : 1u);
-    const uint64_t pthr = std::max<uint64_t>(nthr * 64u, p.n_sums);
+    const uint64_t pthr = std::max<uint64_t>(std::max<uint64_t>(nthr * 64u, p.n_sums), p.n_tiles);
     if (ev0) (void)hipEventRecord(ev0, s);          // the events bracket the whole pass: partition + tiles + expand
     if (p.wave_mode) {
         hipError_t e = launch_intersect_wave(p, s);
         if (e != hipSuccess) return e;
     } else {
         hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
-        const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-        hipLaunchKernelGGL(k_isect_tiles, dim3(grid), dim3(256), 0, s, p);
+        if (p.bm2) {
+            hipError_t e = launch_intersect_bm(p, p.bm2_grid, s);
+            if (e != hipSuccess) return e;
+            IntersectParams pd = p;                       // then the tiles it left behind (usually none: a small grid)
+            pd.defer_mode = 1u;
+            const uint32_t dgrid = p.n_tiles < p.defer_grid ? p.n_tiles : p.defer_grid;
+            hipLaunchKernelGGL(k_isect_tiles<true>, dim3(dgrid), dim3(256), 0, s, pd);
+        } else {
+            const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
+            hipLaunchKernelGGL(k_isect_tiles<false>, dim3(grid), dim3(256), 0, s, p);
+        }
     }
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);

@@ -24,6 +24,11 @@ def _check(ctx, lists, removed=None):
     out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
     ctx.set_option("intersect.bitmap", 1)
     assert n == want.size and np.array_equal(out.download(n), want)
+    if len(lists) <= 4:                        # the experimental bitmap tile kernel (dense queries; off by default)
+        ctx.set_option("intersect.bm2", 1)
+        out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
+        ctx.set_option("intersect.bm2", 0)
+        assert n == want.size and np.array_equal(out.download(n), want)
     # split over two segments as well (lists from different segments)
     if len(lists) >= 2:
         s0, s1 = ctx.encode_lists(lists[:1]), ctx.encode_lists(lists[1:])
