@@ -372,7 +372,6 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             if (tid == 0) {
                 const uint32_t c = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
                 p.tile_count[tile] = c;
-                if (c) atomicAdd(&p.sums[tile >> 6], c);
             }
             II2_STAMP(3)
         } else if (span < ISECT_SMAX) {
@@ -542,7 +541,6 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             if (tid == 0) {
                 const uint32_t c = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
                 p.tile_count[tile] = c;
-                if (c) atomicAdd(&p.sums[tile >> 6], c);
             }
             II2_STAMP(3)          // finalise
         } else {
@@ -633,7 +631,6 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             }
             if (tid == 0) {
                 p.tile_count[tile] = total | LIST_FLAG;
-                if (total) atomicAdd(&p.sums[tile >> 6], total);
             }
             // restart the pipeline for the next tile
             if (has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
@@ -651,6 +648,20 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
 #undef II2_STAMP
+}
+
+// ---- per-64-tile sums of the tile counts (expand reads them to place its tiles) ------------
+// A kernel of its own: an atomicAdd per tile from the tile kernel put 64 same-address device atomics in flight
+// per sum at once, and every workgroup then waited for its own at its next s_waitcnt — ~20 us per pass.
+__global__ void k_isect_sums(IntersectParams p) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.n_sums) return;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < 64u; i++) {
+        const uint32_t t = 64u * g + i;
+        if (t < p.n_tiles) s += p.tile_count[t] & ~LIST_FLAG;
+    }
+    p.sums[g] = s;
 }
 
 // ---- expand: bitmaps / id lists -> the final ascending id array -----------------------------
@@ -750,6 +761,7 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             hipLaunchKernelGGL(k_isect_tiles<false>, dim3(grid), dim3(256), 0, s, p);
         }
     }
+    if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 63u) / 64u), dim3(64), 0, s, p);
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);

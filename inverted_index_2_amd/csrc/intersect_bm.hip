@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256) void k_isect_bm(IntersectParams p) {
             const uint32_t c = tcnt[(it + 1u) & 1u];
             tcnt[(it + 1u) & 1u] = 0u;
             p.tile_count[prev_tile] = c;
-            if (c) atomicAdd(&p.sums[prev_tile >> 6], c);
         }
         if (has_next2 && (uint32_t)tid < stride) dreg = p.ranges[(uint64_t)next2_tile * stride + tid];
         // request the next tile's bytes — they have this whole tile to arrive
@@ -321,7 +320,6 @@ __global__ __launch_bounds__(256) void k_isect_bm(IntersectParams p) {
     if (tid == 0 && prev_ok) {
         const uint32_t c = tcnt[(it + 1u) & 1u];
         p.tile_count[prev_tile] = c;
-        if (c) atomicAdd(&p.sums[prev_tile >> 6], c);
     }
 }
 
