@@ -229,6 +229,7 @@ hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s)
 hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
                              uint32_t grid_rows, hipStream_t s);
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, uint32_t *ends, void *rng, hipStream_t s);
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 

@@ -853,7 +853,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
             const bool fits = load_range(dlo, dhi, true);
             slot = term_slot + sm.rank;                  // rank of the range start (0 for whole-term tiles)
             if (fits) {
-                total = merge_range(&outbuf, true, !root_full);
+                // range tiles of a large term leave its count to k_merge_large_counts: an atomicAdd per tile would put
+                // thousands of same-address device atomics in flight (the top terms own most tiles)
+                total = merge_range(&outbuf, root_full, false);
                 const uint32_t *V = sm.vals[outbuf];
                 for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
             } else {
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         continue;
                     }
                     uint32_t ob2 = 0;
-                    const uint32_t c = merge_range(&ob2, true, true);
+                    const uint32_t c = merge_range(&ob2, nt > 1u, true);       // single-term leaves: counted from the tile totals
                     const uint32_t *V = sm.vals[ob2];
                     for (uint32_t q = (uint32_t)tid; q < c; q += MT) p.tmp[slot + total + q] = V[q];
                     total += c;
@@ -906,6 +908,15 @@ __global__ __launch_bounds__(256) void k_merge_pack(const uint32_t *__restrict__
             if (ob + q < out_cap) out[ob + q] = src[q];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = off[n_tiles];
+}
+
+// survivors of every large term = survivors of its tiles (tile_off = exclusive scan of the tile counts)
+__global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile, const uint64_t *__restrict__ tile_off,
+                                     uint64_t n_terms, uint32_t *__restrict__ out_counts) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_terms || ntl[t] == 0u) return;
+    const uint32_t a = term_tile[t];
+    out_counts[t] = (uint32_t)(tile_off[a + ntl[t]] - tile_off[a]);
 }
 
 __global__ void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out) {
@@ -964,6 +975,11 @@ hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, con
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s) {
     if (p.n_tiles == 0) return hipSuccess;
     hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
+    return hipGetLastError();
+}
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s) {
+    if (p.n_terms == 0 || p.n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, ntl, term_tile, tile_off, p.n_terms, p.out_counts);
     return hipGetLastError();
 }
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s) {

@@ -196,6 +196,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     // 2 workgroups of ~67 KB LDS per CU; each walks tiles w, w+grid, ...
     HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st, e0, e1));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
+    HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, d_tile_off, st));
     HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
     HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
     if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
