@@ -653,15 +653,12 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
 // ---- per-64-tile sums of the tile counts (expand reads them to place its tiles) ------------
 // A kernel of its own: an atomicAdd per tile from the tile kernel put 64 same-address device atomics in flight
 // per sum at once, and every workgroup then waited for its own at its next s_waitcnt — ~20 us per pass.
-__global__ void k_isect_sums(IntersectParams p) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_isect_sums(IntersectParams p) {
+    const uint32_t g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;      // one wave per sum: 64 counts, one load each
     if (g >= p.n_sums) return;
-    uint32_t s = 0;
-    for (uint32_t i = 0; i < 64u; i++) {
-        const uint32_t t = 64u * g + i;
-        if (t < p.n_tiles) s += p.tile_count[t] & ~LIST_FLAG;
-    }
-    p.sums[g] = s;
+    const uint32_t t = 64u * g + (uint32_t)lane_id();
+    const uint32_t s = wave_sum(t < p.n_tiles ? (p.tile_count[t] & ~LIST_FLAG) : 0u);
+    if (lane_id() == 0) p.sums[g] = s;
 }
 
 // ---- expand: bitmaps / id lists -> the final ascending id array -----------------------------
@@ -761,7 +758,7 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             hipLaunchKernelGGL(k_isect_tiles<false>, dim3(grid), dim3(256), 0, s, p);
         }
     }
-    if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 63u) / 64u), dim3(64), 0, s, p);
+    if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);

@@ -15,7 +15,7 @@ def per_kernel(path, counter, prefixes, skip):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0]
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if any(name.startswith(p) for p in prefixes):
                 vals[name].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v[skip:]) / max(len(v[skip:]), 1) for k, v in vals.items() if len(v) > skip}
