@@ -919,11 +919,18 @@ __global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uin
     out_counts[t] = (uint32_t)(tile_off[a + ntl[t]] - tile_off[a]);
 }
 
-__global__ void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out) {
+// one atomic per workgroup, few workgroups: a single address sustains only ~90 device atomics per microsecond
+__global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out) {
+    __shared__ uint32_t wsum[4];
     uint32_t c = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += v[i] != 0;
     c = wave_sum(c);
-    if (lane_id() == 0 && c) atomicAdd((unsigned long long *)out, (unsigned long long)c);
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (t) atomicAdd((unsigned long long *)out, (unsigned long long)t);
+    }
 }
 
 static unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
@@ -999,7 +1006,7 @@ hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint3
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s) {
     if (n == 0) return hipSuccess;
     unsigned g = grid_for(n);
-    if (g > 2048) g = 2048;
+    if (g > 128) g = 128;
     hipLaunchKernelGGL(k_count_nonzero, dim3(g), dim3(256), 0, s, v, n, out);
     return hipGetLastError();
 }
