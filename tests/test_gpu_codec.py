@@ -101,6 +101,20 @@ def test_import_rejects_malformed_segment(ctx):
     with pytest.raises(II2Error):
         ctx.import_dv1(a.size, bad2, skip, payload)
     ctx.import_dv1(a.size, blk, skip, payload)      # the intact one is accepted
+    # block fill rule: every block but a list's last holds 256 postings (the merge places decoded blocks by it).
+    # Build a 3-block list by hand whose MIDDLE block is short: structurally fine, but refused.
+    def enc(ids):
+        gaps = np.diff(ids.astype(np.int64))
+        assert gaps.max() < 128
+        return gaps.astype(np.uint8).tobytes()
+    b0, b1, b2 = np.arange(0, 256), np.arange(1000, 1100), np.arange(5000, 5256)
+    pay = enc(b0) + enc(b1) + enc(b2)
+    sk = np.zeros(4, dtype=skip.dtype)
+    sk["first_doc"] = [0, 1000, 5000, 0]
+    sk["byte_off"] = [0, 255, 255 + 99, 255 + 99 + 255]
+    with pytest.raises(II2Error) as e:
+        ctx.import_dv1(256 + 100 + 256, np.array([0, 3], np.uint32), sk, np.frombuffer(pay, np.uint8))
+    assert e.value.code == -1
 
 
 def test_allgatherv_single_rank_is_a_copy(ctx):

@@ -152,3 +152,27 @@ def test_search_by_prefix_kat(ctx):
     assert ctx.union_host([[1], [1, 2]]).tolist() == [1, 2]
     assert ctx.union_host([[5], [6], [7]]).tolist() == [5, 6, 7]
     assert ctx.intersect_host([[1, 2, 3], [2, 3, 4]], removed=[3]).tolist() == [2]
+
+
+def test_bucket_fold_fallbacks_on_clustered_ids(ctx):
+    """The tile kernel folds runs with a bucket sort keyed on the doc id; ids clustered so that a bucket overflows
+    send the tile to the pairwise folds instead.  Batches of small terms and range tiles of a large term, with
+    duplicates across segments and tombstones inside the clusters."""
+    rng = np.random.default_rng(4242)
+    k, T = 8, 60
+    segs = []
+    for s in range(k):
+        lists = []
+        for t in range(T):
+            if t == 7:        # a large term: dense cluster + two far outliers in every segment
+                ids = np.concatenate([rng.choice(6000, 700, replace=False), [1_000_000_000 + s, 3_000_000_000 - s]])
+            else:             # small terms: ~60 ids inside a 100-doc window + one id far away
+                base = int(rng.integers(0, 1 << 20))
+                ids = np.concatenate([base + rng.choice(100, int(rng.integers(20, 70)), replace=False), [4_000_000_000 - t]])
+            lists.append(np.unique(ids).astype(np.uint32))
+        segs.append(lists)
+    removed = np.unique(np.concatenate([rng.integers(0, 6000, 500), (1 << 19) + rng.integers(0, 1 << 19, 2000)])).astype(np.uint32)
+    offs = [np.concatenate([[0], np.cumsum([x.size for x in lists])]).astype(np.uint64) for lists in segs]
+    vals = [np.concatenate(lists).astype(np.uint32) for lists in segs]
+    _check_merge(ctx, offs, vals, removed)
+    _check_merge(ctx, offs, vals, None)
