@@ -182,7 +182,9 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
 }
 
 // DEFER: work off the tiles the bitmap kernel (intersect_bm.hip) left behind instead of all tiles
-template <bool DEFER>
+// WIDE: 64 lists — 258 descriptor words per tile, two more than threads (kept out of the common instantiation:
+// the kernel sits at its register limit and even two extra loads cost 2.5 % there)
+template <bool DEFER, bool WIDE>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     __shared__ IsectSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
     // prime the pipeline: descriptors of the first tile, then its driver phase
     if ((uint32_t)tid < stride) sm.desc[0][tid] = p.ranges[(uint64_t)tile * stride + tid];
+    if (WIDE && (uint32_t)tid + 256u < stride) sm.desc[0][256u + tid] = p.ranges[(uint64_t)tile * stride + 256u + tid];
     __syncthreads();
     {
         const uint32_t *D = sm.desc[0];
@@ -255,6 +258,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 const Phase d = {D[2 + 4 * j], D[3 + 4 * j], D[4 + 4 * j], D[5 + 4 * j]};
                 const bool staged = can_stage(d);
                 if (j == n - 1u && has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
+                // 64 lists: 258 descriptor words, two more than threads — fetched here, latency exposed (rare)
+                if (WIDE && j == n - 1u && has_next && (uint32_t)tid + 256u < stride) sm.desc[(it + 1u) & 1u][256u + tid] = p.ranges[(uint64_t)next_tile * stride + 256u + tid];
                 if (staged) prefetch_commit(sm, pf, d, tid);
                 II2_STAMP(4)
                 lds_barrier();
@@ -386,6 +391,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 const Phase d = {D[2 + 4 * j], D[3 + 4 * j], D[4 + 4 * j], D[5 + 4 * j]};
                 const bool staged = can_stage(d);
                 if (j == n - 1u && has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
+                // 64 lists: 258 descriptor words, two more than threads — fetched here, latency exposed (rare)
+                if (WIDE && j == n - 1u && has_next && (uint32_t)tid + 256u < stride) sm.desc[(it + 1u) & 1u][256u + tid] = p.ranges[(uint64_t)next_tile * stride + 256u + tid];
                 if (staged) prefetch_commit(sm, pf, d, tid);
                 II2_STAMP(4)      // clear + commit (waits for the prefetched bytes)
                 lds_barrier();
@@ -634,6 +641,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             }
             // restart the pipeline for the next tile
             if (has_next && (uint32_t)tid < stride) sm.desc[(it + 1u) & 1u][tid] = dreg;
+            if (WIDE && has_next && (uint32_t)tid + 256u < stride) sm.desc[(it + 1u) & 1u][256u + tid] = p.ranges[(uint64_t)next_tile * stride + 256u + tid];
             __syncthreads();
             if (has_next) {
                 const uint32_t *DN = sm.desc[(it + 1u) & 1u];
@@ -752,10 +760,11 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             IntersectParams pd = p;                       // then the tiles it left behind (usually none: a small grid)
             pd.defer_mode = 1u;
             const uint32_t dgrid = p.n_tiles < p.defer_grid ? p.n_tiles : p.defer_grid;
-            hipLaunchKernelGGL(k_isect_tiles<true>, dim3(dgrid), dim3(256), 0, s, pd);
+            hipLaunchKernelGGL((k_isect_tiles<true, false>), dim3(dgrid), dim3(256), 0, s, pd);      // the bitmap kernel takes <= 4 lists
         } else {
             const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-            hipLaunchKernelGGL(k_isect_tiles<false>, dim3(grid), dim3(256), 0, s, p);
+            if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true>), dim3(grid), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_isect_tiles<false, false>), dim3(grid), dim3(256), 0, s, p);
         }
     }
     if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);

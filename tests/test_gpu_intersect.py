@@ -150,3 +150,12 @@ def test_bitmap_mode_gap_outliers(ctx):
     d = np.concatenate([np.arange(1, 200_000, 2), 200_000 + 127 * np.arange(1, 3000), 600_000 + np.arange(0, 200_000, 3)]).astype(np.uint32)
     _check(ctx, [d, np.arange(0, 800_001, 1, dtype=np.uint32)])
     _check(ctx, [np.arange(0, 800_001, 2, dtype=np.uint32), d])
+
+
+def test_sixty_four_lists(ctx):
+    """II2_MAX_LISTS terms in one conjunction (258 descriptor words per tile: more than one per thread)."""
+    rng = np.random.default_rng(64)
+    core = sorted_unique(rng, 5000, 300_000)
+    lists = [np.union1d(core, sorted_unique(rng, int(rng.integers(20_000, 60_000)), 300_000)).astype(np.uint32) for _ in range(64)]
+    _check(ctx, lists)
+    _check(ctx, lists[:63], removed=core[::7].copy())
