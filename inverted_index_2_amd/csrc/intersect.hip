@@ -184,11 +184,12 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
 // DEFER: work off the tiles the bitmap kernel (intersect_bm.hip) left behind instead of all tiles
 // WIDE: 64 lists — 258 descriptor words per tile, two more than threads (kept out of the common instantiation:
 // the kernel sits at its register limit and even two extra loads cost 2.5 % there)
-template <bool DEFER, bool WIDE>
+// NFIX: list count known at compile time (0 = read it from the parameters) — the two-term query is by far the most common
+template <bool DEFER, bool WIDE, uint32_t NFIX>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     __shared__ IsectSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
-    const uint32_t n = p.n_lists;
+    const uint32_t n = NFIX ? NFIX : p.n_lists;
     const bool shiftenc = n <= 8u;
     const uint32_t stride = desc_stride(n);
     Prefetch pf;
@@ -760,11 +761,12 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             IntersectParams pd = p;                       // then the tiles it left behind (usually none: a small grid)
             pd.defer_mode = 1u;
             const uint32_t dgrid = p.n_tiles < p.defer_grid ? p.n_tiles : p.defer_grid;
-            hipLaunchKernelGGL((k_isect_tiles<true, false>), dim3(dgrid), dim3(256), 0, s, pd);      // the bitmap kernel takes <= 4 lists
+            hipLaunchKernelGGL((k_isect_tiles<true, false, 0u>), dim3(dgrid), dim3(256), 0, s, pd);      // the bitmap kernel takes <= 4 lists
         } else {
             const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-            if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true>), dim3(grid), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((k_isect_tiles<false, false>), dim3(grid), dim3(256), 0, s, p);
+            if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u>), dim3(grid), dim3(256), 0, s, p);
+            else if (p.n_lists == 2u) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u>), dim3(grid), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_isect_tiles<false, false, 0u>), dim3(grid), dim3(256), 0, s, p);
         }
     }
     if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);
