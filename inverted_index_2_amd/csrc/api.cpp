@@ -649,6 +649,73 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     return II2_OK;
 }
 
+// Union of lists that are dense TOGETHER (>= 1 posting per 16 docs of their common range): the byte-map tiles of
+// the intersection with OR semantics over fixed doc ranges — no decode-to-raw, no fold, ~20x the merge path's rate.
+int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx, const ii2_tomb *tomb,
+                             uint32_t *d_out, uint64_t cap, uint64_t *d_count, bool *taken) {
+    *taken = false;
+    if (!ctx->opt_union_dense || n == 0 || n > MAX_LISTS) return II2_OK;
+    hipStream_t st = ctx->stream;
+    IntersectParams p;
+    std::memset(&p, 0, sizeof p);
+    uint32_t m = 0;
+    uint64_t total_blocks = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        ListView v;
+        int rc = make_list_view(ctx, segs[i], list_idx ? list_idx[i] : 0, &v);
+        if (rc) return rc;
+        if (v.nblk == 0) continue;
+        p.lists[m++] = v;
+        total_blocks += v.nblk;
+    }
+    if (m == 0 || total_blocks < 64) return II2_OK;
+    p.n_lists = m;
+    uint32_t *d_mm = (uint32_t *)(ctx->d_mail + 80);
+    uint32_t mm[2] = {0, 0};
+    HIP_TRY(ctx, launch_union_range(p, d_mm, st));
+    HIP_TRY(ctx, hipMemcpyAsync(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (mm[1] < mm[0]) return II2_OK;
+    constexpr uint32_t S = ISECT_SMAX - 64u;               // tile span: a multiple of 32 below the byte-map size
+    const uint32_t base = mm[0] & ~31u;
+    const uint64_t span = (uint64_t)mm[1] - base + 1;
+    if (total_blocks * II2_DV1_BLOCK * 16u < span) return II2_OK;       // too sparse: the merge passes do better
+    const uint64_t n_tiles = (span + S - 1) / S;
+    if (n_tiles >= (1ull << 24)) return II2_OK;
+    p.op_union = 1u;
+    p.u_base = base;
+    p.u_span = S;
+    p.u_max = mm[1];
+    p.n_tiles = (uint32_t)n_tiles;
+    const size_t dstride = 2 + 4 * (size_t)m;
+    p.desc_words = (uint32_t)dstride;
+    p.slot_words = ((ISECT_SMAX + 32u) / 32u + 3u) & ~3u;
+    size_t need = align_up((size_t)p.n_tiles * dstride * sizeof(uint32_t)) + align_up((size_t)p.n_tiles * p.slot_words * sizeof(uint32_t)) +
+                  2 * align_up(((size_t)p.n_tiles + 2) * sizeof(uint32_t)) + align_up(((size_t)p.n_tiles / 64 + 4) * sizeof(uint32_t)) + 4096;
+    int rc = ii2_ws_reserve(ctx, need);
+    if (rc) return rc;
+    p.ranges = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * dstride);
+    p.tmp = ws_take<uint32_t>(ctx, (size_t)p.n_tiles * p.slot_words);
+    p.tile_count = ws_take<uint32_t>(ctx, (size_t)p.n_tiles + 1);
+    p.n_sums1 = p.n_tiles / 64 + 1;
+    p.n_sums = p.n_sums1;
+    p.sums = ws_take<uint32_t>(ctx, p.n_sums);
+    p.defer = ws_take<uint32_t>(ctx, (size_t)p.n_tiles + 1);
+    p.n_defer = (uint32_t *)(ctx->d_mail + 96);
+    p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : 5u);
+    p.bitmap_mode = ctx->opt_intersect_bitmap ? 1u : 0u;
+    p.tomb = tomb ? tomb->d_words : nullptr;
+    p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+    p.out = d_out;
+    p.out_cap = cap;
+    p.d_count = d_count;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ii2_profile_pair(ctx, &e0, &e1);
+    HIP_TRY(ctx, launch_intersect(p, nullptr, st, e0, e1));
+    *taken = true;
+    return II2_OK;
+}
+
 extern "C" {
 
 int ii2_intersect_async(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
@@ -716,6 +783,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
     else if (k == "intersect.bm2") ctx->opt_intersect_bm2 = value;
+    else if (k == "union.dense") ctx->opt_union_dense = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

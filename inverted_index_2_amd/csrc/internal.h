@@ -33,6 +33,7 @@ struct ii2_ctx {
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
     size_t aux2_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
+    int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
     int64_t opt_intersect_bm2 = 0;      // 1: dense queries of <= 4 lists go to the bitmap tile kernel first (measured slower: off)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
@@ -79,6 +80,9 @@ struct ii2_tomb {
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);   // false when profiling is off
+// union through the intersection tiles (OR); *taken = false when the lists are too sparse for it (caller merges instead)
+int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx, const ii2_tomb *tomb,
+                             uint32_t *d_out, uint64_t cap, uint64_t *d_count, bool *taken);
 int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values,
                                 uint64_t n_postings, ii2_seg **out);
 int ii2_seg_decode_dev_unlocked(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *d_post_off, uint32_t *d_values);
@@ -134,6 +138,8 @@ struct IntersectParams {
     uint32_t bm2;                // 1: the bitmap kernel (intersect_bm.hip) runs first and defers what it cannot take
     uint32_t *defer;             // [n_tiles] tiles left by the bitmap kernel
     uint32_t *n_defer;           // their number (zeroed by the partition kernel)
+    uint32_t op_union;           // 1: OR instead of AND — fixed doc-range tiles [u_base + t * u_span, ...], every list searched per tile
+    uint32_t u_base, u_span, u_max;
     uint32_t bm2_grid, defer_grid;   // workgroups of the bitmap kernel / of the clean-up launch of k_isect_tiles
 };
 
@@ -173,6 +179,7 @@ constexpr uint32_t ISECTW_SMAX = 8192;      // docs a wave's byte map covers (wa
 constexpr uint32_t ISECTW_ABLK = 12;        // prefetched blocks per other list and mini-tile
 constexpr uint32_t ISECTW_MAXL = 4;         // lists the wave-level kernel handles
 hipError_t launch_intersect_wave(const IntersectParams &p, hipStream_t s);
+hipError_t launch_union_range(const IntersectParams &p, uint32_t *d_minmax, hipStream_t s);
 hipError_t launch_intersect_bm(const IntersectParams &p, uint32_t grid, hipStream_t s);
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 

@@ -89,6 +89,29 @@ __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
         if (gid < p.n_tiles) p.tile_count[gid] = 0;
         if (gid == 0) *p.n_defer = 0;
     }
+    if (p.op_union) {
+        // union: fixed doc-range tiles, one wave per (tile, list)
+        if (gw >= (uint64_t)p.n_tiles * n) return;
+        const uint32_t t = (uint32_t)(gw / n), j = (uint32_t)(gw % n);
+        const uint64_t lo64 = (uint64_t)p.u_base + (uint64_t)t * p.u_span;
+        uint64_t hi64 = lo64 + p.u_span - 1u;
+        if (hi64 > p.u_max) hi64 = p.u_max;
+        const uint32_t lo = (uint32_t)lo64, hi = (uint32_t)hi64;
+        uint32_t *r = p.ranges + (uint64_t)t * desc_stride(n);
+        if (j == 0u && lane_id() == 0) { r[0] = lo; r[1] = hi; }
+        const ListView L = p.lists[j];
+        uint32_t ub, bh;
+        wave_skip_upper_bound2(L.skip, L.nblk, lo, hi, ub, bh);
+        const uint32_t bl = ub ? ub - 1u : 0u;
+        if (bh < bl) bh = bl;
+        if (lane_id() == 0) {
+            r[2 + 4 * j] = bl;
+            r[3 + 4 * j] = bh;
+            r[4 + 4 * j] = L.skip[bl].byte_off;
+            r[5 + 4 * j] = L.skip[bh].byte_off;
+        }
+        return;
+    }
     // n - 1 waves per tile (one per non-driver list); the first of them also writes the driver's descriptor
     const uint32_t m = n > 1u ? n - 1u : 1u;
     if (gw >= (uint64_t)p.n_tiles * m) return;
@@ -185,12 +208,13 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
 // WIDE: 64 lists — 258 descriptor words per tile, two more than threads (kept out of the common instantiation:
 // the kernel sits at its register limit and even two extra loads cost 2.5 % there)
 // NFIX: list count known at compile time (0 = read it from the parameters) — the two-term query is by far the most common
-template <bool DEFER, bool WIDE, uint32_t NFIX>
+// UNION: ids of ANY list (every list marks like the driver, the finalise tests for a mark) — dense unions, host-selected
+template <bool DEFER, bool WIDE, uint32_t NFIX, bool UNION>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     __shared__ IsectSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t n = NFIX ? NFIX : p.n_lists;
-    const bool shiftenc = n <= 8u;
+    const bool shiftenc = UNION || n <= 8u;
     const uint32_t stride = desc_stride(n);
     Prefetch pf;
     pf.r0 = make_uint4(0, 0, 0, 0); pf.r1 = pf.r0; pf.sk.first_doc = 0; pf.sk.byte_off = 0;
@@ -363,7 +387,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             uint32_t mine = 0;
             for (uint32_t wi = (uint32_t)tid; wi < nwords; wi += 256u) {
                 uint32_t word = bmw[GU / 32u + wi];
-                for (uint32_t j = 1; j < n; j++) word &= bmw[j * bstride + GU / 32u + wi];
+                for (uint32_t j = 1; j < n; j++) word = UNION ? (word | bmw[j * bstride + GU / 32u + wi]) : (word & bmw[j * bstride + GU / 32u + wi]);
                 if (wi == nwords - 1u && (mspan & 31u) != 31u) word &= (2u << (mspan & 31u)) - 1u;
                 if (p.tomb) {
                     const uint32_t tw = (mlo >> 5) + wi;
@@ -408,12 +432,12 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 }
                 II2_STAMP(0)      // clear + commit + barrier + prefetch issue
                 const uint32_t nblk = d.bh - d.bl;
-                const uint8_t want = (uint8_t)j;
+                const uint8_t want = UNION ? (uint8_t)0 : (uint8_t)j;
                 // n <= 8 (shift code): the driver writes 1 << (8 - n) and every further list shifts the bytes it
                 // hits left by one, so a doc of all n lists ends at 0x80 and nothing else reaches bit 7 — no
                 // compare per posting and a one-AND test when the map is finalised.  n > 8: counting code
                 // (driver 1, list j turns j into j + 1).
-                const uint8_t s0 = shiftenc ? (uint8_t)(1u << (8u - n)) : (uint8_t)1;
+                const uint8_t s0 = UNION ? (uint8_t)0x80 : shiftenc ? (uint8_t)(1u << (8u - n)) : (uint8_t)1;
                 // driver: plain stores of 1.  list j: read the four candidate bytes, then bump the ones at j.
                 auto mark4 = [&](uint32_t, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
                     const uint32_t o0 = id0 - mlo, o1 = id1 - mlo, o2 = id2 - mlo, o3 = id3 - mlo;
@@ -659,6 +683,23 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
 #undef II2_STAMP
 }
 
+// smallest first doc / largest last doc of the lists of a union (one thread per list)
+__global__ void k_union_range(IntersectParams p, uint32_t *__restrict__ minmax) {
+    const uint32_t j = threadIdx.x;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+    if (j < p.n_lists) { mn = p.lists[j].skip[0].first_doc; mx = *p.lists[j].last_doc; }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t on = (uint32_t)__shfl_xor((int)mn, d, 64), ox = (uint32_t)__shfl_xor((int)mx, d, 64);
+        mn = on < mn ? on : mn;
+        mx = ox > mx ? ox : mx;
+    }
+    if (j == 0) { minmax[0] = mn; minmax[1] = mx; }
+}
+hipError_t launch_union_range(const IntersectParams &p, uint32_t *d_minmax, hipStream_t s) {
+    hipLaunchKernelGGL(k_union_range, dim3(1), dim3(64), 0, s, p, d_minmax);
+    return hipGetLastError();
+}
+
 // ---- per-64-tile sums of the tile counts (expand reads them to place its tiles) ------------
 // A kernel of its own: an atomicAdd per tile from the tile kernel put 64 same-address device atomics in flight
 // per sum at once, and every workgroup then waited for its own at its next s_waitcnt — ~20 us per pass.
@@ -719,9 +760,12 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
         const uint32_t mlo = r[0] & ~31u;
         const uint32_t nwords = ((r[1] - mlo) >> 5) + 1u;
         uint32_t done = 0;                       // ids written by earlier rounds
-        for (uint32_t w0 = 0; w0 < nwords; w0 += 256u) {
+        // words per round: an intersection tile holds at most GMAX * 256 ids in all; a union tile can be full,
+        // so its rounds cover no more docs than the staging buffer has slots
+        const uint32_t rw = p.op_union ? ISECT_GMAX * 256u / 32u : 256u;
+        for (uint32_t w0 = 0; w0 < nwords; w0 += rw) {
             const uint32_t wi = w0 + (uint32_t)tid;
-            uint32_t word = wi < nwords ? slot[wi] : 0u;
+            uint32_t word = ((uint32_t)tid < rw && wi < nwords) ? slot[wi] : 0u;
             const uint32_t pc = (uint32_t)__popc(word);
             const uint32_t incl = wave_incl_scan(pc);
             __syncthreads();                      // stage / wsum are free (previous round fully written out)
@@ -747,7 +791,7 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
 
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
-    const uint64_t nthr = (uint64_t)p.n_tiles * (p.n_lists > 1u ? p.n_lists - 1u : 1u);
+    const uint64_t nthr = (uint64_t)p.n_tiles * (p.op_union ? p.n_lists : p.n_lists > 1u ? p.n_lists - 1u : 1u);
     const uint64_t pthr = std::max<uint64_t>(std::max<uint64_t>(nthr * 64u, p.n_sums), p.n_tiles);
     if (ev0) (void)hipEventRecord(ev0, s);          // the events bracket the whole pass: partition + tiles + expand
     if (p.wave_mode) {
@@ -761,12 +805,14 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             IntersectParams pd = p;                       // then the tiles it left behind (usually none: a small grid)
             pd.defer_mode = 1u;
             const uint32_t dgrid = p.n_tiles < p.defer_grid ? p.n_tiles : p.defer_grid;
-            hipLaunchKernelGGL((k_isect_tiles<true, false, 0u>), dim3(dgrid), dim3(256), 0, s, pd);      // the bitmap kernel takes <= 4 lists
+            hipLaunchKernelGGL((k_isect_tiles<true, false, 0u, false>), dim3(dgrid), dim3(256), 0, s, pd);      // the bitmap kernel takes <= 4 lists
         } else {
             const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-            if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u>), dim3(grid), dim3(256), 0, s, p);
-            else if (p.n_lists == 2u) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u>), dim3(grid), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((k_isect_tiles<false, false, 0u>), dim3(grid), dim3(256), 0, s, p);
+            if (p.op_union && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, true>), dim3(grid), dim3(256), 0, s, p);
+            else if (p.op_union) hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, true>), dim3(grid), dim3(256), 0, s, p);
+            else if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false>), dim3(grid), dim3(256), 0, s, p);
+            else if (p.n_lists == 2u) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false>), dim3(grid), dim3(256), 0, s, p);
         }
     }
     if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);

@@ -290,6 +290,18 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
     }
     if (!any) { *count = 0; return II2_OK; }
     if (!d_out) return fail(ctx, II2_EINVAL, "ii2_union: output buffer is NULL");
+    {   // lists dense together: OR over byte-map tiles instead of the merge passes
+        bool taken = false;
+        int rc = ii2_union_dense_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, ctx->d_mail, &taken);
+        if (rc) return rc;
+        if (taken) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            *count = ctx->h_mail[0];
+            if (*count > cap) return fail(ctx, II2_ECAPACITY, "ii2_union: result does not fit the output buffer (content unspecified)");
+            return II2_OK;
+        }
+    }
     ii2_merge_stats st;
     std::memset(&st, 0, sizeof st);
     int rc = merge_core(ctx, n, views.data(), 1, tomb, nullptr, d_out, cap, &st);

@@ -176,3 +176,43 @@ def test_bucket_fold_fallbacks_on_clustered_ids(ctx):
     vals = [np.concatenate(lists).astype(np.uint32) for lists in segs]
     _check_merge(ctx, offs, vals, removed)
     _check_merge(ctx, offs, vals, None)
+
+
+def _check_union(ctx, lists, removed=None):
+    seg = ctx.encode_lists(lists)
+    tomb = ctx.tombstones(removed) if removed is not None else None
+    want = orc.union(lists)
+    if removed is not None:
+        want = orc.filter_removed(want, np.sort(removed))
+    for dense in (1, 0):       # byte-map tiles with OR (lists dense together) / the merge passes
+        ctx.set_option("union.dense", dense)
+        out, n = ctx.union([(seg, i) for i in range(len(lists))], tomb=tomb)
+        assert n == want.size and np.array_equal(out.download(n), want), dense
+    ctx.set_option("union.dense", 1)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 9, 64])
+def test_union_dense_path(ctx, k):
+    """Lists dense enough together for the OR tiles: ranges that start and end apart, an empty list among them,
+    ids at the ends of the id space, tombstones; both paths must give the reference's sort + compact."""
+    rng = np.random.default_rng(300 + k)
+    lists = []
+    for i in range(k):
+        lo = int(rng.integers(0, 200_000))
+        hi = lo + int(rng.integers(50_000, 600_000))
+        lists.append((lo + sorted_unique(rng, int(rng.integers(10_000, 90_000)), hi - lo)).astype(np.uint32))
+    if k >= 3:
+        lists[1] = np.empty(0, np.uint32)
+    _check_union(ctx, lists)
+    _check_union(ctx, lists, removed=rng.integers(0, 800_000, 30_000).astype(np.uint32))
+
+
+def test_union_dense_high_ids_and_sparse_fallback(ctx):
+    top = 0xFFFFFFFF
+    a = (top - np.arange(0, 300_000, 2, dtype=np.uint64)[::-1]).astype(np.uint32)       # dense run ending at 2^32 - 1
+    b = (top - np.arange(1, 300_000, 3, dtype=np.uint64)[::-1]).astype(np.uint32)
+    _check_union(ctx, [a, b])
+    rng = np.random.default_rng(5)
+    sparse = [sorted_unique(rng, 40_000, 1 << 31) for _ in range(3)]                       # far too sparse: merge path
+    _check_union(ctx, sparse)
+    _check_union(ctx, [a, sparse[0]])                                                       # dense run + ids spread over 2^31
