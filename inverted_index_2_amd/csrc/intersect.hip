@@ -153,11 +153,14 @@ constexpr uint32_t RAWCAP = 8192;     // staged payload bytes per phase (2 x uin
 constexpr uint32_t SKIPCAP = 256;     // staged skip entries per phase (1 per thread)
 constexpr uint32_t DESC_WORDS = 2u + 4u * MAX_LISTS;
 
-struct __align__(16) IsectSmem {
+// RAW: staged payload bytes per phase; DW: descriptor words per tile (both smaller in the two-list instantiation,
+// which then fits six workgroups per CU)
+template <uint32_t RAW, uint32_t DW>
+struct __align__(16) IsectSmemT {
     uint8_t map[MAP_BYTES];                  // byte map | gallop: cand[GMAX*256] u32 + hit[GMAX*256] u8
-    uint8_t raw[RAWCAP + 32];                // staged payload | gallop: 4 x 256 decoded block (one per wave)
+    uint8_t raw[RAW + 32];                   // staged payload | gallop: 4 x 256 decoded block (one per wave)
     ii2_skip skipbuf[SKIPCAP + 8];
-    uint32_t desc[2][DESC_WORDS];
+    uint32_t desc[2][DW];
     uint32_t wcnt[4];
     uint32_t ncand;
     uint32_t pad;
@@ -167,8 +170,9 @@ constexpr uint32_t GALLOP_SUB = 8;         // driver blocks the gallop path hand
 static_assert(GALLOP_SUB * 256u * 5u <= MAP_BYTES, "gallop candidates + flags must fit the byte map");
 
 struct Phase { uint32_t bl, bh, qlo, qhi; };
-__device__ __forceinline__ bool can_stage(const Phase &d) {
-    return d.bh > d.bl && d.bh - d.bl < SKIPCAP && d.qhi - (d.qlo & ~15u) <= RAWCAP;
+template <uint32_t RAW>
+__device__ __forceinline__ bool can_stage_t(const Phase &d) {
+    return d.bh > d.bl && d.bh - d.bl < SKIPCAP && d.qhi - (d.qlo & ~15u) <= RAW;
 }
 struct Prefetch { uint4 r0, r1; ii2_skip sk; };
 
@@ -183,7 +187,8 @@ __device__ __forceinline__ void prefetch_issue(Prefetch &pf, const Phase &d, con
     if ((uint32_t)tid + 256u < nch) pf.r1 = *reinterpret_cast<const uint4 *>(src + 16u * ((uint32_t)tid + 256u));
     if ((uint32_t)tid <= d.bh - d.bl) pf.sk = L.skip[d.bl + (uint32_t)tid];
 }
-__device__ __forceinline__ void prefetch_commit(IsectSmem &sm, const Prefetch &pf, const Phase &d, int tid) {
+template <class Smem>
+__device__ __forceinline__ void prefetch_commit(Smem &sm, const Prefetch &pf, const Phase &d, int tid) {
     const uint32_t base16 = d.qlo & ~15u;
     const uint32_t nch = (d.qhi - base16 + 15u) >> 4;
     if ((uint32_t)tid < nch) *reinterpret_cast<uint4 *>(&sm.raw[16u * (uint32_t)tid]) = pf.r0;
@@ -211,7 +216,10 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
 // UNION: ids of ANY list (every list marks like the driver, the finalise tests for a mark) — dense unions, host-selected
 template <bool DEFER, bool WIDE, uint32_t NFIX, bool UNION>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
-    __shared__ IsectSmem sm;
+    constexpr uint32_t RAW = NFIX == 2u ? 7680u : RAWCAP;
+    constexpr uint32_t DW = NFIX ? 2u + 4u * NFIX : DESC_WORDS;
+    __shared__ IsectSmemT<RAW, DW> sm;
+    auto can_stage = [](const Phase &d) { return can_stage_t<RAW>(d); };
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t n = NFIX ? NFIX : p.n_lists;
     const bool shiftenc = UNION || n <= 8u;
