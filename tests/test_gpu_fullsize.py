@@ -70,3 +70,23 @@ def test_config3_scaled_merge_properties(ctx):
     again, st2 = ctx.merge_to_segment([merged, merged])
     po, v = again.decode()
     assert np.array_equal(po, w_off) and np.array_equal(v, w_vals)
+
+
+def test_full_size_union_inclusion_exclusion(ctx):
+    # PrefixSearch dedupe (inverted_index.go:274-292) on the two config-2 lists: |A u B| = |A| + |B| - |A n B|, both
+    # union paths (OR tiles / merge passes) give numpy's union1d, tombstones = set difference
+    D = 100_000_000
+    a, b = synth.zipf_list(2, D), synth.zipf_list(3, D)
+    seg = ctx.encode_lists([a, b])
+    _, n_and = ctx.intersect([(seg, 0), (seg, 1)])
+    want = np.union1d(a, b)
+    out = ctx.empty(a.size + b.size + 8)
+    for dense in (1, 0):
+        ctx.set_option("union.dense", dense)
+        _, n = ctx.union([(seg, 0), (seg, 1)], out=out)
+        assert n == a.size + b.size - n_and == want.size
+        assert np.array_equal(out.download(n), want)
+    ctx.set_option("union.dense", 1)
+    removed = synth.geometric_postings(0.01, D, synth.term_seed(10**6))
+    _, n = ctx.union([(seg, 0), (seg, 1)], tomb=ctx.tombstones(removed), out=out)
+    assert np.array_equal(out.download(n), np.setdiff1d(want, removed, assume_unique=True))
