@@ -17,7 +17,7 @@ for lb in (1,):
     pass
     o, n = ctx.intersect([(seg, 0), (seg, 1)], out=out)
     got = out.download(n)
-    print("lookback", lb, "count", n, "match", n == want.size and np.array_equal(got, want), flush=True)
+    print("check", lb, "count", n, "match", n == want.size and np.array_equal(got, want), flush=True)
     for g in (0, 2, 4, 8):
         ctx.set_option("intersect.g", g)
         ctx.intersect_async([(seg, 0), (seg, 1)], None, out, dcnt); ctx.sync()
