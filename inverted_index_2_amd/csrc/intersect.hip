@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         const unsigned long long MM = (unsigned long long)M << (P & 31u);
                         uint32_t *dst = bmj + (P >> 5);
                         atomicOr(dst, (uint32_t)MM);
-                        atomicOr(dst + 1, (uint32_t)(MM >> 32));
+                        if ((uint32_t)(MM >> 32)) atomicOr(dst + 1, (uint32_t)(MM >> 32));     // LDS atomics cost per active lane
                     }
                     const bool slow = ok && !fast;
                     if (__ballot(slow) != 0ull) {
