@@ -340,7 +340,10 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         atomicOr(dst, (uint32_t)MM);
                         if ((uint32_t)(MM >> 32)) atomicOr(dst + 1, (uint32_t)(MM >> 32));     // LDS atomics cost per active lane
                     }
-                    const bool slow = ok && !fast;
+                    // lanes with a wide group walk their postings one by one if they can reach the tile's range — also a lane
+                    // that STARTS more than the guard below the range (not ok) and jumps into it; a lane of narrow groups
+                    // spans < 128 docs, so one that is not ok lies wholly outside
+                    const bool slow = rv && smax > 31u && (ok || (u + (ss[0] + ss[1] + ss[2] + ss[3])) < u);   // second case: the sum wrapped past 2^32
                     if (__ballot(slow) != 0ull) {
                         uint32_t pp = u;
 #pragma unroll

@@ -159,3 +159,17 @@ def test_sixty_four_lists(ctx):
     lists = [np.union1d(core, sorted_unique(rng, int(rng.integers(20_000, 60_000)), 300_000)).astype(np.uint32) for _ in range(64)]
     _check(ctx, lists)
     _check(ctx, lists[:63], removed=core[::7].copy())
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bitmap_mode_lane_jumping_into_range(ctx, seed):
+    """Regression (found by scripts/stress.py): in bitmap mode a lane of a non-driver list that starts more than the
+    128-doc guard below a tile's range but reaches into it through a wide gap (one-byte gaps up to 127, so 16 postings
+    can span 2000 docs) must still mark its postings.  Dense lists with a sprinkling of wide gaps, many tiles."""
+    rng = np.random.default_rng(4100 + seed)
+    # ~2.9 docs per posting (dense enough for bitmap tiles), 1.5 % gaps of 110..127: ~3 % of the lanes span > 128 docs
+    gaps = [1, 2, 110, 127]
+    probs = [.6, .385, .0075, .0075]
+    lists = [_gap_list(rng, 1_000_000, gaps, probs, start=int(rng.integers(0, 1000))) for _ in range(2 + seed % 2)]
+    _check(ctx, lists)
+    _check(ctx, lists, removed=lists[0][::11].copy())
