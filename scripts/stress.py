@@ -21,6 +21,10 @@ def rand_list(n, universe, style):
         gaps = rng.choice([1, 2, 3, 4, 9, 31, 32, 33, 127, 128, 300, 20000], size=n, p=[.3, .25, .2, .1, .05, .02, .02, .02, .01, .01, .01, .01])
         v = int(rng.integers(0, max(1, universe // 4))) + np.cumsum(gaps)
         return np.unique(v[v < universe]).astype(np.uint32)
+    if style == 2:      # very dense (bitmap tiles) with rare wide one-byte gaps
+        gaps = rng.choice([1, 2, 3, 110, 127], size=n, p=[.55, .33, .105, .0075, .0075])
+        v = int(rng.integers(0, max(1, universe // 8))) + np.cumsum(gaps)
+        return np.unique(v[v < universe]).astype(np.uint32)
     # clustered
     centers = rng.integers(0, universe, max(1, n // 500), dtype=np.uint64)
     v = (centers[rng.integers(0, centers.size, n)] + rng.integers(0, 2000, n, dtype=np.uint64)) % universe
@@ -33,8 +37,8 @@ while time.time() < t_end:
     it += 1
     universe = int(rng.choice([5_000, 200_000, 5_000_000, 1 << 31, (1 << 32) - 1]))
     k = int(rng.choice([1, 2, 2, 3, 4, 7, 8, 9, 20, 64]))
-    sizes = [int(rng.choice([0, 1, 255, 256, 257, 3000, 40_000, 300_000])) for _ in range(k)]
-    lists = [rand_list(min(s, universe), universe, int(rng.integers(0, 3))) for s in sizes]
+    sizes = [int(rng.choice([0, 1, 255, 256, 257, 3000, 40_000, 300_000, 1_000_000], p=[.05, .05, .05, .1, .05, .2, .2, .2, .1])) for _ in range(k)]
+    lists = [rand_list(min(s, universe), universe, int(rng.integers(0, 4))) for s in sizes]
     removed = None
     if rng.random() < 0.5:
         removed = np.unique(rng.integers(0, universe, int(rng.integers(1, 5000)), dtype=np.uint64)).astype(np.uint32)
