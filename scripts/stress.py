@@ -45,6 +45,17 @@ while time.time() < t_end:
     tomb = ctx.tombstones(removed) if removed is not None else None
     seg = ctx.encode_lists(lists)
     ref_rm = removed if removed is not None else ()
+    # codec: decode == input, byte-exact with the oracle's encoder, export -> import -> intersect gives the same
+    po_w = np.concatenate([[0], np.cumsum([l.size for l in lists])]).astype(np.uint64)
+    flat = np.concatenate(lists + [np.empty(0, np.uint32)]).astype(np.uint32)
+    po_g, vals_g = seg.decode()
+    blk, skip, payload = seg.export()
+    o_blk, o_skip, o_payload = orc.dv1_encode(po_w, flat)
+    if not (np.array_equal(po_g, po_w) and np.array_equal(vals_g, flat) and np.array_equal(blk, o_blk) and np.array_equal(payload, o_payload)
+            and np.array_equal(skip["first_doc"][:-1], o_skip["first_doc"][:-1]) and np.array_equal(skip["byte_off"], o_skip["byte_off"])):
+        print("MISMATCH codec", it, "seed", seed, "k", k, "universe", universe, "sizes", [l.size for l in lists]); sys.exit(1)
+    if it % 5 == 0:
+        seg = ctx.import_dv1(int(flat.size), blk, skip, payload)       # the imported copy serves the rest of the iteration
     # intersect (all option combinations that change the kernel path)
     want = orc.intersect(lists, ref_rm)
     for bm, bm2 in ((1, 0), (0, 0), (1, 1)):
