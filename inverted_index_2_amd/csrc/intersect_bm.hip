@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256) void k_isect_bm(IntersectParams p) {
                     // lanes with a wide group walk their postings one by one if they can reach the tile's range — also a lane
                     // that STARTS more than the guard below the range (not ok) and jumps into it; a lane of narrow groups
                     // spans < 128 docs, so one that is not ok lies wholly outside
-                    const bool slow = rv && smax > 31u && (ok || (uu + (ss[0] + ss[1] + ss[2] + ss[3])) < uu);   // second case: the sum wrapped past 2^32
-                    if (__ballot(slow) != 0ull) {
+                    if (__ballot(rv && smax > 31u) != 0ull) {          // rare: the test for reaching the range is only made here
+                        const bool slow = rv && smax > 31u && (ok || (uu + (ss[0] + ss[1] + ss[2] + ss[3])) < uu);   // second case: the sum wrapped past 2^32
                         uint32_t pp = uu;
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
