@@ -773,11 +773,13 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
         uint32_t done = 0;                       // ids written by earlier rounds
         // words per round: an intersection tile holds at most GMAX * 256 ids in all; a union tile can be full,
         // so its rounds cover no more docs than the staging buffer has slots
-        const uint32_t rw = p.op_union ? ISECT_GMAX * 256u / 32u : 256u;
+        const uint32_t rw = p.op_union ? ISECT_GMAX * 256u / 32u : 512u;       // two consecutive words per thread
         for (uint32_t w0 = 0; w0 < nwords; w0 += rw) {
-            const uint32_t wi = w0 + (uint32_t)tid;
-            uint32_t word = ((uint32_t)tid < rw && wi < nwords) ? slot[wi] : 0u;
-            const uint32_t pc = (uint32_t)__popc(word);
+            const uint32_t wi = w0 + 2u * (uint32_t)tid;
+            const bool mine = 2u * (uint32_t)tid < rw;
+            uint32_t wordA = (mine && wi < nwords) ? slot[wi] : 0u;
+            uint32_t wordB = (mine && wi + 1u < nwords) ? slot[wi + 1u] : 0u;
+            const uint32_t pc = (uint32_t)__popc(wordA) + (uint32_t)__popc(wordB);
             const uint32_t incl = wave_incl_scan(pc);
             __syncthreads();                      // stage / wsum are free (previous round fully written out)
             if (l == 63) wsum[wv] = incl;
@@ -785,11 +787,17 @@ __global__ __launch_bounds__(256) void k_isect_expand(IntersectParams p) {
             uint32_t pre = 0, tot = 0;
             for (int w = 0; w < 4; w++) { if (w < wv) pre += wsum[w]; tot += wsum[w]; }
             uint32_t q = pre + incl - pc;
-            const uint32_t basedoc = mlo + 32u * wi;
-            while (word) {
-                const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+            uint32_t basedoc = mlo + 32u * wi;
+            while (wordA) {
+                const uint32_t bit = (uint32_t)__ffs((int)wordA) - 1u;
                 stage[q++] = basedoc + bit;
-                word &= word - 1u;
+                wordA &= wordA - 1u;
+            }
+            basedoc += 32u;
+            while (wordB) {
+                const uint32_t bit = (uint32_t)__ffs((int)wordB) - 1u;
+                stage[q++] = basedoc + bit;
+                wordB &= wordB - 1u;
             }
             __syncthreads();
             for (uint32_t i = (uint32_t)tid; i < tot; i += 256u)
