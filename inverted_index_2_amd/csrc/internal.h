@@ -33,6 +33,7 @@ struct ii2_ctx {
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
     size_t aux2_cap = 0;
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
+    int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
     int64_t opt_intersect_bm2 = 0;      // 1: dense queries of <= 4 lists go to the bitmap tile kernel first (measured slower: off)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
@@ -138,6 +139,7 @@ struct IntersectParams {
     uint32_t bm2;                // 1: the bitmap kernel (intersect_bm.hip) runs first and defers what it cannot take
     uint32_t *defer;             // [n_tiles] tiles left by the bitmap kernel
     uint32_t *n_defer;           // their number (zeroed by the partition kernel)
+    uint32_t map_docs_per_block; // tiles with more docs per driver block than this take the gallop path (option intersect.map_docs)
     uint32_t op_union;           // 1: OR instead of AND — fixed doc-range tiles [u_base + t * u_span, ...], every list searched per tile
     uint32_t u_base, u_span, u_max;
     uint32_t bm2_grid, defer_grid;   // workgroups of the bitmap kernel / of the clean-up launch of k_isect_tiles

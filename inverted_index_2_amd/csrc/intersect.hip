@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     constexpr uint32_t DW = NFIX ? 2u + 4u * NFIX : DESC_WORDS;
     __shared__ IsectSmemT<RAW, DW> sm;
     auto can_stage = [](const Phase &d) { return can_stage_t<RAW>(d); };
+    // byte/bit map tiles pay per DOC of the tile's range (clear + finalise), the gallop path per driver posting: sparse
+    // tiles (many docs per driver block) gallop even when their range would fit the map
+    const uint32_t map_docs_per_block = p.map_docs_per_block < (1u << 27) ? p.map_docs_per_block : (1u << 27);
+    auto use_map = [&](const uint32_t *DD) { return DD[1] - DD[0] < ISECT_SMAX && (UNION || DD[1] - DD[0] < map_docs_per_block * (DD[3] - DD[2])); };   // (G <= 16 blocks: no overflow below 2^28 docs per block)
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t n = NFIX ? NFIX : p.n_lists;
     const bool shiftenc = UNION || n <= 8u;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     {
         const uint32_t *D = sm.desc[0];
         const Phase d0 = {D[2], D[3], D[4], D[5]};
-        if (D[1] - D[0] < ISECT_SMAX && can_stage(d0)) prefetch_issue(pf, d0, p.lists[0], tid);
+        if (use_map(D) && can_stage(d0)) prefetch_issue(pf, d0, p.lists[0], tid);
     }
 
     for (uint32_t it = 0; item < n_items; it++) {
@@ -270,7 +274,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
         // BITMAP per list instead of the byte map: a lane turns four gap bytes into a 32-bit mask in registers
         // ((M << gap) | 1, one instruction per posting) and ORs it into its list's bitmap with two LDS atomics per
         // four postings; the result is the AND of the bitmaps.  Purely a fast path: any block is still decoded right.
-        bool bm = span < ISECT_SMAX && n <= BM_MAXL && p.bitmap_mode != 0u;
+        const bool mapped = use_map(D);
+        bool bm = mapped && n <= BM_MAXL && p.bitmap_mode != 0u;
         for (uint32_t j = 0; j < n && bm; j++) {
             const uint32_t nb = D[3 + 4 * j] - D[2 + 4 * j], bytes = D[5 + 4 * j] - D[4 + 4 * j];
             bm = nb > 0u && bytes == 255u * nb && (uint64_t)bytes * 13u >= (uint64_t)span * 4u;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 } else if (has_next) {
                     const uint32_t *DN = sm.desc[(it + 1u) & 1u];
                     const Phase dn = {DN[2], DN[3], DN[4], DN[5]};
-                    if (DN[1] - DN[0] < ISECT_SMAX && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
+                    if (use_map(DN) && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
                 }
                 II2_STAMP(0)
                 const uint32_t nblk = d.bh - d.bl;
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 p.tile_count[tile] = c;
             }
             II2_STAMP(3)
-        } else if (span < ISECT_SMAX) {
+        } else if (mapped) {
             // ================= byte-map path =================
             const uint32_t mlo = lo & ~31u;                  // map origin: 32-doc aligned
             const uint32_t mspan = hi - mlo;                 // last valid map offset
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 } else if (has_next) {
                     const uint32_t *DN = sm.desc[(it + 1u) & 1u];
                     const Phase dn = {DN[2], DN[3], DN[4], DN[5]};
-                    if (DN[1] - DN[0] < ISECT_SMAX && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
+                    if (use_map(DN) && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
                 }
                 II2_STAMP(0)      // clear + commit + barrier + prefetch issue
                 const uint32_t nblk = d.bh - d.bl;
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             if (has_next) {
                 const uint32_t *DN = sm.desc[(it + 1u) & 1u];
                 const Phase dn = {DN[2], DN[3], DN[4], DN[5]};
-                if (DN[1] - DN[0] < ISECT_SMAX && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
+                if (use_map(DN) && can_stage(dn)) prefetch_issue(pf, dn, drv, tid);
             }
         }
         lds_barrier();        // map / wcnt are reused by the next tile
