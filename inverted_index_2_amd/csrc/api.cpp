@@ -598,10 +598,18 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         if (gb < 4u) bm2 = false;
         else if (gb < G) G = gb;
     }
+    // a tiny sparse driver (a rare term against long lists) would keep only a handful of workgroups busy, each decoding
+    // one block of the long list per candidate, one after the other: split its blocks over several tiles
+    uint32_t sub = 1;
+    if (!wave && !bm2 && n >= 2 && G == 1 && (per_block_span >= 8192.0 || (nblk0 == 1 && views[n - 1].nblk >= 64)) && ctx->opt_intersect_g <= 0) {
+        const uint32_t want_tiles = 4u * (uint32_t)ctx->cu_count;
+        if (nblk0 < want_tiles) sub = std::min<uint32_t>(16u, (want_tiles + nblk0 - 1u) / nblk0);
+    }
     p.G = G;
+    p.sub = sub;
     p.bm2 = bm2 ? 1u : 0u;
     p.wave_mode = wave ? 1u : 0u;
-    p.n_tiles = (nblk0 + G - 1) / G;
+    p.n_tiles = ((nblk0 + G - 1) / G) * sub;
     const size_t dstride = wave ? (16 + 40 * ((size_t)n - 1)) : (2 + 4 * (size_t)n);
     p.desc_words = (uint32_t)dstride;
     uint32_t slot_words = wave ? (ISECTW_SMAX + 32u) / 32u : (ISECT_SMAX + 32u) / 32u;
@@ -686,6 +694,7 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
     const uint64_t n_tiles = (span + S - 1) / S;
     if (n_tiles >= (1ull << 24)) return II2_OK;
     p.op_union = 1u;
+    p.sub = 1u;
     p.u_base = base;
     p.u_span = S;
     p.u_max = mm[1];

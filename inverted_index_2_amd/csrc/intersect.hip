@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
     if (gw >= (uint64_t)p.n_tiles * m) return;
     const uint32_t t = (uint32_t)(gw / m), j = (uint32_t)(gw % m) + 1u;
     const ListView d = p.lists[0];
-    const uint32_t b0 = t * p.G;
+    const uint32_t b0 = (p.sub > 1u ? t / p.sub : t) * p.G;   // sub > 1 (tiny drivers, G = 1): several tiles share a driver block
     const uint32_t b1 = b0 + p.G < d.nblk ? b0 + p.G : d.nblk;
     const uint32_t lo = d.skip[b0].first_doc;
     const uint32_t hi = b1 < d.nblk ? d.skip[b1].first_doc - 1u : *d.last_doc;
@@ -214,7 +214,8 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
 // the kernel sits at its register limit and even two extra loads cost 2.5 % there)
 // NFIX: list count known at compile time (0 = read it from the parameters) — the two-term query is by far the most common
 // UNION: ids of ANY list (every list marks like the driver, the finalise tests for a mark) — dense unions, host-selected
-template <bool DEFER, bool WIDE, uint32_t NFIX, bool UNION>
+// SUBT: driver blocks are split over several tiles (p.sub > 1; gallop only)
+template <bool DEFER, bool WIDE, uint32_t NFIX, bool UNION, bool SUBT = false>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     constexpr uint32_t RAW = NFIX == 2u ? 7680u : RAWCAP;
     constexpr uint32_t DW = NFIX ? 2u + 4u * NFIX : DESC_WORDS;
@@ -223,7 +224,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     // byte/bit map tiles pay per DOC of the tile's range (clear + finalise), the gallop path per driver posting: sparse
     // tiles (many docs per driver block) gallop even when their range would fit the map
     const uint32_t map_docs_per_block = p.map_docs_per_block < (1u << 27) ? p.map_docs_per_block : (1u << 27);
-    auto use_map = [&](const uint32_t *DD) { return DD[1] - DD[0] < ISECT_SMAX && (UNION || DD[1] - DD[0] < map_docs_per_block * (DD[3] - DD[2])); };   // (G <= 16 blocks: no overflow below 2^28 docs per block)
+    constexpr bool whole_blocks = !SUBT;
+    auto use_map = [&](const uint32_t *DD) { return whole_blocks && DD[1] - DD[0] < ISECT_SMAX && (UNION || DD[1] - DD[0] < map_docs_per_block * (DD[3] - DD[2])); };   // (G <= 16 blocks: no overflow below 2^28 docs per block)
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t n = NFIX ? NFIX : p.n_lists;
     const bool shiftenc = UNION || n <= 8u;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
         // BITMAP per list instead of the byte map: a lane turns four gap bytes into a 32-bit mask in registers
         // ((M << gap) | 1, one instruction per posting) and ORs it into its list's bitmap with two LDS atomics per
         // four postings; the result is the AND of the bitmaps.  Purely a fast path: any block is still decoded right.
-        const bool mapped = use_map(D);
+        const bool mapped = use_map(D);          // (use_map is false for every tile when driver blocks are split: p.sub > 1)
         bool bm = mapped && n <= BM_MAXL && p.bitmap_mode != 0u;
         for (uint32_t j = 0; j < n && bm; j++) {
             const uint32_t nb = D[3 + 4 * j] - D[2 + 4 * j], bytes = D[5 + 4 * j] - D[4 + 4 * j];
@@ -611,6 +613,14 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 }
                 __syncthreads();
                 const uint32_t ncand = sm.ncand;
+                if (SUBT) {
+                    // this tile owns one slice of its (single) driver block: the other candidates are dead from the start
+                    const uint32_t si = tile % p.sub;
+                    const uint32_t c0 = (uint32_t)(((uint64_t)ncand * si) / p.sub), c1 = (uint32_t)(((uint64_t)ncand * (si + 1u)) / p.sub);
+                    for (uint32_t pi = (uint32_t)tid; pi < ncand; pi += 256u)
+                        if (pi < c0 || pi >= c1) hit[pi] = 0;
+                    __syncthreads();
+                }
                 for (uint32_t j = 1; j < n; j++) {
                     const ListView L = p.lists[j];
                     const uint32_t bl = D[2 + 4 * j], bh = D[3 + 4 * j];
@@ -834,6 +844,8 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
             if (p.op_union && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, true>), dim3(grid), dim3(256), 0, s, p);
             else if (p.op_union) hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, true>), dim3(grid), dim3(256), 0, s, p);
+            else if (p.sub > 1u && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
+            else if (p.sub > 1u) hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
             else if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false>), dim3(grid), dim3(256), 0, s, p);
             else if (p.n_lists == 2u) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
             else hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false>), dim3(grid), dim3(256), 0, s, p);

@@ -173,3 +173,16 @@ def test_bitmap_mode_lane_jumping_into_range(ctx, seed):
     lists = [_gap_list(rng, 1_000_000, gaps, probs, start=int(rng.integers(0, 1000))) for _ in range(2 + seed % 2)]
     _check(ctx, lists)
     _check(ctx, lists, removed=lists[0][::11].copy())
+
+
+@pytest.mark.parametrize("n_rare", [3, 200, 256, 257, 700])
+def test_rare_term_against_long_lists(ctx, n_rare):
+    """A tiny sparse driver (one to three blocks) against long lists: its blocks are split over several tiles so that
+    more than a handful of workgroups decode the long lists' blocks (sub-block tiles, gallop path)."""
+    rng = np.random.default_rng(7000 + n_rare)
+    U = 40_000_000
+    long1 = _gap_list(rng, 2_000_000, [1, 5, 20, 60], [.25, .25, .25, .25])
+    long2 = sorted_unique(rng, 900_000, U)
+    rare = np.union1d(sorted_unique(rng, n_rare, U), rng.choice(np.intersect1d(long1, long2), min(n_rare, 40), replace=False)).astype(np.uint32)
+    _check(ctx, [rare, long1])
+    _check(ctx, [long2, rare, long1], removed=rare[::3].copy())
