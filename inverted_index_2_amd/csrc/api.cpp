@@ -606,6 +606,8 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         if (nblk0 < want_tiles) sub = std::min<uint32_t>(16u, (want_tiles + nblk0 - 1u) / nblk0);
     }
     p.G = G;
+    // the pipelined gallop pays when a driver block faces many blocks of a long list (candidates then hit distinct blocks)
+    p.sparse_driver = ((per_block_span >= 8192.0 && views[n - 1].nblk / 16u >= nblk0) || sub > 1) ? 1u : 0u;
     p.sub = sub;
     p.bm2 = bm2 ? 1u : 0u;
     p.wave_mode = wave ? 1u : 0u;

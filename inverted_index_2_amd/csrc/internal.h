@@ -118,6 +118,7 @@ struct IntersectParams {
     ListView lists[MAX_LISTS];   // lists[0] is the driver (fewest blocks)
     uint32_t n_lists;
     uint32_t G;                  // driver blocks per tile
+    uint32_t sparse_driver;      // host hint: most tiles will gallop (picks the kernel instantiation with the pipelined gallop)
     uint32_t sub;                // tiles per driver block (1; > 1 only with G == 1: tiny drivers are spread over more workgroups)
     uint32_t n_tiles;
     uint32_t tomb_nwords;

@@ -209,6 +209,30 @@ __device__ __forceinline__ uint32_t bytes_msb_mask(uint32_t w) {
     return ((((w & 0x80808080u) >> 7) * 0x00204081u) >> 21) & 0xFu;
 }
 
+// ---- gallop helpers: one block of a long list held in registers (up to 5 x 256 payload bytes, 4 per lane) -------
+struct GallopBlock { uint32_t cur, q0, q1, first; uint32_t w[5]; };
+struct RegBytes5 {
+    uint32_t w0, w1, w2, w3, w4, q0;
+    __device__ __forceinline__ uint32_t operator()(uint32_t myq) const {      // myq = q0 + 256 k + 4 lane
+        const uint32_t k = (myq - q0) >> 8;                                   // wave-uniform
+        return k == 0u ? w0 : k == 1u ? w1 : k == 2u ? w2 : k == 3u ? w3 : w4;
+    }
+};
+// fetch the payload of lane `leader`'s block (its skip entries are already in ea / eb of that lane)
+__device__ __forceinline__ void gallop_fetch(GallopBlock &g, const uint8_t *__restrict__ payload, uint32_t blk, const ii2_skip &ea,
+                                             const ii2_skip &eb, int leader) {
+    g.cur = wave_bcast(blk, leader);
+    g.q0 = wave_bcast(ea.byte_off, leader);
+    g.q1 = wave_bcast(eb.byte_off, leader);
+    g.first = wave_bcast(ea.first_doc, leader);
+    const uint32_t l4 = 4u * (uint32_t)lane_id();
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const uint32_t q = g.q0 + 256u * (uint32_t)k + l4;
+        g.w[k] = q < g.q1 ? load_u32_unaligned(payload + q) : 0u;
+    }
+}
+
 // DEFER: work off the tiles the bitmap kernel (intersect_bm.hip) left behind instead of all tiles
 // WIDE: 64 lists — 258 descriptor words per tile, two more than threads (kept out of the common instantiation:
 // the kernel sits at its register limit and even two extra loads cost 2.5 % there)
@@ -633,6 +657,41 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                             const uint32_t ub = skip_upper_bound(L.skip, bl, bh, c);
                             if (ub > bl) blk = ub - 1u;
                         }
+                        if (NFIX == 0u && bh - bl >= 16u) {       // many blocks in range: candidates mostly hit distinct ones
+                        // Every live lane fetches the skip entries of ITS block at once (one round trip for the wave instead of
+                        // one per block), and the payload of the next distinct block is in flight while the current one is
+                        // decoded out of registers: a random HBM access costs ~2 us, a block decode a fraction of that.
+                        ii2_skip ea = {0u, 0u}, eb = {0u, 0u};
+                        if (blk != NONE) { ea = L.skip[blk]; eb = L.skip[blk + 1u]; }
+                        unsigned long long pending = __ballot(blk != NONE);
+                        GallopBlock cb, nb;
+                        cb.cur = NONE;
+                        if (pending) gallop_fetch(cb, L.payload, blk, ea, eb, __ffsll((long long)pending) - 1);
+                        while (pending) {
+                            const unsigned long long rest = pending & ~__ballot(blk == cb.cur);
+                            nb.cur = NONE;
+                            if (rest) gallop_fetch(nb, L.payload, blk, ea, eb, __ffsll((long long)rest) - 1);
+                            const uint32_t cnt = decode_block_wave4(RegBytes5{cb.w[0], cb.w[1], cb.w[2], cb.w[3], cb.w[4], cb.q0}, cb.q0, cb.q1, cb.first,
+                                                                    [&](uint32_t ix, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                                                                        if (mask & 1u) { wbuf[ix] = id0; ix++; }
+                                                                        if (mask & 2u) { wbuf[ix] = id1; ix++; }
+                                                                        if (mask & 4u) { wbuf[ix] = id2; ix++; }
+                                                                        if (mask & 8u) { wbuf[ix] = id3; ix++; }
+                                                                    });
+                            __threadfence_block();
+                            if (blk == cb.cur) {
+                                uint32_t a = 0, e = cnt;
+                                while (a < e) {
+                                    const uint32_t mid = (a + e) >> 1;
+                                    if (wbuf[mid] < c) a = mid + 1u; else e = mid;
+                                }
+                                if (a < cnt && wbuf[a] == c) hit[pi] = (uint8_t)(j + 1u);
+                            }
+                            __threadfence_block();
+                            pending = rest;
+                            cb = nb;
+                        }
+                        } else {       // the dense two-list instantiation keeps the plain loop: it sits at its register limit
                         unsigned long long pending = __ballot(blk != NONE);
                         while (pending) {
                             const int leader = __ffsll((long long)pending) - 1;
@@ -651,6 +710,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                             }
                             __threadfence_block();
                             pending &= ~__ballot(blk == cur);
+                        }
                         }
                     }
                     __syncthreads();
@@ -847,7 +907,7 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
             else if (p.sub > 1u && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
             else if (p.sub > 1u) hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
             else if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false>), dim3(grid), dim3(256), 0, s, p);
-            else if (p.n_lists == 2u) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
+            else if (p.n_lists == 2u && !p.sparse_driver) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
             else hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false>), dim3(grid), dim3(256), 0, s, p);
         }
     }
