@@ -621,6 +621,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             // ================= gallop path =================
             uint32_t *cand = reinterpret_cast<uint32_t *>(sm.map);
             uint8_t *hit = sm.map + GALLOP_SUB * 256u * 4u;
+            uint32_t *fd = reinterpret_cast<uint32_t *>(sm.map + GALLOP_SUB * 256u * 5u);      // rest of the map: staged first docs
+            constexpr uint32_t FDCAP = (MAP_BYTES - GALLOP_SUB * 256u * 5u) / 4u;
             uint32_t *wbuf = reinterpret_cast<uint32_t *>(sm.raw) + (uint32_t)wv * 256u;
             uint32_t total = 0;
             for (uint32_t b0 = D[2]; b0 < D[3]; b0 += GALLOP_SUB) {
@@ -648,13 +650,25 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 for (uint32_t j = 1; j < n; j++) {
                     const ListView L = p.lists[j];
                     const uint32_t bl = D[2 + 4 * j], bh = D[3 + 4 * j];
+                    // the first docs of the blocks in range go to LDS in one coalesced fetch: a candidate's binary search
+                    // then costs LDS latency per step instead of an HBM round trip (~2 us) per step
+                    const bool fd_staged = bh > bl && bh - bl <= FDCAP;
+                    if (fd_staged) {
+                        for (uint32_t i = (uint32_t)tid; i < bh - bl; i += 256u) fd[i] = L.skip[bl + i].first_doc;
+                        __syncthreads();
+                    }
                     for (uint32_t base = (uint32_t)wv * 64u; base < ncand; base += 256u) {
                         const uint32_t pi = base + (uint32_t)l;
                         const bool alive = pi < ncand && hit[pi] == (uint8_t)j;
                         const uint32_t c = alive ? cand[pi] : 0u;
                         uint32_t blk = NONE;
                         if (alive && bl < bh) {
-                            const uint32_t ub = skip_upper_bound(L.skip, bl, bh, c);
+                            uint32_t ub;
+                            if (fd_staged) {
+                                uint32_t a = 0, e = bh - bl;
+                                while (a < e) { const uint32_t mid = a + ((e - a) >> 1); if (fd[mid] <= c) a = mid + 1u; else e = mid; }
+                                ub = bl + a;
+                            } else ub = skip_upper_bound(L.skip, bl, bh, c);
                             if (ub > bl) blk = ub - 1u;
                         }
                         if (NFIX == 0u && bh - bl >= 16u) {       // many blocks in range: candidates mostly hit distinct ones
