@@ -657,8 +657,10 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         for (uint32_t i = (uint32_t)tid; i < bh - bl; i += 256u) fd[i] = L.skip[bl + i].first_doc;
                         __syncthreads();
                     }
-                    for (uint32_t base = (uint32_t)wv * 64u; base < ncand; base += 256u) {
-                        const uint32_t pi = base + (uint32_t)l;
+                    // split driver blocks leave a run of consecutive candidates alive: deal them out to the four waves
+                    // candidate by candidate, or one wave would decode all their blocks one after the other
+                    for (uint32_t base = SUBT ? 0u : (uint32_t)wv * 64u; base < ncand; base += 256u) {
+                        const uint32_t pi = SUBT ? base + 4u * (uint32_t)l + (uint32_t)wv : base + (uint32_t)l;
                         const bool alive = pi < ncand && hit[pi] == (uint8_t)j;
                         const uint32_t c = alive ? cand[pi] : 0u;
                         uint32_t blk = NONE;
