@@ -657,6 +657,33 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         for (uint32_t i = (uint32_t)tid; i < bh - bl; i += 256u) fd[i] = L.skip[bl + i].first_doc;
                         __syncthreads();
                     }
+                    if (bh > bl && bh - bl <= 4u) {
+                        // a handful of blocks in range (two sparse lists): wave w decodes block bl + w ONCE into LDS — in
+                        // parallel, one fetch latency for the tile — and every candidate searches its block there
+                        uint32_t *allbuf = reinterpret_cast<uint32_t *>(sm.raw);
+                        if ((uint32_t)wv < bh - bl) {
+                            const uint32_t b = bl + (uint32_t)wv;
+                            const uint32_t cntb = decode_block_wave(GlobalBytes{L.payload}, L.skip[b].byte_off, L.skip[b + 1u].byte_off,
+                                                                    L.skip[b].first_doc, [&](uint32_t ix, uint32_t id) { allbuf[(uint32_t)wv * 256u + ix] = id; });
+                            if (l == 0) sm.wcnt[wv] = cntb;
+                        }
+                        __syncthreads();
+                        for (uint32_t pi = (uint32_t)tid; pi < ncand; pi += 256u) {
+                            if (hit[pi] != (uint8_t)j) continue;
+                            const uint32_t c = cand[pi];
+                            uint32_t a = 0, e = bh - bl;
+                            while (a < e) { const uint32_t mid = a + ((e - a) >> 1); if (fd[mid] <= c) a = mid + 1u; else e = mid; }
+                            if (a == 0u) continue;                         // before the first block in range
+                            const uint32_t wb = a - 1u;
+                            const uint32_t *ids = allbuf + wb * 256u;
+                            uint32_t x = 0, y = sm.wcnt[wb];
+                            const uint32_t cntb = y;
+                            while (x < y) { const uint32_t mid = (x + y) >> 1; if (ids[mid] < c) x = mid + 1u; else y = mid; }
+                            if (x < cntb && ids[x] == c) hit[pi] = (uint8_t)(j + 1u);
+                        }
+                        __syncthreads();
+                        continue;
+                    }
                     // split driver blocks leave a run of consecutive candidates alive: deal them out to the four waves
                     // candidate by candidate, or one wave would decode all their blocks one after the other
                     for (uint32_t base = SUBT ? 0u : (uint32_t)wv * 64u; base < ncand; base += 256u) {
