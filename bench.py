@@ -339,8 +339,6 @@ def bench_merge(args, ctx, torch, dist, world, rank):
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    if rank != 0:
-        return
     enc = sum(s.info.n_bytes for s in segs)
     nblk = sum(s.info.n_blocks for s in segs)
     alg = enc + 8 * nblk + 4 * k * (T + 1) + args.docs // 8 + 4 * st.n_out + 4 * (T + 1)
@@ -365,7 +363,52 @@ def bench_merge(args, ctx, torch, dist, world, rank):
                      "unit": "GB/s", "frac": alg / kavg / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": int(alg), "kernel_avg_us": kavg * 1e6, "launches_timed": int(kern_n)},
     }
-    if not args.no_cpu_baseline:
+    # BASELINE config 4's exchange step, once, after the timed region: the ranks' merged postings concatenated in rank
+    # (= term-range) order with the library's RCCL all-gatherv.  A watchdog keeps a stuck exchange from taking the run.
+    gather = None
+    if world > 1:
+        import threading
+        from inverted_index_2_amd import comm_unique_id
+        done = threading.Event()
+
+        def on_timeout():
+            if not done.is_set():
+                if rank == 0:
+                    result["allgatherv_impl"] = "skipped: the exchange did not finish within %d s" % args.gather_timeout
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+
+        timer = threading.Timer(args.gather_timeout, on_timeout)
+        timer.daemon = True
+        timer.start()
+        try:
+            counts_t = torch.tensor([int(st.n_out)], dtype=torch.int64, device="cuda")
+            all_counts = [torch.zeros_like(counts_t) for _ in range(world)]
+            dist.all_gather(all_counts, counts_t)
+            total = int(sum(int(c.item()) for c in all_counts))
+            gout = ctx.empty(total + 8)
+            uid = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(world, rank, uid[0])
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            counts = ctx.allgatherv(out_vals, int(st.n_out), gout, world)
+            gather = {"allgatherv_ms": (time.perf_counter() - g0) * 1e3, "allgatherv_ids": int(sum(counts)),
+                      "allgatherv_impl": "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv)"}
+            mine = gout.download(int(sum(counts[:rank + 1])))[int(sum(counts[:rank])):]
+            if not np.array_equal(mine, out_vals.download(int(st.n_out))):
+                raise SystemExit(f"rank {rank}: all-gatherv result is not the rank-order concatenation")
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 — the timed figures stand on their own
+            gather = {"allgatherv_impl": "failed: %s" % type(e).__name__}
+        done.set()
+        timer.cancel()
+    if rank != 0:
+        return
+    if gather:
+        result.update(gather)
+    if not args.no_cpu_baseline and world == 1:
         from oracle import oracle as orc
         ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
         t0 = time.perf_counter()
