@@ -320,10 +320,12 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return pre + incl - v;
 }
 
+// KFIX: segment count known at compile time (0 = read it from the parameters); 16-way merges get their own instantiation
+template <uint32_t KFIX>
 __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
     __shared__ MergeSmem sm;
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
-    const uint32_t k = p.k;
+    const uint32_t k = KFIX ? KFIX : p.k;
     // diagnostics only: thread 0 sums the cycles spent in each step of the tile loop
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
@@ -999,7 +1001,8 @@ hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hip
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (p.n_tiles == 0) return hipSuccess;
     if (ev0) (void)hipEventRecord(ev0, s);
-    hipLaunchKernelGGL(k_merge_tiles, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
+    if (p.k == 16u) hipLaunchKernelGGL(k_merge_tiles<16u>, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
+    else hipLaunchKernelGGL(k_merge_tiles<0u>, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
     if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }
