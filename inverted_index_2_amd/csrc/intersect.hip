@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
         if (has_next && (uint32_t)tid < stride) dreg = p.ranges[(uint64_t)next_tile * stride + tid];
         const ListView drv = p.lists[0];
         uint32_t *slot = p.tmp + (uint64_t)tile * p.slot_words;     // this tile's bitmap words / id list
+        bool map_tile = false;                                      // a map tile: its count is published after the end barrier
 
         // Very dense tiles (every phase: full blocks of single-byte gaps, at most ~3 docs per posting) keep one
         // BITMAP per list instead of the byte map: a lane turns four gap bytes into a 32-bit mask in registers
@@ -439,12 +440,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 mine += (uint32_t)__popc(word);
             }
             mine = wave_sum(mine);
-            if (l == 0) sm.wcnt[wv] = mine;
-            lds_barrier();
-            if (tid == 0) {
-                const uint32_t c = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
-                p.tile_count[tile] = c;
-            }
+            if (l == 0) sm.wcnt[wv] = mine;        // summed up after the end-of-tile barrier (one barrier fewer per tile)
+            map_tile = true;
             II2_STAMP(3)
         } else if (mapped) {
             // ================= byte-map path =================
@@ -610,12 +607,8 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                 mine += (uint32_t)__popc(word);
             }
             mine = wave_sum(mine);
-            if (l == 0) sm.wcnt[wv] = mine;
-            lds_barrier();
-            if (tid == 0) {
-                const uint32_t c = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
-                p.tile_count[tile] = c;
-            }
+            if (l == 0) sm.wcnt[wv] = mine;        // summed up after the end-of-tile barrier
+            map_tile = true;
             II2_STAMP(3)          // finalise
         } else {
             // ================= gallop path =================
@@ -804,6 +797,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
             }
         }
         lds_barrier();        // map / wcnt are reused by the next tile
+        if (map_tile && tid == 0) p.tile_count[tile] = sm.wcnt[0] + sm.wcnt[1] + sm.wcnt[2] + sm.wcnt[3];
         item = next_item;
         tile = next_tile;
     }
