@@ -1,24 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — posting-list hot path on MI355X: postings/s and fraction of the HBM roofline.
 
-Workload at N=1 (BASELINE.json configs[1]): 2-term intersection over a 100M-doc index, Zipf
-ranks 2 and 3 (≈50M and ≈33M postings), block-Δ-varint (DV1) lists resident in HBM, decoded
-in-kernel; output = the ascending doc ids of the intersection, resident in HBM.
-A step = one pass of the hot path (partition pre-pass + tile kernel) over that input.
+One run times BOTH halves of the metric ("intersect + segment-merge") and prints ONE JSON line on rank 0:
 
-N > 1 (one process per GPU, launched by torch.distributed.run): the doc-id space is sharded —
-rank g holds the lists' postings in [g*D, (g+1)*D) — so per-GPU work is fixed (weak scaling)
-and ranks do not talk during the timed steps (the reference's shards are independent,
-inverted_index.go:83-103).  The rank-order concatenation of the per-rank results
-(RCCL all-gatherv, inverted_index.go:330-339) runs once after the timed region and is
-reported separately as `allgatherv_ms` (use --gather-timed to put it inside every step).
+* headline (`value`, `roofline`, `cpu_baseline`): BASELINE.json configs[1] — 2-term intersection over a 100M-doc
+  index, Zipf ranks 2 and 3 (≈50M and ≈33M postings), block-Δ-varint (DV1) lists resident in HBM, decoded in-kernel;
+  output = the ascending doc ids of the intersection, resident in HBM.  A step = one pass over that input.
+  `roofline.cold_*`: the same passes rotated over 4 distinct list pairs (4 x 150 MB of traffic > the 256 MiB Infinity
+  Cache), so the figure cannot be fed by the cache.
+* `merge` (N = 1): configs[2] — 16-way segment merge of 1M terms x mean 1000 postings (~1.06e9 postings in), 1 %
+  tombstones; checked against the oracle before timing; that oracle run is also the `cpu_baseline` sample.
+* `merge_strong` (every N): configs[3] — ONE fixed problem, 64 segments x 1M terms, the terms cut into N contiguous
+  ranges balanced by posting count (shard.go:362-378 ranges are contiguous too); every rank merges its range, then the
+  merged postings are concatenated in rank order with ii2_allgatherv (RCCL).  This is the STRONG-scaling figure the
+  1 -> 8 GPU target is about.  (The headline is WEAK scaling: every rank intersects its own doc-range shard.)
 
-Prints ONE JSON line on rank 0.
+N > 1: one process per GPU, launched by torch.distributed.run; ranks do not talk during the timed steps of the
+intersection (the reference's shards are independent, inverted_index.go:83-103).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -27,23 +31,43 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--docs", type=int, default=100_000_000, help="doc-id universe per GPU (config 2: 100M)")
-    ap.add_argument("--workload", choices=["intersect", "merge"], default="intersect")
+    ap.add_argument("--workload", choices=["all", "intersect", "merge", "strong"], default="all")
     ap.add_argument("--tombstones", action="store_true", help="apply a 1%% tombstone bitmap during the intersection")
-    ap.add_argument("--gather-timed", action="store_true", help="include the RCCL all-gatherv in every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-timeout", type=int, default=120, help="seconds the post-timing all-gatherv may take (N > 1)")
-    ap.add_argument("--merge-terms", type=int, default=200_000, help="merge workload: aligned terms")
+    ap.add_argument("--gather-timeout", type=int, default=120, help="seconds the all-gatherv exchange may take (N > 1)")
+    ap.add_argument("--merge-terms", type=int, default=1_000_000, help="merge workloads: aligned terms")
     ap.add_argument("--merge-segments", type=int, default=16)
+    ap.add_argument("--strong-segments", type=int, default=64)
     ap.add_argument("--merge-mean", type=float, default=1000.0)
+    ap.add_argument("--merge-steps", type=int, default=0, help="timed merges (0: min(steps, 10))")
+    ap.add_argument("--cold-pairs", type=int, default=4)
     return ap.parse_args()
+
+
+def cores_available():
+    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def pmc_traffic(name):
+    """HBM bytes per pass from the PMC passes kept under profiles/ (same command, same workload) — a recorded figure,
+    not a counter of this run; the JSON says so (`traffic_source`)."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
+        try:
+            with open(path) as f:
+                return json.load(f)["hbm_bytes_per_pass_corrected"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline_intersect(lists, removed, reps, threads=1):
@@ -76,47 +100,124 @@ def cpu_baseline_intersect(lists, removed, reps, threads=1):
     return n_post / dt, np.concatenate(res) if res else np.empty(0, np.uint32), dt
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
+class Job:
+    """Process-wide state of one bench run."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.args, self.torch, self.dist = args, torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+        torch.cuda.set_device(self.local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        from inverted_index_2_amd import Context
+        self.ctx = Context(self.local_rank)
+        self.ctx.selftest()
+        self.comm = None           # "ii2" | "torch" once decided (identically on every rank)
+        self.rc = 0
 
-    from inverted_index_2_amd import Context, comm_unique_id, synth
+    def sync_all(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
 
-    ctx = Context(local_rank)
-    ctx.selftest()
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    if args.workload == "merge":
-        return bench_merge(args, ctx, torch, dist, world, rank)
+    def init_comm(self):
+        """The library's own RCCL communicator (torch's only carries the unique id).  Every rank learns whether EVERY
+        rank got one — ranks must never run different collectives against each other."""
+        if self.comm is not None or self.world == 1:
+            return
+        from inverted_index_2_amd import comm_unique_id
+        ok = 1
+        try:
+            uid = [comm_unique_id() if self.rank == 0 else None]
+            self.dist.broadcast_object_list(uid, src=0)
+            self.ctx.comm_init(self.world, self.rank, uid[0])
+        except Exception as e:  # noqa: BLE001
+            print("rank %d: ii2_comm_init failed: %r" % (self.rank, e), file=sys.stderr, flush=True)
+            ok = 0
+        t = self.torch.tensor([ok], dtype=self.torch.int32, device="cuda")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        self.comm = "ii2" if int(t.item()) == 1 else "torch"
 
+    def gather(self, local, n_local, cap_per_rank):
+        """Rank-order concatenation of the ranks' device arrays (inverted_index.go:330-339).  Returns (DeviceArray,
+        counts, implementation)."""
+        self.init_comm()
+        torch, dist = self.torch, self.dist
+        if self.comm == "ii2":
+            out = self.ctx.empty(cap_per_rank * self.world + 8)
+            counts = self.ctx.allgatherv(local, n_local, out, self.world)
+            return out, counts, "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv over xGMI)"
+        # every rank agreed that the library communicator is unusable: padded all_gather through torch's RCCL communicator
+        cnt = torch.tensor([n_local], dtype=torch.int64, device="cuda")
+        cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
+        dist.all_gather(cnts, cnt)
+        host = local.download(n_local)
+        mine = torch.from_numpy(np.concatenate([host, np.zeros(cap_per_rank - n_local, np.uint32)]).view(np.int32)).cuda()
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        counts = [int(c.item()) for c in cnts]
+        packed = np.concatenate([pp[:c].cpu().numpy().view(np.uint32) for pp, c in zip(parts, counts)])
+        out = self.ctx.empty(packed.size + 8)
+        out.upload(packed)
+        return out, counts, "torch.distributed.all_gather fallback (ii2_comm_init failed on some rank)"
+
+    def guarded(self, what, fn):
+        """Runs an exchange step under a watchdog: a stuck RCCL exchange is a GPU hang — report it and leave NON-zero."""
+        done = threading.Event()
+
+        def on_timeout():
+            if not done.is_set():
+                print("rank %d: %s did not finish within %d s — aborting" % (self.rank, what, self.args.gather_timeout),
+                      file=sys.stderr, flush=True)
+                os._exit(3)
+
+        timer = threading.Timer(self.args.gather_timeout, on_timeout)
+        timer.daemon = True
+        timer.start()
+        try:
+            return fn()
+        finally:
+            done.set()
+            timer.cancel()
+
+
+def bench_intersect(job):
+    """Headline: configs[1].  Returns the dict of headline fields."""
+    args, ctx, world, rank = job.args, job.ctx, job.world, job.rank
+    from inverted_index_2_amd import synth
     D = args.docs
     offset = rank * D
     if offset + D > (1 << 32):
         raise SystemExit("doc-id shards exceed the uint32 id space")
     a = synth.zipf_list(2, D, offset)
     b = synth.zipf_list(3, D, offset)
-    removed = None
-    tomb = None
+    removed = tomb = None
     if args.tombstones:
         removed = (synth.geometric_postings(0.01, D, synth.term_seed(10**6), offset)).astype(np.uint32)
         tomb = ctx.tombstones(removed)
     seg = ctx.encode_lists([a, b])
     lists = [(seg, 0), (seg, 1)]
     n_in = int(a.size + b.size)
-    out = ctx.empty(min(a.size, b.size) + 512)
+    cap = min(a.size, b.size) + 512
+    out = ctx.empty(cap)
     d_count = ctx.empty(8, np.uint64)
 
-    # correctness of this rank's result before timing: count + order + checksum
+    # correctness of this rank's result before timing: bit-exact id sequence
     _, n_out = ctx.intersect(lists, tomb=tomb, out=out)
     got = out.download(n_out)
     want_np = np.intersect1d(a, b, assume_unique=True)
@@ -125,306 +226,325 @@ def main():
     if n_out != want_np.size or not np.array_equal(got, want_np):
         raise SystemExit(f"rank {rank}: GPU intersection differs from the numpy cross-check")
 
-    gather_out = None
-    gstate = {"impl": None}
+    def timed(pairs, steps):
+        for i in range(args.warmup):
+            ctx.intersect_async(pairs[i % len(pairs)], tomb, out, d_count)
+        job.sync_all()
+        ctx.profile_region(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            ctx.intersect_async(pairs[i % len(pairs)], tomb, out, d_count)
+        ctx.profile_region(False)
+        job.sync_all()
+        dt = time.perf_counter() - t0
+        return job.max_over_ranks(dt), ctx.profile_region_ms() * 1e-3
 
-    def init_comm():
-        # the library's own RCCL communicator (ii2_comm_*); torch's communicator only carries the unique id
-        nonlocal gather_out
-        if gstate["impl"] is not None:
-            return
-        gather_out = ctx.empty((min(a.size, b.size) + 512) * world)
-        try:
-            uid = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(world, rank, uid[0])
-            gstate["impl"] = "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv)"
-        except Exception as e:  # noqa: BLE001 — keep the scaling run alive; the exchange then goes through torch (RCCL too)
-            gstate["impl"] = "torch.distributed.all_gather fallback (%s)" % type(e).__name__
-
-    if world > 1 and args.gather_timed:
-        init_comm()
-
-    def gather_all():
-        if gstate["impl"].startswith("ii2_"):
-            return ctx.allgatherv(out, n_out, gather_out, world)
-        # fallback: padded all_gather through torch's RCCL communicator, then pack on the host side of the check
-        cap = min(a.size, b.size) + 512
-        cnt = torch.tensor([n_out], dtype=torch.int64, device="cuda")
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        mine = torch.from_numpy(np.concatenate([got, np.zeros(cap - n_out, np.uint32)]).view(np.int32)).cuda()
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine)
-        counts = [int(c.item()) for c in cnts]
-        packed = np.concatenate([pp[:c].cpu().numpy().view(np.uint32) for pp, c in zip(parts, counts)])
-        gather_out.upload(packed)
-        return counts
-
-    def step():
-        ctx.intersect_async(lists, tomb, out, d_count)
-        if args.gather_timed and world > 1:
-            gather_all()
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    ctx.set_option("profile.events", 8)      # every 8th pass is bracketed by HIP events (a pair idles the stream ~10 us)
+    dt, dev_s = timed([lists], args.steps)
+    # per-pass device time sampled with an event pair around single passes (a pair idles the stream ~10 us, so
+    # this loop is separate from the timed one)
+    ctx.set_option("profile.events", 1)
     ctx.profile_read()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.profile_read()
+    for _ in range(max(10, min(args.steps, 40))):
+        ctx.intersect_async(lists, tomb, out, d_count)
+    pass_ms, pass_n = ctx.profile_read()
     ctx.set_option("profile.events", 0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-
-    # secondary figure: two passes in flight (two contexts = two HIP streams).  The partition / expand
-    # kernels of one pass then overlap the tile kernel of the other; same work per step.
-    pipelined = None
-    if world == 1:
-        ctx2 = Context(local_rank)
-        seg2 = ctx2.encode_lists([a, b])
-        out2 = ctx2.empty(min(a.size, b.size) + 512)
-        cnt2 = ctx2.empty(8, np.uint64)
-        tomb2 = ctx2.tombstones(removed) if removed is not None else None
-        pair = [(ctx, lists, tomb, out, d_count), (ctx2, [(seg2, 0), (seg2, 1)], tomb2, out2, cnt2)]
-        for c, ls, tb, o, dc in pair:
-            c.intersect_async(ls, tb, o, dc)
-        torch.cuda.synchronize()
-        p0 = time.perf_counter()
-        for i in range(args.steps):
-            c, ls, tb, o, dc = pair[i & 1]
-            c.intersect_async(ls, tb, o, dc)
-        torch.cuda.synchronize()
-        pdt = time.perf_counter() - p0
-        if not np.array_equal(out2.download(n_out), got):
-            raise SystemExit("second stream's result differs")
-        pipelined = {"streams": 2, "value": n_in * args.steps / pdt, "unit": "postings/s", "ms_per_step": pdt / args.steps * 1e3}
-        ctx2.close()
 
     info = seg.info
-    # algorithmic bytes of one pass (SURVEY.md §8 d): encoded payload + 8 B per block of
-    # skip table + 4 B per result id (+ D/8 tombstone bitmap).  The HIP events bracket the whole pass
-    # on the library's stream: k_isect_partition + k_isect_tiles (dominant) + k_isect_expand.
+    # algorithmic bytes of one pass (SURVEY.md §8 d): encoded payload + 8 B per block of skip table
+    # + 4 B per result id (+ D/8 tombstone bitmap)
     alg_bytes = info.n_bytes + 8 * info.n_blocks + 4 * n_out + (D // 8 if tomb is not None else 0)
-    kern_avg_s = (kern_ms / max(kern_n, 1)) * 1e-3
-    achieved = alg_bytes / kern_avg_s / 1e9 if kern_n else None
-    # HBM traffic from the PMC passes kept under profiles/ (same command, same workload); null otherwise
-    traffic = None
-    try:
-        if D == 100_000_000 and tomb is None and world == 1:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_intersect.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_pass_corrected"]
-    except OSError:
-        pass
+    kern_avg_s = dev_s / args.steps
+    achieved = alg_bytes / kern_avg_s / 1e9
+    traffic, traffic_src = (None, None)
+    if D == 100_000_000 and tomb is None:
+        traffic, traffic_src = pmc_traffic("intersect")
 
-    result = {
-        "metric": "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline",
+    # cold variant: rotate over distinct list pairs so that no pass finds its input in the Infinity Cache
+    cold = None
+    if args.cold_pairs > 1:
+        pairs = [lists]
+        keep = [seg]
+        n_in_cold, alg_cold = n_in, alg_bytes
+        for i in range(1, args.cold_pairs):
+            a2 = synth.zipf_list(2, D, offset, synth.GLOBAL_SEED + 7919 * i)
+            b2 = synth.zipf_list(3, D, offset, synth.GLOBAL_SEED + 7919 * i)
+            s2 = ctx.encode_lists([a2, b2])
+            keep.append(s2)
+            pairs.append([(s2, 0), (s2, 1)])
+            _, n2 = ctx.intersect(pairs[-1], tomb=tomb, out=out)
+            w2 = np.intersect1d(a2, b2, assume_unique=True)
+            if removed is not None:
+                w2 = np.setdiff1d(w2, removed, assume_unique=True)
+            if n2 != w2.size or not np.array_equal(out.download(n2), w2):
+                raise SystemExit(f"rank {rank}: cold pair {i} differs from the numpy cross-check")
+            n_in_cold += int(a2.size + b2.size)
+            alg_cold += s2.info.n_bytes + 8 * s2.info.n_blocks + 4 * n2 + (D // 8 if tomb is not None else 0)
+        steps_c = max(args.cold_pairs, (args.steps // args.cold_pairs) * args.cold_pairs)
+        cdt, cdev = timed(pairs, steps_c)
+        per_pass_alg = alg_cold / args.cold_pairs
+        cold = {"pairs": args.cold_pairs, "steps": steps_c, "ms_per_step": cdt / steps_c * 1e3,
+                "value": n_in_cold / args.cold_pairs * world * steps_c / cdt,
+                "kernel_avg_us": cdev / steps_c * 1e6, "achieved": per_pass_alg / (cdev / steps_c) / 1e9,
+                "frac": per_pass_alg / (cdev / steps_c) / 1e9 / HBM_PEAK_GBS,
+                "bytes_touched_between_reuses_MB": round((args.cold_pairs - 1) * per_pass_alg / 1e6, 1)}
+        for s2 in keep[1:]:
+            s2.free()
+        ctx.intersect(lists, tomb=tomb, out=out)       # leave the headline pair's result in `out`
+
+    res = {
         "value": n_in * world * args.steps / dt,
-        "unit": "postings/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "u32",
-        "data": "synthetic",
         "config": {
             "workload": "2-term intersection (Zipf ranks 2 and 3), %d-doc universe per GPU, DV1 block-delta-varint "
                         "decoded in-kernel, doc-range sharded" % D,
             "postings_per_gpu": n_in, "result_ids_per_gpu": n_out, "tombstones": bool(args.tombstones),
             "encoded_bytes_per_gpu": int(info.n_bytes), "blocks_per_gpu": int(info.n_blocks),
-            "parallelism": "docrange%d" % world, "allgatherv": "timed" if args.gather_timed else "after timed region",
+            "parallelism": "docrange%d" % world,
         },
         "roofline": {
-            "bound": "hbm", "kernel": "one pass: ii2::k_isect_partition + ii2::k_isect_tiles (dominant) + ii2::k_isect_expand",
-            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-            "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_us": kern_avg_s * 1e6, "launches_timed": int(kern_n),
+            "bound": "hbm", "kernel": "one pass of ii2_intersect: every kernel between the first launch and the last "
+                                      "(names in profiles/)",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_avg_us": kern_avg_s * 1e6, "launches_timed": int(args.steps),
+            "timing": "one HIP event pair on the library's stream around the %d timed passes" % args.steps,
+            "sampled_pass_us": (pass_ms / pass_n * 1e3) if pass_n else None, "sampled_passes": int(pass_n),
         },
     }
-    if pipelined is not None:
-        result["pipelined"] = pipelined
-    # the exchange step, once, outside the timed region: rank-order concatenation of the results.  The timed
-    # figures above are already final; a watchdog keeps a stuck exchange from taking the whole scaling run with it.
+    if cold is not None:
+        res["roofline"]["cold_frac"] = cold["frac"]
+        res["roofline"]["cold"] = cold
+
+    # the exchange step, once, after the timed region: rank-order concatenation of the results
     if world > 1:
-        import threading
-
-        def on_timeout():
-            if rank == 0:
-                result["allgatherv_impl"] = "skipped: the exchange did not finish within %d s" % args.gather_timeout
-                print(json.dumps(result), flush=True)
-            os._exit(0)
-
-        timer = threading.Timer(args.gather_timeout, on_timeout)
-        timer.daemon = True
-        timer.start()
-        try:      # nothing in here may cost the run its (already final) timed figures
-            init_comm()
-            torch.cuda.synchronize()
+        def exchange():
+            job.torch.cuda.synchronize()
             g0 = time.perf_counter()
-            counts = gather_all()
-            gather_ms = (time.perf_counter() - g0) * 1e3
-            total_out = sum(counts)
-            allv = gather_out.download(total_out)
-            good = bool(np.all(np.diff(allv.astype(np.int64)) > 0) and np.array_equal(allv[sum(counts[:rank]):sum(counts[:rank + 1])], got))
-            result["allgatherv_ms"] = gather_ms
-            result["allgatherv_impl"] = gstate["impl"]
-            result["allgatherv_ids"] = int(total_out)
-            result["allgatherv_check"] = "rank-order concatenation verified on rank 0" if good else "MISMATCH on rank %d" % rank
-            if not good:
-                print(f"rank {rank}: all-gatherv result is not the rank-order concatenation", file=sys.stderr, flush=True)
-        except BaseException as e:  # noqa: BLE001
-            result["allgatherv_impl"] = "failed: %s: %s" % (type(e).__name__, e)
-        timer.cancel()
-        if rank != 0:
-            try:
-                dist.destroy_process_group()
-            except Exception:  # noqa: BLE001
-                pass
-            return
-    if not args.no_cpu_baseline and world == 1:      # the CPU baseline is a rank-0, N=1 figure
-        reps = 20                                      # ~8 s single-thread + ~8 s on the pool
-        v1, res, per1 = cpu_baseline_intersect([a, b], removed, reps, threads=1)
-        if not np.array_equal(res, got):
+            gout, counts, impl = job.gather(out, n_out, cap)
+            ms = (time.perf_counter() - g0) * 1e3
+            total = sum(counts)
+            allv = gout.download(total)
+            good = bool(np.all(np.diff(allv.astype(np.int64)) > 0) and
+                        np.array_equal(allv[sum(counts[:rank]):sum(counts[:rank + 1])], got))
+            gout.free()
+            return ms, total, impl, good
+        ms, total, impl, good = job.guarded("the intersection's all-gatherv", exchange)
+        res["allgatherv"] = {"ms": ms, "ids": int(total), "impl": impl,
+                             "check": "rank-order concatenation verified on rank 0" if good else "MISMATCH on rank %d" % rank}
+        if not good:
+            print(f"rank {rank}: all-gatherv result is not the rank-order concatenation", file=sys.stderr, flush=True)
+            job.rc = 4
+
+    if not args.no_cpu_baseline and world == 1:       # the CPU baseline is a rank-0, N = 1 figure
+        reps = 10                                       # ~4 s single-thread + a few seconds on the pool
+        v1, res1, per1 = cpu_baseline_intersect([a, b], removed, reps, threads=1)
+        if not np.array_equal(res1, got):
             raise SystemExit("GPU result differs from the oracle")
-        ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
-        vN, resN, perN = cpu_baseline_intersect([a, b], removed, max(reps * max(1, ncores // 2), reps), threads=ncores)
+        avail = cores_available()
+        vN, resN, perN = cpu_baseline_intersect([a, b], removed, max(reps, int(8.0 / max(per1 / avail, 1e-3) / 4)), threads=avail)
         if not np.array_equal(resN, got):
             raise SystemExit("GPU result differs from the oracle (sharded run)")
-        result["cpu_baseline"] = {
-            "value": vN, "unit": "postings/s", "cores": ncores, "kind": "port", "value_1_thread": v1,
+        res["cpu_baseline"] = {
+            "value": vN, "unit": "postings/s", "cores": avail, "cores_available": avail, "kind": "port", "value_1_thread": v1,
             "sample": "the full rank-0 workload (DV1 decode + two-pointer intersection of %d postings) cut into %d doc-range "
-                      "shards on a %d-thread pool, %.3f s per repetition; single thread: %.2f s per repetition, %d repetitions "
-                      "(oracle/ii2_oracle.c)" % (n_in, ncores, ncores, perN, per1, reps),
+                      "shards on a %d-thread pool (every core of the affinity mask), %.3f s per repetition; single thread: "
+                      "%.2f s per repetition, %d repetitions (oracle/ii2_oracle.c)" % (n_in, avail, avail, perN, per1, reps),
         }
-    print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    seg.free()
+    out.free()
+    return res
 
 
-def bench_merge(args, ctx, torch, dist, world, rank):
-    """Secondary workload (BASELINE config 3 family): k-way segment merge with tombstones.
-    Terms are sharded over the ranks in contiguous ranges; each rank generates its own shard."""
+def merge_alg_bytes(segs, T, k, docs, n_out):
+    """SURVEY §8 d: sum over segments (encoded payload + 8 B per block + 4 (T+1) offsets) + D/8 + 4 |out| + 4 (T+1)."""
+    enc = sum(s.info.n_bytes for s in segs)
+    nblk = sum(s.info.n_blocks for s in segs)
+    return enc + 8 * nblk + 4 * k * (T + 1) + docs // 8 + 4 * n_out + 4 * (T + 1)
+
+
+def time_merges(job, segs, tomb, out_off, out_vals, steps):
+    ctx = job.ctx
+    ctx.merge(segs, tomb, out_off, out_vals)
+    ctx.set_option("profile.events", 1)
+    ctx.profile_read()
+    job.sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.merge(segs, tomb, out_off, out_vals)
+    job.sync_all()
+    dt = job.max_over_ranks(time.perf_counter() - t0)
+    dev_ms, dev_n = ctx.profile_read()
+    ctx.set_option("profile.events", 0)
+    return dt, dev_ms, dev_n
+
+
+def bench_merge(job):
+    """configs[2] on one GPU: 16-way merge of `--merge-terms` terms, oracle-checked, oracle-timed."""
+    args, ctx = job.args, job.ctx
     from inverted_index_2_amd import synth
     T, k = args.merge_terms, args.merge_segments
-    offs, vals, removed = synth.merge_workload(T, k, args.merge_mean, args.docs, seed=synth.GLOBAL_SEED + rank)
+    avail = cores_available()
+    g0 = time.perf_counter()
+    offs, vals, removed = synth.merge_workload_big(T, k, args.merge_mean, args.docs, threads=min(avail, 32))
+    gen_s = time.perf_counter() - g0
     segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
     tomb = ctx.tombstones(removed)
     n_in = int(sum(int(o[-1]) for o in offs))
     out_off = ctx.empty(T + 1, np.uint64)
     out_vals = ctx.empty(n_in)
     _, _, st = ctx.merge(segs, tomb, out_off, out_vals)
-    for _ in range(args.warmup):
-        ctx.merge(segs, tomb, out_off, out_vals)
-    ctx.set_option("profile.events", 1)
-    ctx.profile_read()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ctx.merge(segs, tomb, out_off, out_vals)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.profile_read()
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    enc = sum(s.info.n_bytes for s in segs)
-    nblk = sum(s.info.n_blocks for s in segs)
-    alg = enc + 8 * nblk + 4 * k * (T + 1) + args.docs // 8 + 4 * st.n_out + 4 * (T + 1)
-    kavg = kern_ms / max(kern_n, 1) * 1e-3
-    # HBM traffic of one merge (all its kernels) from the PMC passes kept under profiles/ (same command, default sizes)
-    traffic = None
-    try:
-        if T == 200_000 and k == 16 and args.merge_mean == 1000.0 and args.docs == 100_000_000 and world == 1:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_merge.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_pass_corrected"]
-    except OSError:
-        pass
-    result = {
-        "metric": "postings/sec (intersect + segment-merge) at 1/2/4/8 MI355X; % HBM roofline",
-        "value": n_in * world * args.steps / dt, "unit": "postings/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "%d-way segment merge, %d terms x mean %.0f postings per GPU, 1%% tombstones, term-sharded"
-                               % (k, T, args.merge_mean), "postings_in_per_gpu": n_in, "postings_out_per_gpu": int(st.n_out),
-                   "tiles": int(st.n_tiles), "parallelism": "terms%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "ii2::k_merge_tiles", "achieved": alg / kavg / 1e9, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": alg / kavg / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": int(alg), "kernel_avg_us": kavg * 1e6, "launches_timed": int(kern_n)},
-    }
-    # BASELINE config 4's exchange step, once, after the timed region: the ranks' merged postings concatenated in rank
-    # (= term-range) order with the library's RCCL all-gatherv.  A watchdog keeps a stuck exchange from taking the run.
-    gather = None
-    if world > 1:
-        import threading
-        from inverted_index_2_amd import comm_unique_id
-        done = threading.Event()
-
-        def on_timeout():
-            if not done.is_set():
-                if rank == 0:
-                    result["allgatherv_impl"] = "skipped: the exchange did not finish within %d s" % args.gather_timeout
-                    print(json.dumps(result), flush=True)
-                os._exit(0)
-
-        timer = threading.Timer(args.gather_timeout, on_timeout)
-        timer.daemon = True
-        timer.start()
-        try:
-            counts_t = torch.tensor([int(st.n_out)], dtype=torch.int64, device="cuda")
-            all_counts = [torch.zeros_like(counts_t) for _ in range(world)]
-            dist.all_gather(all_counts, counts_t)
-            total = int(sum(int(c.item()) for c in all_counts))
-            gout = ctx.empty(total + 8)
-            uid = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(world, rank, uid[0])
-            torch.cuda.synchronize()
-            g0 = time.perf_counter()
-            counts = ctx.allgatherv(out_vals, int(st.n_out), gout, world)
-            gather = {"allgatherv_ms": (time.perf_counter() - g0) * 1e3, "allgatherv_ids": int(sum(counts)),
-                      "allgatherv_impl": "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv)"}
-            mine = gout.download(int(sum(counts[:rank + 1])))[int(sum(counts[:rank])):]
-            good = bool(np.array_equal(mine, out_vals.download(int(st.n_out))))
-            gather["allgatherv_check"] = "rank-order concatenation verified on rank 0" if good else "MISMATCH on rank %d" % rank
-        except BaseException as e:  # noqa: BLE001 — the timed figures stand on their own
-            gather = {"allgatherv_impl": "failed: %s: %s" % (type(e).__name__, e)}
-        done.set()
-        timer.cancel()
-    if rank != 0:
-        return
-    if gather:
-        result.update(gather)
-    if not args.no_cpu_baseline and world == 1:
+    cpu = None
+    if not args.no_cpu_baseline:
+        # the oracle's worker pool over term ranges (mirrors InvertedIndex.Merge(…, concurrency)) on every core of the
+        # affinity mask: ONE run, which is both the correctness check and the CPU baseline sample
         from oracle import oracle as orc
-        ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 16)
         t0 = time.perf_counter()
-        w_off, w_vals, _ = orc.merge_segments(offs, vals, removed, threads=ncores)
+        w_off, w_vals, _ = orc.merge_segments(offs, vals, removed, threads=avail)
         cdt = time.perf_counter() - t0
         if not (np.array_equal(out_off.download(), w_off) and np.array_equal(out_vals.download(int(w_off[-1])), w_vals)):
             raise SystemExit("GPU merge differs from the oracle")
-        result["cpu_baseline"] = {"value": n_in / cdt, "unit": "postings/s", "cores": ncores, "kind": "port",
-                                  "sample": "the full rank-0 merge workload once, oracle worker pool over term ranges"}
-    print(json.dumps(result))
+        del w_off, w_vals
+        cpu = {"value": n_in / cdt, "unit": "postings/s", "cores": avail, "cores_available": avail, "kind": "port",
+               "sample": "the whole workload once (%d postings in, %.1f s): oracle worker pool over term ranges, pairwise "
+                         "concat+sort+compact fold and binary-search tombstone filter (oracle/ii2_oracle.c); this run is "
+                         "also the correctness check of the GPU result" % (n_in, cdt)}
+    del offs, vals
+    steps = args.merge_steps or min(args.steps, 10)
+    dt, dev_ms, dev_n = time_merges(job, segs, tomb, out_off, out_vals, steps)
+    alg = merge_alg_bytes(segs, T, k, args.docs, int(st.n_out))
+    step_s = dev_ms / max(dev_n, 1) * 1e-3
+    traffic, traffic_src = (None, None)
+    if T == 1_000_000 and k == 16 and args.merge_mean == 1000.0 and args.docs == 100_000_000:
+        traffic, traffic_src = pmc_traffic("merge")
+    res = {
+        "value": n_in * steps / dt, "unit": "postings/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "scaling": "n/a (N = 1)",
+        "config": {"workload": "%d-way segment merge, %d terms x mean %.0f postings, 10 %% duplicated postings, 1 %% tombstones "
+                               "(BASELINE configs[2])" % (k, T, args.merge_mean),
+                   "postings_in": n_in, "postings_out": int(st.n_out), "terms_out": int(st.n_terms_out), "tiles": int(st.n_tiles),
+                   "generate_s": round(gen_s, 1)},
+        "roofline": {"bound": "hbm", "kernel": "one ii2_merge_segments call: every kernel from the first decode launch to the "
+                                               "final offset scan (names in profiles/)",
+                     "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": int(alg),
+                     "kernel_avg_us": step_s * 1e6, "launches_timed": int(dev_n),
+                     "timing": "one HIP event pair per call around all of its kernels; wall ms_per_step adds the call's host side"},
+    }
+    if cpu is not None:
+        res["cpu_baseline"] = cpu
+    for s in segs:
+        s.free()
+    out_off.free()
+    out_vals.free()
+    return res
+
+
+def bench_merge_strong(job):
+    """configs[3]: ONE 64-segment x 1M-term merge, the terms cut into `world` contiguous ranges balanced by posting
+    count; every rank merges its range; the merged postings are concatenated in rank order over RCCL."""
+    args, ctx, world, rank = job.args, job.ctx, job.world, job.rank
+    from inverted_index_2_amd import sharding, synth
+    T, k = args.merge_terms, args.strong_segments
+    ranges = sharding.balanced_term_ranges(T, args.merge_mean, args.docs, world)
+    t0, t1 = ranges[rank]
+    offs, vals, removed = synth.merge_workload_big(T, k, args.merge_mean, args.docs, threads=min(cores_available(), 32),
+                                                   term_range=(t0, t1))
+    n_in_local = int(sum(int(o[-1]) for o in offs))
+    segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+    tomb = ctx.tombstones(removed)
+    out_off = ctx.empty(t1 - t0 + 1, np.uint64)
+    out_vals = ctx.empty(max(n_in_local, 1))
+    _, _, st = ctx.merge(segs, tomb, out_off, out_vals)
+    # cheap exactness check of this rank's share (config 4 itself is oracle-checked in tests/test_gpu_configs.py):
+    # per term ascending + duplicate-free + no tombstoned id, and the count of distinct (term, doc) pairs minus removed
+    g_off = out_off.download().astype(np.int64)
+    g_vals = out_vals.download(int(st.n_out))
+    d = np.diff(g_vals.astype(np.int64))
+    inner = np.ones(d.size, bool)
+    b = g_off[1:-1]
+    inner[b[(b > 0) & (b <= d.size)] - 1] = False
+    if d.size and not np.all(d[inner] > 0):
+        raise SystemExit(f"rank {rank}: merged lists are not strictly ascending")
+    if np.isin(g_vals[:: max(1, g_vals.size // 4_000_000)], removed).any():
+        raise SystemExit(f"rank {rank}: a tombstoned id survived the merge")
+    del offs, vals
+    steps = args.merge_steps or min(args.steps, 10)
+    dt, dev_ms, dev_n = time_merges(job, segs, tomb, out_off, out_vals, steps)
+    tot = job.torch.tensor([float(n_in_local), float(st.n_out)], dtype=job.torch.float64, device="cuda")
+    if world > 1:
+        job.dist.all_reduce(tot)
+    n_in_total, n_out_total = int(tot[0].item()), int(tot[1].item())
+    res = {
+        "value": n_in_total * steps / dt, "unit": "postings/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "scaling": "strong",
+        "config": {"workload": "ONE %d-way segment merge of %d terms x mean %.0f postings (BASELINE configs[3]), terms cut into "
+                               "%d contiguous ranges balanced by posting count" % (k, T, args.merge_mean, world),
+                   "postings_in_total": n_in_total, "postings_out_total": n_out_total,
+                   "rank0_terms": [int(t0), int(t1)] if rank == 0 else None, "rank0_postings_in": n_in_local if rank == 0 else None,
+                   "parallelism": "terms%d" % world},
+        "rank0_device_ms_per_step": dev_ms / max(dev_n, 1),
+    }
+    if world > 1:
+        def exchange():
+            job.torch.cuda.synchronize()
+            cap = job.torch.tensor([int(st.n_out)], dtype=job.torch.int64, device="cuda")
+            job.dist.all_reduce(cap, op=job.dist.ReduceOp.MAX)
+            g0 = time.perf_counter()
+            gout, counts, impl = job.gather(out_vals, int(st.n_out), int(cap.item()))
+            ms = (time.perf_counter() - g0) * 1e3
+            mine = gout.download(int(sum(counts[:rank + 1])))[int(sum(counts[:rank])):]
+            good = bool(np.array_equal(mine, g_vals))
+            gout.free()
+            return ms, counts, impl, good
+        ms, counts, impl, good = job.guarded("the merge's all-gatherv", exchange)
+        res["allgatherv"] = {"ms": ms, "ids": int(sum(counts)), "impl": impl, "GBps_per_rank_received": sum(counts) * 4 / ms / 1e6,
+                             "check": "every rank found its own merged postings at its rank offset" if good else "MISMATCH on rank %d" % rank}
+        res["value_with_allgatherv"] = n_in_total / (dt / steps + ms * 1e-3)
+        if not good:
+            print(f"rank {rank}: merge all-gatherv mismatch", file=sys.stderr, flush=True)
+            job.rc = 4
+    for s in segs:
+        s.free()
+    out_off.free()
+    out_vals.free()
+    return res
+
+
+def main():
+    args = parse()
+    job = Job(args)
+    world, rank = job.world, job.rank
+    parts = {}
+    if args.workload in ("all", "intersect"):
+        parts["intersect"] = bench_intersect(job)
+    if args.workload in ("all", "merge") and world == 1:
+        parts["merge"] = bench_merge(job)
+    if args.workload in ("all", "strong") or (args.workload == "merge" and world > 1):
+        parts["merge_strong"] = bench_merge_strong(job)
+
+    head = parts.get("intersect") or parts.get("merge") or parts["merge_strong"]
+    result = {
+        "metric": METRIC, "value": head["value"], "unit": "postings/s", "n_gpus": world, "steps": args.steps if "intersect" in parts else head.get("steps", args.steps),
+        "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak" if "intersect" in parts else head.get("scaling", "weak"), "vs_baseline": None, "dtype": "u32",
+        "data": "synthetic", "config": head["config"],
+    }
+    for key in ("roofline", "cpu_baseline", "allgatherv"):
+        if key in head:
+            result[key] = head[key]
+    for name in ("merge", "merge_strong"):
+        if name in parts and parts[name] is not head:
+            result[name] = parts[name]
+    if world > 1:
+        rc = job.torch.tensor([job.rc], dtype=job.torch.int32, device="cuda")
+        job.dist.all_reduce(rc, op=job.dist.ReduceOp.MAX)
+        job.rc = int(rc.item())
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        try:
+            job.dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+    sys.exit(job.rc)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,155 @@
+// Package gpu binds the posting-list hot path of lezhnev74/inverted_index_2 to libii2_hip.so
+// (include/ii2.h) through cgo.  It replaces bodies, not signatures: the reference's exported
+// API (inverted_index.go, shard.go) keeps its shape; see index.go for the drop-in methods.
+//
+// This image has no Go toolchain, so the package has never been compiled here; the same
+// entry points are exercised through ctypes by the repository's -m gpu tests.
+//
+// cgo rules honoured: only flat slices cross (no Go pointer to Go pointer), buffers are pinned
+// for the duration of one call, the library retains nothing.
+package gpu
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../inverted_index_2_amd -lii2_hip -Wl,-rpath,${SRCDIR}/../../inverted_index_2_amd
+#include "ii2.h"
+*/
+import "C"
+
+import (
+	"fmt"
+	"unsafe"
+)
+
+// Ctx is one GPU + one HIP stream.  Calls on a Ctx are serialised by the library; give every
+// worker goroutine of InvertedIndex.Merge its own Ctx (inverted_index.go:83-103).  Segments and
+// tombstone bitmaps belong to the device and may be shared by all Ctx of that device.
+type Ctx struct{ h *C.ii2_ctx }
+
+func NewCtx(device int) (*Ctx, error) {
+	var h *C.ii2_ctx
+	if rc := C.ii2_ctx_create(C.int(device), 0, &h); rc != 0 {
+		return nil, fmt.Errorf("gpu: ctx: %s (%d)", C.GoString(C.ii2_last_error(nil)), int(rc))
+	}
+	return &Ctx{h}, nil
+}
+
+func (c *Ctx) Close()      { C.ii2_ctx_destroy(c.h) }
+func (c *Ctx) Device() int { return int(C.ii2_ctx_device(c.h)) }
+
+func (c *Ctx) err(what string, rc C.int) error {
+	return fmt.Errorf("gpu: %s: %s (%d)", what, C.GoString(C.ii2_last_error(c.h)), int(rc))
+}
+
+func u32ptr(s []uint32) *C.uint32_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint32_t)(unsafe.Pointer(&s[0]))
+}
+func u64ptr(s []uint64) *C.uint64_t {
+	if len(s) == 0 {
+		return nil
+	}
+	return (*C.uint64_t)(unsafe.Pointer(&s[0]))
+}
+
+// Segment is a device-resident DV1 segment (the encode step, file/writer.go:32-59).
+type Segment struct{ h *C.ii2_seg }
+
+// Encode uploads nLists posting lists given CSR-style (postOff[nLists+1] into values).
+func (c *Ctx) Encode(postOff []uint64, values []uint32) (*Segment, error) {
+	var s *C.ii2_seg
+	if rc := C.ii2_seg_encode(c.h, C.uint64_t(len(postOff)-1), u64ptr(postOff), u32ptr(values), C.II2_HOST, &s); rc != 0 {
+		return nil, c.err("encode", rc)
+	}
+	return &Segment{s}, nil
+}
+
+// Decode is the decode step (file/reader.go:79-100).
+func (c *Ctx) Decode(s *Segment) (postOff []uint64, values []uint32, err error) {
+	var info C.ii2_seg_info
+	C.ii2_seg_get_info(s.h, &info)
+	postOff = make([]uint64, uint64(info.n_lists)+1)
+	values = make([]uint32, uint64(info.n_postings))
+	if rc := C.ii2_seg_decode(c.h, s.h, u64ptr(postOff), u32ptr(values), C.II2_HOST); rc != 0 {
+		return nil, nil, c.err("decode", rc)
+	}
+	return postOff, values, nil
+}
+
+func (s *Segment) Free() { C.ii2_seg_free(s.h); s.h = nil }
+
+// MergeAligned replaces the loop of Shard.Merge (shard.go:163-212) for k term-aligned segments
+// held in host memory.  segOff: k*(nTerms+1) offsets (per segment, into that segment's slice of
+// values); segBase: k+1 starts of the segments' slices in values; removed: RemovedLists.Values().
+// A term with outOff[t+1]==outOff[t] has no survivors and is dropped by the caller
+// (shard.go:192-194); termsOut == 0 means "write no segment" (shard.go:219-225).
+func (c *Ctx) MergeAligned(k int, nTerms uint64, segOff, segBase []uint64, values, removed []uint32) (outOff []uint64, outVals []uint32, termsOut uint64, err error) {
+	outOff = make([]uint64, nTerms+1)
+	outVals = make([]uint32, len(values)+1)
+	var st C.ii2_merge_stats
+	rc := C.ii2_merge_host(c.h, C.uint32_t(k), C.uint64_t(nTerms), u64ptr(segOff), u64ptr(segBase), u32ptr(values),
+		u32ptr(removed), C.uint64_t(len(removed)), u64ptr(outOff), u32ptr(outVals), C.uint64_t(len(outVals)), &st)
+	if rc != 0 {
+		return nil, nil, 0, c.err("merge", rc)
+	}
+	return outOff, outVals[:st.n_out], uint64(st.n_terms_out), nil
+}
+
+// AlignTerms replaces the k-way term-dictionary walk of makeIterator (shard.go:253-278,
+// bytes.Compare order of file/types.go:24-26): the k sorted dictionaries are given flat
+// (termBytes, termOff[nAll+1], segFirst[k+1] = first term of each segment in termOff);
+// it returns the union dictionary as indices into the input terms (one representative per
+// distinct term) and, per segment, srcList[s*nUnion+u] = list of segment s that holds union
+// term u, or -1.
+func (c *Ctx) AlignTerms(termBytes []byte, termOff []uint64, segFirst []uint64) (rep []uint64, srcList []int64, err error) {
+	k := len(segFirst) - 1
+	nAll := len(termOff) - 1
+	rep = make([]uint64, nAll)
+	srcList = make([]int64, k*nAll)
+	var nUnion C.uint64_t
+	var tb *C.uint8_t
+	if len(termBytes) > 0 {
+		tb = (*C.uint8_t)(unsafe.Pointer(&termBytes[0]))
+	}
+	var sl *C.int64_t
+	if len(srcList) > 0 {
+		sl = (*C.int64_t)(unsafe.Pointer(&srcList[0]))
+	}
+	rc := C.ii2_align_terms(c.h, C.uint32_t(k), tb, u64ptr(termOff), u64ptr(segFirst), u64ptr(rep), sl, &nUnion)
+	if rc != 0 {
+		return nil, nil, c.err("align", rc)
+	}
+	n := int(nUnion)
+	out := make([]int64, k*n)
+	for s := 0; s < k; s++ { // the library packs rows with stride nAll; repack with stride nUnion
+		copy(out[s*n:(s+1)*n], srcList[s*nAll:s*nAll+n])
+	}
+	return rep[:n], out, nil
+}
+
+// Union replaces PrefixSearch's append + slices.Sort + slices.Compact (inverted_index.go:274-292).
+func (c *Ctx) Union(listOff []uint64, values, removed []uint32) ([]uint32, error) {
+	return c.lists(true, listOff, values, removed)
+}
+
+// Intersect: ids present in every list (additive operator; the reference has none).
+func (c *Ctx) Intersect(listOff []uint64, values, removed []uint32) ([]uint32, error) {
+	return c.lists(false, listOff, values, removed)
+}
+
+func (c *Ctx) lists(union bool, listOff []uint64, values, removed []uint32) ([]uint32, error) {
+	out := make([]uint32, len(values)+1)
+	var n C.uint64_t
+	var rc C.int
+	if union {
+		rc = C.ii2_union_host(c.h, C.uint32_t(len(listOff)-1), u64ptr(listOff), u32ptr(values), u32ptr(removed), C.uint64_t(len(removed)), u32ptr(out), C.uint64_t(len(out)), &n)
+	} else {
+		rc = C.ii2_intersect_host(c.h, C.uint32_t(len(listOff)-1), u64ptr(listOff), u32ptr(values), u32ptr(removed), C.uint64_t(len(removed)), u32ptr(out), C.uint64_t(len(out)), &n)
+	}
+	if rc != 0 {
+		return nil, c.err("lists", rc)
+	}
+	return out[:n], nil
+}

@@ -18,6 +18,10 @@
  *     internal mutex, so a ctx may be shared by goroutines / threads (InvertedIndex.Merge
  *     fans Shard.Merge over `concurrency` goroutines, inverted_index.go:83-103); use one
  *     ctx per worker to overlap.
+ *   - segments and tombstone bitmaps belong to a DEVICE, not to the ctx that made them: they
+ *     are read-only once created and any ctx of that device may use them, from any thread,
+ *     concurrently (the reference's readers share segments, segments.go:32-46).  The caller
+ *     must not free one while a call that reads it is still running.
  *   - doc ids ("values") are uint32 everywhere, as in the reference (file/types.go:11).
  *   - there is NO CPU fallback: without a usable gfx950 device ii2_ctx_create fails.
  */
@@ -78,6 +82,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx);
 const char *ii2_last_error(const ii2_ctx *ctx);     /* ctx may be NULL: last create error */
 int ii2_ctx_sync(ii2_ctx *ctx);                     /* waits for the ctx stream */
 void *ii2_ctx_stream(ii2_ctx *ctx);                 /* the hipStream_t, for event timing */
+int ii2_ctx_device(const ii2_ctx *ctx);             /* the device ordinal the context is bound to (-1 for NULL) */
 
 /* raw device buffers for II2_DEVICE arguments */
 int ii2_dev_alloc(ii2_ctx *ctx, size_t bytes, void **dptr);
@@ -170,12 +175,22 @@ int ii2_union_host(ii2_ctx *ctx, uint32_t n, const uint64_t *list_off, const uin
  * the term space (or the doc-id space) is sharded over the GPUs of one node.  One process
  * per GPU; rank 0 calls ii2_comm_unique_id and hands the 128 bytes to the others. */
 #define II2_UNIQUE_ID_BYTES 128
+#define II2_MAX_RANKS 64u
 int ii2_comm_unique_id(void *id_out);
 int ii2_comm_init(ii2_ctx *ctx, int world, int rank, const void *unique_id);
 /* Every rank contributes d_local[n_local]; every rank receives all contributions in rank
- * order in d_out (capacity cap, in values) and the per-rank counts in counts_host[world]. */
+ * order in d_out (capacity cap, in values) and the per-rank counts in counts_host[world].
+ * Whether the concatenation fits is decided on the SMALLEST capacity of all ranks, identically
+ * on every rank: either every rank exchanges, or every rank returns II2_ECAPACITY.  d_local may
+ * be d_out + (its own offset) for an in-place gather, and must not overlap d_out otherwise. */
 int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local,
                    uint32_t *d_out, uint64_t cap, uint64_t *counts_host);
+
+/* The exchange's arithmetic, host only (no GPU needed): offsets[r] = where rank r's contribution
+ * starts in the concatenation (offsets has world + 1 entries, offsets[world] = total).
+ * II2_ECAPACITY when the total exceeds cap (offsets are still filled), II2_EINVAL for
+ * world outside 1..II2_MAX_RANKS. */
+int ii2_gatherv_offsets(const uint64_t *counts, int world, uint64_t cap, uint64_t *offsets);
 
 /* ---- diagnostics ------------------------------------------------------------------------ */
 /* Runs the device self-checks (wave scan, block decode against a scalar decode). 0 = pass. */
@@ -190,6 +205,11 @@ int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words);
  * for ~10 us, so sample (N = 8) when the calls themselves are being timed; this waits for the stream and
  * returns the summed device time and the number of bracketed launches since the previous read. */
 int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches);
+/* One event pair around a whole run of calls: begin != 0 records the start event on the ctx stream, begin == 0 the
+ * end event; ii2_profile_region_ms waits for the end event and returns the device time between the two — the time
+ * the stream spent on everything enqueued in between, without a per-call event pair's idle time. */
+int ii2_profile_region(ii2_ctx *ctx, int begin);
+int ii2_profile_region_ms(ii2_ctx *ctx, double *ms);
 
 #ifdef __cplusplus
 }

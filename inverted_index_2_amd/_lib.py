@@ -39,6 +39,7 @@ PROTOTYPES = {
     "ii2_last_error": (C.c_char_p, [vp]),
     "ii2_ctx_sync": (C.c_int, [vp]),
     "ii2_ctx_stream": (vp, [vp]),
+    "ii2_ctx_device": (C.c_int, [vp]),
     "ii2_dev_alloc": (C.c_int, [vp, C.c_size_t, vpp]),
     "ii2_dev_free": (C.c_int, [vp, vp]),
     "ii2_copy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
@@ -63,10 +64,13 @@ PROTOTYPES = {
     "ii2_comm_unique_id": (C.c_int, [vp]),
     "ii2_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ii2_allgatherv": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
+    "ii2_gatherv_offsets": (C.c_int, [u64p, C.c_int, C.c_uint64, u64p]),
     "ii2_selftest": (C.c_int, [vp]),
     "ii2_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
     "ii2_debug_read": (C.c_int, [vp, u64p, C.c_uint64]),
     "ii2_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), u64p]),
+    "ii2_profile_region": (C.c_int, [vp, C.c_int]),
+    "ii2_profile_region_ms": (C.c_int, [vp, C.POINTER(C.c_double)]),
 }
 
 _lib = None

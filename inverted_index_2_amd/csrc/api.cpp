@@ -88,6 +88,26 @@ int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches) {
     return II2_OK;
 }
 
+int ii2_profile_region(ii2_ctx *ctx, int begin) {
+    if (!ctx) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipEvent_t &e = ctx->region_ev[begin ? 0 : 1];
+    if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventRecord(e, ctx->stream));
+    return II2_OK;
+}
+
+int ii2_profile_region_ms(ii2_ctx *ctx, double *ms) {
+    if (!ctx || !ms || !ctx->region_ev[0] || !ctx->region_ev[1]) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->region_ev[1]));
+    float f = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&f, ctx->region_ev[0], ctx->region_ev[1]));
+    *ms = f;
+    return II2_OK;
+}
+
 int ii2_abi_version(void) { return II2_ABI_VERSION; }
 
 int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
@@ -112,8 +132,8 @@ int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->h_mail, 64 * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_mail, 128 * sizeof(uint64_t)) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->h_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess) {
         g_create_err = "context resource allocation failed";
         ii2_ctx_destroy(ctx);
         return II2_EHIP;
@@ -133,6 +153,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+    for (hipEvent_t e : ctx->region_ev) if (e) (void)hipEventDestroy(e);
     for (auto *v : {&ctx->prof_events, &ctx->prof_pool})
         for (auto &pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -149,6 +170,7 @@ int ii2_ctx_sync(ii2_ctx *ctx) {
 }
 
 void *ii2_ctx_stream(ii2_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int ii2_ctx_device(const ii2_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 int ii2_dev_alloc(ii2_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return II2_EINVAL;
@@ -223,7 +245,7 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     hipStream_t st = ctx->stream;
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
-    seg->ctx = ctx;
+    seg->device = ctx->device;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
     const uint64_t nb_bound = n_postings / II2_DV1_BLOCK + n_lists + 1;
@@ -313,7 +335,7 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const ui
     const hipMemcpyKind kind = where == II2_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
-    seg->ctx = ctx;
+    seg->device = ctx->device;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
     uint32_t nb = 0;
@@ -362,6 +384,15 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const ui
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (bad) return fail(ctx, II2_EINVAL, "ii2_seg_import: malformed DV1 segment (a block that is not its list's last must hold 256 postings)");
     }
+    {   // the caller's n_postings sizes the decode buffers (ii2_seg_decode): it must be the count the blocks really hold
+        uint64_t *d_sum = ctx->d_mail + 8;
+        uint64_t sum = 0;
+        HIP_TRY(ctx, hipMemsetAsync(d_sum, 0, sizeof(uint64_t), ctx->stream));
+        HIP_TRY(ctx, launch_sum_u32(seg->d_cnt, n_lists, d_sum, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&sum, d_sum, sizeof sum, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (sum != n_postings) return fail(ctx, II2_EINVAL, "ii2_seg_import: n_postings differs from the number of postings the blocks hold");
+    }
     *out = seg.release();
     return II2_OK;
 }
@@ -403,7 +434,7 @@ int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info) {
 }
 
 int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64_t *src_list, ii2_seg **out) {
-    if (!ctx || !src || !out || (n_out && !src_list) || src->ctx != ctx) return fail(ctx, II2_EINVAL, "ii2_seg_select: bad argument");
+    if (!ctx || !src || !out || (n_out && !src_list) || src->device != ctx->device) return fail(ctx, II2_EINVAL, "ii2_seg_select: bad argument");
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *out = nullptr;
@@ -431,7 +462,7 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     }
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
-    seg->ctx = ctx;
+    seg->device = ctx->device;
     seg->store = src->store;
     seg->d_skip = src->d_skip;
     seg->d_payload = src->d_payload;
@@ -450,11 +481,10 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
 
 void ii2_seg_free(ii2_seg *seg) {
     if (!seg) return;
-    if (seg->ctx) {
-        std::lock_guard<std::mutex> g(seg->ctx->mu);
-        (void)hipStreamSynchronize(seg->ctx->stream);
-        seg_release(seg);
-    } else seg_release(seg);
+    // the caller guarantees no call that reads the segment is still running (as with any free); hipFree itself waits for
+    // the device's pending work
+    (void)hipSetDevice(seg->device);
+    seg_release(seg);
 }
 
 // ---- tombstones ---------------------------------------------------------------------------
@@ -480,7 +510,7 @@ int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where
     }
     ii2_tomb *t = new (std::nothrow) ii2_tomb();
     if (!t) return II2_ENOMEM;
-    t->ctx = ctx;
+    t->device = ctx->device;
     t->n_words = n ? (uint64_t)(mx >> 5) + 1 : 0;
     // bitmap, then its summary (1 bit per 16 docs = per half bitmap word) in the same allocation
     const uint64_t words_padded = (t->n_words + 4 + 3) & ~3ull;
@@ -505,10 +535,7 @@ int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where
 
 void ii2_tomb_free(ii2_tomb *t) {
     if (!t) return;
-    if (t->ctx) {
-        std::lock_guard<std::mutex> g(t->ctx->mu);
-        (void)hipStreamSynchronize(t->ctx->stream);
-    }
+    (void)hipSetDevice(t->device);
     if (t->d_words) (void)hipFree(t->d_words);
     delete t;
 }
@@ -518,7 +545,7 @@ void ii2_tomb_free(ii2_tomb *t) {
 // ---- intersect ------------------------------------------------------------------------------
 static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListView *v) {
     if (!seg || idx >= seg->n_lists) return fail(ctx, II2_EINVAL, "list index out of range");
-    if (seg->ctx != ctx) return fail(ctx, II2_EINVAL, "segment belongs to another context");
+    if (seg->device != ctx->device) return fail(ctx, II2_EINVAL, "segment lives on another device");
     const uint32_t b0 = seg->h_blk_off[idx], b1 = seg->h_blk_off[idx + 1];
     v->skip = seg->d_skip + b0;
     v->payload = seg->d_payload;
@@ -561,47 +588,34 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
             const uint64_t li = list_idx ? list_idx[i] : 0;
             if (segs[i]->d_skip + segs[i]->h_blk_off[li] == views[0].skip) { dseg = segs[i]; didx = li; break; }
         }
-        std::pair<uint32_t, uint32_t> ends;
-        auto hit = dseg->span_cache.find(didx);
-        if (hit != dseg->span_cache.end()) ends = hit->second;
-        else {
+        ii2_seg::ListSpan ends;
+        bool cached = false;
+        {
+            std::lock_guard<std::mutex> sg(dseg->span_mu);
+            auto hit = dseg->span_cache.find(didx);
+            if (hit != dseg->span_cache.end()) { ends = hit->second; cached = true; }
+        }
+        if (!cached) {
             ii2_skip e[2];
+            uint32_t last = 0;
             HIP_TRY(ctx, hipMemcpyAsync(&e[0], views[0].skip, sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipMemcpyAsync(&e[1], views[0].skip + (nblk0 - 1), sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(&last, views[0].last_doc, sizeof last, hipMemcpyDeviceToHost, st));
             HIP_TRY(ctx, hipStreamSynchronize(st));
-            ends = {e[0].first_doc, e[1].first_doc};
+            ends = {e[0].first_doc, e[1].first_doc, last};
+            std::lock_guard<std::mutex> sg(dseg->span_mu);
             dseg->span_cache[didx] = ends;
         }
-        const double per_block = (double)(ends.second - ends.first) / (double)(nblk0 - 1);
+        const double per_block = (double)(ends.last_block_first_doc - ends.first_doc) / (double)(nblk0 - 1);
         per_block_span = per_block;
         const double g = per_block > 0 ? 0.85 * ISECT_SMAX / per_block : ISECT_GMAX;
         G = g >= ISECT_GMAX ? ISECT_GMAX : g < 1 ? 1u : (uint32_t)g;
         while (G > 1 && nblk0 / G < 8u * (uint32_t)ctx->cu_count) G >>= 1;
     }
-    // wave-level kernels (<= 4 lists): mini-tiles of up to 4 driver blocks, 8 Ki-doc byte map per wave
-    const bool wave = n >= 2 && n <= ISECTW_MAXL && ctx->opt_intersect_wave != 0;
-    if (wave) {
-        uint32_t gw = 4;
-        if (ctx->opt_intersect_g > 0) gw = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, 4);
-        else if (per_block_span > 0) {
-            while (gw > 1 && per_block_span * gw > 0.8 * ISECTW_SMAX) gw >>= 1;
-        }
-        G = gw;
-    }
-    // dense queries of up to 4 lists: the bitmap tile kernel, all phases of a tile staged together (12 KB)
-    bool bm2 = !wave && n <= ISECTB_MAXL && ctx->opt_intersect_bm2 != 0 && ctx->opt_intersect_g <= 0 && nblk0 > 1 &&
-               per_block_span > 0 && per_block_span <= 3.25 * II2_DV1_BLOCK;
-    if (bm2) {
-        double ratio = 0;                                  // payload bytes of a tile per driver block, in blocks
-        for (uint32_t i = 0; i < n; i++) ratio += (double)views[i].nblk / (double)nblk0;
-        const uint32_t gb = (uint32_t)(11000.0 / (255.0 * ratio + 255.0 * 0.15 * n));
-        if (gb < 4u) bm2 = false;
-        else if (gb < G) G = gb;
-    }
     // a tiny sparse driver (a rare term against long lists) would keep only a handful of workgroups busy, each decoding
     // one block of the long list per candidate, one after the other: split its blocks over several tiles
     uint32_t sub = 1;
-    if (!wave && !bm2 && n >= 2 && G == 1 && (per_block_span >= 8192.0 || (nblk0 == 1 && views[n - 1].nblk >= 64)) && ctx->opt_intersect_g <= 0) {
+    if (n >= 2 && G == 1 && (per_block_span >= 8192.0 || (nblk0 == 1 && views[n - 1].nblk >= 64)) && ctx->opt_intersect_g <= 0) {
         const uint32_t want_tiles = 4u * (uint32_t)ctx->cu_count;
         if (nblk0 < want_tiles) sub = std::min<uint32_t>(16u, (want_tiles + nblk0 - 1u) / nblk0);
     }
@@ -609,12 +623,10 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     // the pipelined gallop pays when a driver block faces many blocks of a long list (candidates then hit distinct blocks)
     p.sparse_driver = ((per_block_span >= 8192.0 && views[n - 1].nblk / 16u >= nblk0) || sub > 1) ? 1u : 0u;
     p.sub = sub;
-    p.bm2 = bm2 ? 1u : 0u;
-    p.wave_mode = wave ? 1u : 0u;
     p.n_tiles = ((nblk0 + G - 1) / G) * sub;
-    const size_t dstride = wave ? (16 + 40 * ((size_t)n - 1)) : (2 + 4 * (size_t)n);
+    const size_t dstride = 2 + 4 * (size_t)n;
     p.desc_words = (uint32_t)dstride;
-    uint32_t slot_words = wave ? (ISECTW_SMAX + 32u) / 32u : (ISECT_SMAX + 32u) / 32u;
+    uint32_t slot_words = (ISECT_SMAX + 32u) / 32u;
     if (slot_words < G * 256u) slot_words = G * 256u;
     slot_words = (slot_words + 3u) & ~3u;
     p.slot_words = slot_words;
@@ -628,18 +640,8 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.n_sums1 = p.n_tiles / 64 + 1;
     p.n_sums = p.n_sums1;
     p.sums = ws_take<uint32_t>(ctx, p.n_sums);
-    p.defer = ws_take<uint32_t>(ctx, (size_t)p.n_tiles + 1);
-    p.n_defer = (uint32_t *)(ctx->d_mail + 96);
-    {
-        size_t per_cu = (160u * 1024u) / bm2_lds_bytes(n);
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
-        if (ctx->opt_intersect_wgs > 0) per_cu = (size_t)ctx->opt_intersect_wgs;
-        p.bm2_grid = (uint32_t)(ctx->cu_count * per_cu);
-        p.defer_grid = (uint32_t)ctx->cu_count * 2u;
-    }
     uint64_t *d_tile_off = nullptr;
-    const uint32_t wgs_default = wave ? 4u : 5u;    // LDS per workgroup: ~37 KB (wave) / ~29 KB
+    const uint32_t wgs_default = 5u;    // LDS per workgroup: ~29 KB
     p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : wgs_default);
     p.bitmap_mode = ctx->opt_intersect_bitmap ? 1u : 0u;
     // measured on 100M-doc Zipf pairs: the gallop path wins from ~32 docs per driver posting on (ranks 30/60: 80 -> 64 us),
@@ -714,8 +716,6 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
     p.n_sums1 = p.n_tiles / 64 + 1;
     p.n_sums = p.n_sums1;
     p.sums = ws_take<uint32_t>(ctx, p.n_sums);
-    p.defer = ws_take<uint32_t>(ctx, (size_t)p.n_tiles + 1);
-    p.n_defer = (uint32_t *)(ctx->d_mail + 96);
     p.max_grid = (uint32_t)ctx->cu_count * (ctx->opt_intersect_wgs > 0 ? (uint32_t)ctx->opt_intersect_wgs : 5u);
     p.bitmap_mode = ctx->opt_intersect_bitmap ? 1u : 0u;
     p.tomb = tomb ? tomb->d_words : nullptr;
@@ -791,12 +791,10 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     const std::string k(name);
     if (k == "intersect.g") ctx->opt_intersect_g = value;
     else if (k == "intersect.wgs") ctx->opt_intersect_wgs = value;
-    else if (k == "intersect.wave") ctx->opt_intersect_wave = value;
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
-    else if (k == "intersect.bm2") ctx->opt_intersect_bm2 = value;
     else if (k == "union.dense") ctx->opt_union_dense = value;
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else return fail(ctx, II2_EINVAL, "unknown option");

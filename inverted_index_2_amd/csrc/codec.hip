@@ -248,6 +248,22 @@ __global__ void k_max_u32(const uint32_t *__restrict__ v, uint64_t n, uint32_t *
     if (lane_id() == 0) atomicMax(out, m);
 }
 
+// sum of n u32 values into a u64 (one atomic per wave, few workgroups)
+__global__ void k_sum_u32(const uint32_t *__restrict__ v, uint64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) m += v[i];
+    for (int d = 32; d >= 1; d >>= 1) m += (unsigned long long)__shfl_xor((long long)m, d, 64);
+    if (lane_id() == 0 && m) atomicAdd(out, m);
+}
+
+hipError_t launch_sum_u32(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    unsigned g = (unsigned)((n + 255) / 256);
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(k_sum_u32, dim3(g), dim3(256), 0, s, v, n, (unsigned long long *)out);
+    return hipGetLastError();
+}
+
 hipError_t launch_tomb_build(const uint32_t *removed, uint64_t n, uint32_t *words, uint64_t n_words, uint32_t *summary, hipStream_t s) {
     if (n == 0) return hipSuccess;
     unsigned g = (unsigned)((n + 255) / 256);

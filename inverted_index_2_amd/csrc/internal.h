@@ -11,6 +11,10 @@
 
 #include "../../include/ii2.h"
 
+// mailbox layout (u64 words; h_mail and d_mail both hold II2_MAIL_WORDS)
+constexpr size_t II2_MAIL_WORDS = 512;
+constexpr size_t II2_MAIL_COMM = 256;      // all-gatherv: {count, cap} of this rank, then of every rank (2 + 2 * II2_MAX_RANKS words)
+
 struct ii2_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -26,7 +30,6 @@ struct ii2_ctx {
     // options
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
-    int64_t opt_intersect_wave = 0;     // 1: wave-level kernels for 2..4 lists (measured slower on C2: more, smaller tiles)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
     size_t aux_cap = 0;
@@ -35,12 +38,12 @@ struct ii2_ctx {
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
-    int64_t opt_intersect_bm2 = 0;      // 1: dense queries of <= 4 lists go to the bitmap tile kernel first (measured slower: off)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;     // reusable pairs
+    hipEvent_t region_ev[2] = {nullptr, nullptr};                 // ii2_profile_region: one pair around a whole run of calls
     unsigned long long *d_debug = nullptr;
     void *comm = nullptr;               // ncclComm_t
     int world = 1, rank = 0;
@@ -57,8 +60,10 @@ struct ii2_seg_store {
     }
 };
 
+// A segment is read-only once created and belongs to a DEVICE, not to a context: any context of that device may
+// read it, from any thread (the reference's readers share segments, segments.go:32-46).
 struct ii2_seg {
-    ii2_ctx *ctx = nullptr;
+    int device = 0;
     std::shared_ptr<ii2_seg_store> store;   // owns d_skip / d_payload
     uint64_t n_lists = 0, n_postings = 0, n_blocks = 0, n_bytes = 0;
     uint32_t *d_blk_off = nullptr;   // [n_lists+1]
@@ -68,12 +73,14 @@ struct ii2_seg {
     uint32_t *d_cnt = nullptr;       // [n_lists] postings of each list
     uint32_t *d_blk_list = nullptr;  // [n_blocks] list owning each block (0xFFFFFFFF: none of this view's lists)
     std::vector<uint32_t> h_blk_off; // host mirror of d_blk_off
-    // per list: first_doc of its first and of its last block (tile-height heuristic), fetched once
-    mutable std::unordered_map<uint64_t, std::pair<uint32_t, uint32_t>> span_cache;
+    // per list: first_doc of its first and of its last block and its last doc (tile-height heuristic), fetched once
+    struct ListSpan { uint32_t first_doc, last_block_first_doc, last_doc; };
+    mutable std::mutex span_mu;             // contexts on different threads share the cache
+    mutable std::unordered_map<uint64_t, ListSpan> span_cache;
 };
 
 struct ii2_tomb {
-    ii2_ctx *ctx = nullptr;
+    int device = 0;
     uint32_t *d_words = nullptr;
     uint32_t *d_summary = nullptr;   // bit g set <=> some doc of [16g, 16g+16) is removed (same allocation as d_words)
     uint64_t n_words = 0;   // bitmap covers doc ids [0, 32*n_words)
@@ -111,8 +118,6 @@ struct SegView {
 };
 
 constexpr uint32_t MAX_LISTS = II2_MAX_LISTS;
-constexpr uint32_t ISECTB_MAXL = 4;          // lists the bitmap tile kernel (intersect_bm.hip) takes
-size_t bm2_lds_bytes(uint32_t n_lists);      // its dynamic LDS per workgroup
 
 struct IntersectParams {
     ListView lists[MAX_LISTS];   // lists[0] is the driver (fewest blocks)
@@ -134,17 +139,11 @@ struct IntersectParams {
     uint32_t n_sums, n_sums1;    // total entries, entries of the per-64 level
     uint32_t slot_words;
     uint32_t desc_words;         // words per tile in `ranges`
-    uint32_t wave_mode;          // 1: wave-level kernels (intersect_wave.hip)
     uint32_t max_grid;           // workgroups of the tile kernel (each walks tiles w, w+grid, ...)
     uint32_t bitmap_mode;        // 1: very dense tiles use per-list bitmaps (option intersect.bitmap)
-    uint32_t defer_mode;         // 1: k_isect_tiles handles only the tiles listed in defer[0 .. *n_defer)
-    uint32_t bm2;                // 1: the bitmap kernel (intersect_bm.hip) runs first and defers what it cannot take
-    uint32_t *defer;             // [n_tiles] tiles left by the bitmap kernel
-    uint32_t *n_defer;           // their number (zeroed by the partition kernel)
     uint32_t map_docs_per_block; // tiles with more docs per driver block than this take the gallop path (option intersect.map_docs)
     uint32_t op_union;           // 1: OR instead of AND — fixed doc-range tiles [u_base + t * u_span, ...], every list searched per tile
     uint32_t u_base, u_span, u_max;
-    uint32_t bm2_grid, defer_grid;   // workgroups of the bitmap kernel / of the clean-up launch of k_isect_tiles
 };
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
@@ -174,17 +173,13 @@ hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_l
                                   uint64_t n_blocks, uint32_t *bad, hipStream_t s);
 hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const ii2_skip *skip, uint64_t n_blocks, uint64_t n_bytes,
                                uint32_t *bad, hipStream_t s);
+hipError_t launch_sum_u32(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
 
 // intersect
 constexpr uint32_t ISECT_GMAX = 16;         // driver blocks per tile (max)
 constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
-constexpr uint32_t ISECTW_SMAX = 8192;      // docs a wave's byte map covers (wave-level kernel)
-constexpr uint32_t ISECTW_ABLK = 12;        // prefetched blocks per other list and mini-tile
-constexpr uint32_t ISECTW_MAXL = 4;         // lists the wave-level kernel handles
-hipError_t launch_intersect_wave(const IntersectParams &p, hipStream_t s);
 hipError_t launch_union_range(const IntersectParams &p, uint32_t *d_minmax, hipStream_t s);
-hipError_t launch_intersect_bm(const IntersectParams &p, uint32_t grid, hipStream_t s);
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // merge / union

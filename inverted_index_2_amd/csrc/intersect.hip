@@ -85,10 +85,6 @@ __global__ __launch_bounds__(256) void k_isect_partition(IntersectParams p) {
     const uint32_t n = p.n_lists;
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid < p.n_sums) p.sums[gid] = 0;                      // level sums of the tile counts (filled by the tile kernel)
-    if (p.bm2) {                                              // the bitmap kernel adds its counts per wave and lists what it skips
-        if (gid < p.n_tiles) p.tile_count[gid] = 0;
-        if (gid == 0) *p.n_defer = 0;
-    }
     if (p.op_union) {
         // union: fixed doc-range tiles, one wave per (tile, list)
         if (gw >= (uint64_t)p.n_tiles * n) return;
@@ -233,13 +229,12 @@ __device__ __forceinline__ void gallop_fetch(GallopBlock &g, const uint8_t *__re
     }
 }
 
-// DEFER: work off the tiles the bitmap kernel (intersect_bm.hip) left behind instead of all tiles
 // WIDE: 64 lists — 258 descriptor words per tile, two more than threads (kept out of the common instantiation:
 // the kernel sits at its register limit and even two extra loads cost 2.5 % there)
 // NFIX: list count known at compile time (0 = read it from the parameters) — the two-term query is by far the most common
 // UNION: ids of ANY list (every list marks like the driver, the finalise tests for a mark) — dense unions, host-selected
 // SUBT: driver blocks are split over several tiles (p.sub > 1; gallop only)
-template <bool DEFER, bool WIDE, uint32_t NFIX, bool UNION, bool SUBT = false>
+template <bool WIDE, uint32_t NFIX, bool UNION, bool SUBT = false>
 __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     constexpr uint32_t RAW = NFIX == 2u ? 7680u : RAWCAP;
     constexpr uint32_t DW = NFIX ? 2u + 4u * NFIX : DESC_WORDS;
@@ -257,11 +252,10 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
     Prefetch pf;
     pf.r0 = make_uint4(0, 0, 0, 0); pf.r1 = pf.r0; pf.sk.first_doc = 0; pf.sk.byte_off = 0;
 
-    // work items: all tiles, or (after the bitmap kernel) the tiles it left for this kernel
-    const uint32_t n_items = DEFER ? *p.n_defer : p.n_tiles;
+    const uint32_t n_items = p.n_tiles;
     uint32_t item = blockIdx.x;
     if (item >= n_items) return;
-    uint32_t tile = DEFER ? p.defer[item] : item;
+    uint32_t tile = item;
     // diagnostics only: thread 0 sums the cycles spent in each part of the tile loop
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
@@ -289,7 +283,7 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
         const uint32_t span = hi - lo;
         const uint32_t next_item = item + gridDim.x;
         const bool has_next = next_item < n_items;
-        const uint32_t next_tile = DEFER ? (has_next ? p.defer[next_item] : 0u) : next_item;
+        const uint32_t next_tile = next_item;
         // descriptors of this workgroup's next tile: one word per thread, in flight during the tile
         uint32_t dreg = 0;
         if (has_next && (uint32_t)tid < stride) dreg = p.ranges[(uint64_t)next_tile * stride + tid];
@@ -925,30 +919,18 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
     const uint64_t nthr = (uint64_t)p.n_tiles * (p.op_union ? p.n_lists : p.n_lists > 1u ? p.n_lists - 1u : 1u);
     const uint64_t pthr = std::max<uint64_t>(std::max<uint64_t>(nthr * 64u, p.n_sums), p.n_tiles);
     if (ev0) (void)hipEventRecord(ev0, s);          // the events bracket the whole pass: partition + tiles + expand
-    if (p.wave_mode) {
-        hipError_t e = launch_intersect_wave(p, s);
-        if (e != hipSuccess) return e;
-    } else {
-        hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
-        if (p.bm2) {
-            hipError_t e = launch_intersect_bm(p, p.bm2_grid, s);
-            if (e != hipSuccess) return e;
-            IntersectParams pd = p;                       // then the tiles it left behind (usually none: a small grid)
-            pd.defer_mode = 1u;
-            const uint32_t dgrid = p.n_tiles < p.defer_grid ? p.n_tiles : p.defer_grid;
-            hipLaunchKernelGGL((k_isect_tiles<true, false, 0u, false>), dim3(dgrid), dim3(256), 0, s, pd);      // the bitmap kernel takes <= 4 lists
-        } else {
-            const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
-            if (p.op_union && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, true>), dim3(grid), dim3(256), 0, s, p);
-            else if (p.op_union) hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, true>), dim3(grid), dim3(256), 0, s, p);
-            else if (p.sub > 1u && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
-            else if (p.sub > 1u) hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
-            else if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<false, true, 0u, false>), dim3(grid), dim3(256), 0, s, p);
-            else if (p.n_lists == 2u && !p.sparse_driver) hipLaunchKernelGGL((k_isect_tiles<false, false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((k_isect_tiles<false, false, 0u, false>), dim3(grid), dim3(256), 0, s, p);
-        }
+    hipLaunchKernelGGL(k_isect_partition, dim3((unsigned)((pthr + 255) / 256)), dim3(256), 0, s, p);
+    {
+        const uint32_t grid = p.n_tiles < p.max_grid ? p.n_tiles : p.max_grid;
+        if (p.op_union && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<true, 0u, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.op_union) hipLaunchKernelGGL((k_isect_tiles<false, 0u, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.sub > 1u && desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<true, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.sub > 1u) hipLaunchKernelGGL((k_isect_tiles<false, 0u, false, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (desc_stride(p.n_lists) > 256u) hipLaunchKernelGGL((k_isect_tiles<true, 0u, false>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.n_lists == 2u && !p.sparse_driver) hipLaunchKernelGGL((k_isect_tiles<false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_isect_tiles<false, 0u, false>), dim3(grid), dim3(256), 0, s, p);
     }
-    if (!p.wave_mode) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);

@@ -71,6 +71,8 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     if (p.wmin > p.small_max) p.wmin = p.small_max;
     p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : (cap / 4u) * 3u;   // exact counts: leave slack for uneven lists
 
+    hipEvent_t e0 = nullptr, e1 = nullptr;          // option profile.events: the pair brackets the WHOLE call, first launch to last
+    if (ii2_profile_pair(ctx, &e0, &e1)) (void)hipEventRecord(e0, st);
     // ---- pass 1: decode every input list once into a raw scratch array (grow-only aux buffers) ----
     auto grow = [&](uint8_t *&buf, size_t &cap, size_t bytes) -> bool {
         if (bytes <= cap) return true;
@@ -191,15 +193,14 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
     HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
     HIP_TRY(ctx, hipMemsetAsync(p.tile_count + n_tiles, 0, sizeof(uint32_t), st));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    ii2_profile_pair(ctx, &e0, &e1);
     // 2 workgroups of ~67 KB LDS per CU; each walks tiles w, w+grid, ...
-    HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st, e0, e1));
+    HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
     HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, d_tile_off, st));
     HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
     HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
     if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
+    if (e1) (void)hipEventRecord(e1, st);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (n_tiles == 0) ctx->h_mail[0] = 0;
@@ -215,7 +216,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
 static int check_segs(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs) {
     if (k == 0 || k > MAX_LISTS || !segs) return fail(ctx, II2_EINVAL, "segment count must be 1..64");
     for (uint32_t s = 0; s < k; s++) {
-        if (!segs[s] || segs[s]->ctx != ctx) return fail(ctx, II2_EINVAL, "segment is NULL or belongs to another context");
+        if (!segs[s] || segs[s]->device != ctx->device) return fail(ctx, II2_EINVAL, "segment is NULL or lives on another device");
         if (segs[s]->n_lists != segs[0]->n_lists) return fail(ctx, II2_EINVAL, "segments must be term-aligned (same n_lists)");
     }
     return II2_OK;
@@ -283,7 +284,7 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
     bool any = false;
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t li = list_idx ? list_idx[i] : 0;
-        if (!segs[i] || segs[i]->ctx != ctx || li >= segs[i]->n_lists) return fail(ctx, II2_EINVAL, "ii2_union: bad list");
+        if (!segs[i] || segs[i]->device != ctx->device || li >= segs[i]->n_lists) return fail(ctx, II2_EINVAL, "ii2_union: bad list");
         // a one-term view of the segment: blk_off shifted to the list
         views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_cnt + li, segs[i]->d_blk_list, (uint32_t)li, 0u};
         any |= segs[i]->h_blk_off[li + 1] > segs[i]->h_blk_off[li];

@@ -118,6 +118,15 @@ class Context:
         self._ck(self.lib.ii2_profile_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_region(self, begin: bool) -> None:
+        """Record the start (begin=True) / end event of a region on the ctx stream."""
+        self._ck(self.lib.ii2_profile_region(self.h, 1 if begin else 0))
+
+    def profile_region_ms(self) -> float:
+        ms = C.c_double()
+        self._ck(self.lib.ii2_profile_region_ms(self.h, C.byref(ms)))
+        return ms.value
+
     def selftest(self) -> None:
         self._ck(self.lib.ii2_selftest(self.h))
 

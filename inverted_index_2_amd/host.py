@@ -1,4 +1,4 @@
-"""Python face of the C++ host mirror (csrc/host_index.cpp): the reference's Shard and
+"""Python face of the C++ host mirror (host/host_index.cpp, libii2_host.so): the reference's Shard and
 InvertedIndex operations — Put / Read / Merge / Remove (PutRemoved) / PrefixSearch, plus the
 additive Intersect — with every posting operation executed on the GPU through the C ABI.
 Segments stay in HBM; terms are byte strings.  Errors surface as HostError with the
@@ -6,6 +6,7 @@ reference-style "s: merge: …" prefix."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -24,9 +25,18 @@ class HostError(RuntimeError):
 _typed = False
 
 
+_host = None
+HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libii2_host.so")
+
+
 def _lib_typed():
-    global _typed
-    lib = _lib.load()
+    global _typed, _host
+    if _host is None:
+        _lib.load()                      # libii2_hip.so first: the host library links against it
+        if not os.path.exists(HOST_LIB_PATH):
+            raise RuntimeError(f"{HOST_LIB_PATH} is missing: build it with __graft_entry__.build()")
+        _host = C.CDLL(HOST_LIB_PATH)
+    lib = _host
     if not _typed:
         lib.ii2h_create.restype = vp
         lib.ii2h_create.argtypes = [vp, C.c_int]

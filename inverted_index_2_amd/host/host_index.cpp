@@ -12,15 +12,19 @@
 //   shardKey                                         shard.go:362-378
 //   Intersect(terms)                                 additive
 //
-// A small C facade (ii2h_*) at the bottom lets the Python tests replay the reference's test
-// scripts against this layer.
+// Built as its own library (libii2_host.so) that only sees include/ii2.h and links libii2_hip.so:
+// the product library exports the C ABI and nothing else.  A small C facade (ii2h_*) at the bottom
+// lets the Python tests replay the reference's test scripts against this layer.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ii2.h"
@@ -55,6 +59,18 @@ struct SegHandle {
     SegHandle(const SegHandle &) = delete;
 };
 
+struct DevMem {                // device buffer freed at scope exit
+    ii2_ctx *ctx;
+    void *p = nullptr;
+    explicit DevMem(ii2_ctx *c) : ctx(c) {}
+    ~DevMem() { if (p) ii2_dev_free(ctx, p); }
+    DevMem(const DevMem &) = delete;
+};
+struct TombHandle {
+    ii2_tomb *h = nullptr;
+    ~TombHandle() { ii2_tomb_free(h); }
+};
+
 struct Segment {               // segments.go:16-24
     int64_t key;               // unix-ns key
     std::vector<Term> terms;   // sorted
@@ -62,8 +78,10 @@ struct Segment {               // segments.go:16-24
     bool merging = false;
 };
 
-static int64_t now_ns() {
+static int64_t now_ns() {      // strictly increasing across threads (segment keys order the tombstone batches)
+    static std::mutex mu;
     static int64_t last = 0;
+    std::lock_guard<std::mutex> g(mu);
     int64_t t = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
     if (t <= last) t = last + 1;
     last = t;
@@ -110,8 +128,10 @@ class Shard {
         return r;
     }
 
-    // shard.go:127-245
-    int Merge(int reqCount, int mCount) {
+    // shard.go:127-245.  `worker`: the context (= HIP stream) of the calling worker thread; segments are shared
+    // between contexts of one device, so InvertedIndex.Merge's workers each bring their own (inverted_index.go:83-103)
+    int Merge(int reqCount, int mCount, ii2_ctx *worker = nullptr) {
+        ii2_ctx *ctx = worker ? worker : ctx_;
         if ((int)segments_.size() < reqCount) return 0;
         std::vector<std::shared_ptr<Segment>> picked;
         for (auto &s : segments_) {
@@ -123,7 +143,7 @@ class Shard {
         for (auto &s : picked) segs.push_back(s.get());
         const std::vector<uint32_t> removed = RemovedValues();
         Segment out;
-        const bool any = merged_segment(segs, removed, &out);
+        const bool any = merged_segment(ctx, segs, removed, &out);
         if (any) add(std::move(out));              // lazy writer: nothing survives -> no segment (shard.go:219-225)
         segments_.erase(std::remove_if(segments_.begin(), segments_.end(),
                                        [&](const std::shared_ptr<Segment> &s) {
@@ -168,7 +188,7 @@ class Shard {
         std::vector<Term> terms;
         std::vector<std::shared_ptr<SegHandle>> views;
     };
-    Aligned align(const std::vector<const Segment *> &segs, const Term *min, const Term *max) const {
+    Aligned align(ii2_ctx *ctx, const std::vector<const Segment *> &segs, const Term *min, const Term *max) const {
         Aligned a;
         for (auto *s : segs)
             for (auto &t : s->terms) {
@@ -188,7 +208,7 @@ class Shard {
             }
             if (!any) continue;                    // segment has nothing in range: skipped (shard.go:257-261)
             ii2_seg *v = nullptr;
-            ck(ctx_, ii2_seg_select(ctx_, s->seg->h, a.terms.size(), src.data(), &v), "index read");
+            ck(ctx, ii2_seg_select(ctx, s->seg->h, a.terms.size(), src.data(), &v), "index read");
             a.views.push_back(std::make_shared<SegHandle>(v));
         }
         return a;
@@ -197,10 +217,10 @@ class Shard {
     std::vector<TermValues> merged(const std::vector<const Segment *> &segs, const Term *min, const Term *max,
                                    const std::vector<uint32_t> *removed) const {
         std::vector<TermValues> out;
-        Aligned a = align(segs, min, max);
+        Aligned a = align(ctx_, segs, min, max);
         if (a.views.empty()) return out;
-        ii2_tomb *tomb = nullptr;
-        if (removed && !removed->empty()) ck(ctx_, ii2_tomb_create(ctx_, removed->data(), removed->size(), II2_HOST, &tomb), "s: merge");
+        TombHandle tomb;
+        if (removed && !removed->empty()) ck(ctx_, ii2_tomb_create(ctx_, removed->data(), removed->size(), II2_HOST, &tomb.h), "s: merge");
         std::vector<const ii2_seg *> hs;
         uint64_t cap = 0;
         for (auto &v : a.views) {
@@ -210,19 +230,16 @@ class Shard {
             cap += info.n_postings;
         }
         const uint64_t T = a.terms.size();
-        void *d_off = nullptr, *d_vals = nullptr;
-        ck(ctx_, ii2_dev_alloc(ctx_, (T + 1) * 8, &d_off), "s: merge");
-        ck(ctx_, ii2_dev_alloc(ctx_, (cap + 1) * 4, &d_vals), "s: merge");
+        DevMem d_off(ctx_), d_vals(ctx_);
+        ck(ctx_, ii2_dev_alloc(ctx_, (T + 1) * 8, &d_off.p), "s: merge");
+        ck(ctx_, ii2_dev_alloc(ctx_, (cap + 1) * 4, &d_vals.p), "s: merge");
         ii2_merge_stats st;
-        int rc = ii2_merge_segments(ctx_, (uint32_t)hs.size(), hs.data(), tomb, (uint64_t *)d_off, (uint32_t *)d_vals, cap + 1, &st);
+        std::memset(&st, 0, sizeof st);
+        ck(ctx_, ii2_merge_segments(ctx_, (uint32_t)hs.size(), hs.data(), tomb.h, (uint64_t *)d_off.p, (uint32_t *)d_vals.p, cap + 1, &st), "s: merge");
         std::vector<uint64_t> off(T + 1);
         std::vector<uint32_t> vals(st.n_out);
-        if (!rc) rc = ii2_copy_d2h(ctx_, off.data(), d_off, (T + 1) * 8);
-        if (!rc && st.n_out) rc = ii2_copy_d2h(ctx_, vals.data(), d_vals, st.n_out * 4);
-        ii2_dev_free(ctx_, d_off);
-        ii2_dev_free(ctx_, d_vals);
-        ii2_tomb_free(tomb);
-        ck(ctx_, rc, "s: merge");
+        ck(ctx_, ii2_copy_d2h(ctx_, off.data(), d_off.p, (T + 1) * 8), "s: merge");
+        if (st.n_out) ck(ctx_, ii2_copy_d2h(ctx_, vals.data(), d_vals.p, st.n_out * 4), "s: merge");
         for (uint64_t t = 0; t < T; t++) {
             TermValues tv{a.terms[t], std::vector<uint32_t>(vals.begin() + off[t], vals.begin() + off[t + 1])};
             if (removed && tv.values.empty()) continue;      // merge drops emptied terms (shard.go:192-194)
@@ -232,29 +249,28 @@ class Shard {
     }
 
     // Merge into a new device-resident segment; false when no term survives.
-    bool merged_segment(const std::vector<const Segment *> &segs, const std::vector<uint32_t> &removed, Segment *out) const {
-        Aligned a = align(segs, nullptr, nullptr);
+    bool merged_segment(ii2_ctx *ctx, const std::vector<const Segment *> &segs, const std::vector<uint32_t> &removed, Segment *out) const {
+        Aligned a = align(ctx, segs, nullptr, nullptr);
         if (a.views.empty()) return false;
-        ii2_tomb *tomb = nullptr;
-        if (!removed.empty()) ck(ctx_, ii2_tomb_create(ctx_, removed.data(), removed.size(), II2_HOST, &tomb), "s: merge");
+        TombHandle tomb;
+        if (!removed.empty()) ck(ctx, ii2_tomb_create(ctx, removed.data(), removed.size(), II2_HOST, &tomb.h), "s: merge");
         std::vector<const ii2_seg *> hs;
         for (auto &v : a.views) hs.push_back(v->h);
         ii2_seg *m = nullptr;
         ii2_merge_stats st;
-        int rc = ii2_merge_segments_to_seg(ctx_, (uint32_t)hs.size(), hs.data(), tomb, &m, &st);
-        ii2_tomb_free(tomb);
-        ck(ctx_, rc, "s: merge");
+        std::memset(&st, 0, sizeof st);
+        ck(ctx, ii2_merge_segments_to_seg(ctx, (uint32_t)hs.size(), hs.data(), tomb.h, &m, &st), "s: merge");
         if (!m) return false;
         SegHandle full(m);
         // drop the terms that lost every posting: compacted view over the merged segment
         const uint64_t T = a.terms.size();
         std::vector<uint64_t> off(T + 1);
-        ck(ctx_, ii2_seg_decode(ctx_, m, off.data(), nullptr, II2_HOST), "s: merge");
+        ck(ctx, ii2_seg_decode(ctx, m, off.data(), nullptr, II2_HOST), "s: merge");
         std::vector<int64_t> src;
         for (uint64_t t = 0; t < T; t++)
             if (off[t + 1] > off[t]) { src.push_back((int64_t)t); out->terms.push_back(a.terms[t]); }
         ii2_seg *c = nullptr;
-        ck(ctx_, ii2_seg_select(ctx_, m, src.size(), src.data(), &c), "s: merge");
+        ck(ctx, ii2_seg_select(ctx, m, src.size(), src.data(), &c), "s: merge");
         out->seg = std::make_shared<SegHandle>(c);
         out->key = now_ns();
         return true;
@@ -284,11 +300,40 @@ class InvertedIndex {
     void PutRemoved(const std::vector<uint32_t> &values) {                    // inverted_index.go:41-55
         for (auto &s : shards_) s.second->Remove(values);
     }
-    int64_t Merge(int reqCount, int mCount, int /*concurrency*/) {            // inverted_index.go:62-109
-        int64_t n = 0;
-        for (auto &s : shards_) n += s.second->Merge(reqCount, mCount);
-        return n;
+    // inverted_index.go:62-109: `concurrency` workers pull shards off one queue; every worker owns a context (a HIP
+    // stream with its scratch) on the index's device, the segments are shared.  A worker that fails records the
+    // error and stops pulling, the others drain the queue (the reference's goroutines do the same); concurrency <= 0
+    // starts no worker and merges nothing.
+    int64_t Merge(int reqCount, int mCount, int concurrency) {
+        std::vector<Shard *> shards;
+        for (auto &s : shards_) shards.push_back(s.second.get());
+        if (concurrency <= 0 || shards.empty()) return 0;
+        const size_t nw = std::min<size_t>((size_t)concurrency, shards.size());
+        while (workers_.size() + 1 < nw) {                       // worker 0 uses the index's own context
+            ii2_ctx *c = nullptr;
+            if (ii2_ctx_create(ii2_ctx_device(ctx_), 0, &c)) throw Error(std::string("merge: worker context: ") + ii2_last_error(nullptr));
+            workers_.push_back(c);
+        }
+        std::atomic<size_t> next{0};
+        std::atomic<int64_t> merged{0};
+        std::mutex err_mu;
+        std::string err;
+        auto work = [&](ii2_ctx *c) {
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= shards.size()) return;
+                try { merged += shards[i]->Merge(reqCount, mCount, c); }
+                catch (const std::exception &e) { std::lock_guard<std::mutex> g(err_mu); err = e.what(); return; }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < nw; w++) pool.emplace_back(work, workers_[w - 1]);
+        work(ctx_);
+        for (auto &t : pool) t.join();
+        if (!err.empty()) throw Error(err);
+        return merged.load();
     }
+    ~InvertedIndex() { for (ii2_ctx *c : workers_) ii2_ctx_destroy(c); }
     std::vector<TermValues> Read(const Term *min, const Term *max) const {    // inverted_index.go:300-340
         std::vector<TermValues> out;
         for (auto &s : shards_) {                                             // ascending shard key
@@ -366,6 +411,7 @@ class InvertedIndex {
         return out;
     }
     ii2_ctx *ctx_;
+    std::vector<ii2_ctx *> workers_;                       // contexts of Merge's workers 1..n-1 (created on demand)
     std::map<uint32_t, std::unique_ptr<Shard>> shards_;    // sorted by key, like ii.shards
 };
 

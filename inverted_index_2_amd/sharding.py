@@ -52,3 +52,26 @@ def slice_list_to_docs(ids: np.ndarray, lo: int, hi: int) -> np.ndarray:
 
 def concat_in_rank_order(parts: Sequence[np.ndarray]) -> np.ndarray:
     return np.concatenate(list(parts)) if len(parts) else np.empty(0, np.uint32)
+
+
+def balanced_term_ranges(n_terms: int, mean_len: float, universe: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous term ranges of the big synthetic merge workload, one per rank, balanced by POSTING count (Zipf skew:
+    equal term counts would give rank 0 most of the work — SURVEY §8 e), cut at the generator's chunk boundaries so
+    that every rank can generate exactly its own share."""
+    from . import synth
+    sizes, fine = synth.merge_chunk_bounds(n_terms, mean_len, universe)
+    cum = np.concatenate([[0], np.cumsum(sizes)])
+    total = int(cum[-1])
+    fine = np.asarray(fine)
+    cuts = [0]
+    for r in range(1, world):
+        want = total * r / world
+        j = int(np.argmin(np.abs(cum[fine] - want)))
+        c = int(fine[j])
+        c = max(c, cuts[-1])
+        cuts.append(c)
+    cuts.append(n_terms)
+    for r in range(1, world + 1):                 # strictly increasing where possible (tiny inputs may leave empty ranks)
+        if cuts[r] < cuts[r - 1]:
+            cuts[r] = cuts[r - 1]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]

@@ -58,18 +58,16 @@ while time.time() < t_end:
         seg = ctx.import_dv1(int(flat.size), blk, skip, payload)       # the imported copy serves the rest of the iteration
     # intersect (all option combinations that change the kernel path)
     want = orc.intersect(lists, ref_rm)
-    for bm, bm2 in ((1, 0), (0, 0), (1, 1)):
-        if bm2 and k > 4:
-            continue
-        ctx.set_option("intersect.bitmap", bm); ctx.set_option("intersect.bm2", bm2)
+    for bm in (1, 0):
+        ctx.set_option("intersect.bitmap", bm)
         out, n = ctx.intersect([(seg, i) for i in range(k)], tomb=tomb)
         got = out.download(n)
         if n != want.size or not np.array_equal(got, want):
-            print("MISMATCH intersect", it, "seed", seed, "k", k, "universe", universe, "sizes", [l.size for l in lists], "bm", bm, "bm2", bm2, n, want.size)
+            print("MISMATCH intersect", it, "seed", seed, "k", k, "universe", universe, "sizes", [l.size for l in lists], "bm", bm, n, want.size)
             os.makedirs("gpurun_out", exist_ok=True)
             np.savez_compressed("gpurun_out/stress_fail.npz", got=got, want=want, removed=removed if removed is not None else np.empty(0, np.uint32), **{"list%d" % i: l for i, l in enumerate(lists)})
             sys.exit(1)
-    ctx.set_option("intersect.bitmap", 1); ctx.set_option("intersect.bm2", 0)
+    ctx.set_option("intersect.bitmap", 1)
     # union
     wantu = orc.union(lists)
     if removed is not None:

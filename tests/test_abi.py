@@ -31,6 +31,29 @@ def test_library_exports_every_declared_symbol():
     assert _lib.load().ii2_abi_version() == 1
 
 
+def test_library_exports_nothing_but_the_header():
+    """libii2_hip.so's dynamic symbol table is exactly include/ii2.h (the host mirror lives in libii2_host.so)."""
+    import subprocess
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({line.split()[-1].split("@")[0] for line in out.splitlines() if line.strip() and " T " in line or " W " in line})
+    assert exported == _header_symbols(), sorted(set(exported) ^ set(_header_symbols()))
+
+
+def test_host_mirror_is_a_separate_library_over_the_abi():
+    from inverted_index_2_amd import host
+    if not os.path.exists(host.HOST_LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = C.CDLL(_lib.LIB_PATH)        # dependency first
+    h = C.CDLL(host.HOST_LIB_PATH)
+    assert hasattr(h, "ii2h_create") and not hasattr(lib, "ii2h_create")
+    src = open(os.path.join(ROOT, "inverted_index_2_amd", "host", "host_index.cpp")).read()
+    assert "internal.h" not in src and "hip/hip_runtime" not in src      # only include/ii2.h
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

@@ -37,4 +37,4 @@ def test_bench_argument_contract():
         a = b.parse()
     finally:
         sys.argv = argv
-    assert (a.gpus, a.steps, a.warmup, a.workload) == (1, 7, 2, "intersect")
+    assert (a.gpus, a.steps, a.warmup, a.workload) == (1, 7, 2, "all")

@@ -101,6 +101,11 @@ def test_import_rejects_malformed_segment(ctx):
     with pytest.raises(II2Error):
         ctx.import_dv1(a.size, bad2, skip, payload)
     ctx.import_dv1(a.size, blk, skip, payload)      # the intact one is accepted
+    # n_postings sizes the decode buffers: a count that differs from what the blocks hold is refused either way
+    for wrong in (a.size - 1, a.size + 1, 0):
+        with pytest.raises(II2Error) as e:
+            ctx.import_dv1(wrong, blk, skip, payload)
+        assert e.value.code == -1
     # block fill rule: every block but a list's last holds 256 postings (the merge places decoded blocks by it).
     # Build a 3-block list by hand whose MIDDLE block is short: structurally fine, but refused.
     def enc(ids):

@@ -13,22 +13,13 @@ def _check(ctx, lists, removed=None):
     seg = ctx.encode_lists(lists)
     tomb = ctx.tombstones(removed) if removed is not None else None
     want = orc.intersect(lists, np.sort(removed) if removed is not None else ())
-    for wave in (0, 1):        # workgroup-level tile kernel, wave-level tile kernel (2..4 lists)
-        ctx.set_option("intersect.wave", wave)
+    for bitmap in (1, 0):      # very dense tiles: per-list bitmaps (default) vs the byte map
+        ctx.set_option("intersect.bitmap", bitmap)
         out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
         got = out.download(n)
-        assert n == want.size, (wave, n, want.size)
-        assert np.array_equal(got, want), wave
-    ctx.set_option("intersect.wave", 0)
-    ctx.set_option("intersect.bitmap", 0)      # very dense tiles: per-list bitmaps (default) vs the byte map
-    out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
+        assert n == want.size, (bitmap, n, want.size)
+        assert np.array_equal(got, want), bitmap
     ctx.set_option("intersect.bitmap", 1)
-    assert n == want.size and np.array_equal(out.download(n), want)
-    if len(lists) <= 4:                        # the experimental bitmap tile kernel (dense queries; off by default)
-        ctx.set_option("intersect.bm2", 1)
-        out, n = ctx.intersect([(seg, i) for i in range(len(lists))], tomb=tomb)
-        ctx.set_option("intersect.bm2", 0)
-        assert n == want.size and np.array_equal(out.download(n), want)
     # split over two segments as well (lists from different segments)
     if len(lists) >= 2:
         s0, s1 = ctx.encode_lists(lists[:1]), ctx.encode_lists(lists[1:])
