@@ -580,6 +580,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     // tile height: aim the tile's doc span at the LDS byte map; keep >= ~8 tiles per CU
     uint32_t G = 1;
     double per_block_span = 0;                   // docs per driver block (tile-height heuristics)
+    uint32_t dense_first_doc = 0, dense_last_doc = 0;
     if (ctx->opt_intersect_g > 0) G = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, ISECT_GMAX);
     else if (nblk0 > 1) {
         const ii2_seg *dseg = nullptr;
@@ -608,9 +609,55 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         }
         const double per_block = (double)(ends.last_block_first_doc - ends.first_doc) / (double)(nblk0 - 1);
         per_block_span = per_block;
+        dense_first_doc = ends.first_doc;
+        dense_last_doc = ends.last_doc;
         const double g = per_block > 0 ? 0.85 * ISECT_SMAX / per_block : ISECT_GMAX;
         G = g >= ISECT_GMAX ? ISECT_GMAX : g < 1 ? 1u : (uint32_t)g;
         while (G > 1 && nblk0 / G < 8u * (uint32_t)ctx->cu_count) G >>= 1;
+    }
+    // Lists that are dense together (the headline 2-term query): every wave streams through its own run of driver
+    // blocks, no partition pass, no workgroup barriers (intersect_dense.hip).  The driver must be dense enough for
+    // the 1-bit-per-doc result bitmap to stay small next to the payload.
+    if (ctx->opt_intersect_dense && ctx->opt_intersect_g <= 0 && n >= 2 && n <= DENSE_MAXL && nblk0 >= 1024 &&
+        per_block_span > 0 && per_block_span <= 2048.0) {
+        DenseParams dp;
+        std::memset(&dp, 0, sizeof dp);
+        for (uint32_t i = 0; i < n; i++) dp.lists[i] = views[i];
+        dp.n_lists = n;
+        // one generation of waves: the tile kernel holds 8 waves per SIMD (<= 64 VGPRs), and a second, partly filled round of
+        // workgroups would cost as much as a full one
+        const uint32_t resident = (uint32_t)ctx->cu_count * 4u * 8u;
+        uint32_t bpw = ctx->opt_dense_bpw > 0 ? (uint32_t)ctx->opt_dense_bpw : std::max<uint32_t>(8u, (nblk0 + resident - 1u) / resident);
+        bpw = std::min<uint32_t>(std::max<uint32_t>((bpw + 3u) & ~3u, 4u), 60u);
+        dp.bpw = bpw;
+        dp.n_waves = (nblk0 + bpw - 1) / bpw;
+        const uint32_t grid = (dp.n_waves + 3u) / 4u;
+        dp.n_meta = grid * 4u;
+        dp.base32 = dense_first_doc & ~31u;
+        const uint64_t bm_words = (((uint64_t)dense_last_doc - dp.base32) >> 5) + 1 + dp.n_meta + 8;
+        size_t need = align_up(bm_words * sizeof(uint32_t)) + align_up((size_t)dp.n_meta * sizeof(uint4)) + align_up((size_t)grid * sizeof(uint32_t)) + 4096;
+        int rc = ii2_ws_reserve(ctx, need);
+        if (rc) return rc;
+        dp.bitmap = ws_take<uint32_t>(ctx, bm_words);
+        dp.meta = ws_take<uint4>(ctx, dp.n_meta);
+        dp.wg_sum = ws_take<uint32_t>(ctx, grid);
+        dp.tomb = tomb ? tomb->d_words : nullptr;
+        dp.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+        dp.out = d_out;
+        dp.out_cap = cap;
+        dp.d_count = d_count;
+        dp.debug = nullptr;
+        if (ctx->opt_debug_stamps) {
+            if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
+                return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_debug, 0, (size_t)2048 * 8 * sizeof(unsigned long long), st));
+            dp.debug = ctx->d_debug;
+            dp.debug_expand = ctx->opt_debug_stamps == 2 ? 1u : 0u;
+        }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ii2_profile_pair(ctx, &e0, &e1);
+        HIP_TRY(ctx, launch_intersect_dense(dp, st, e0, e1));
+        return II2_OK;
     }
     // a tiny sparse driver (a rare term against long lists) would keep only a handful of workgroups busy, each decoding
     // one block of the long list per candidate, one after the other: split its blocks over several tiles
@@ -654,7 +701,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.d_count = d_count;
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
-        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)ctx->cu_count * 8 * 8 * sizeof(unsigned long long)) != hipSuccess)
+        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }
@@ -779,7 +826,7 @@ int ii2_selftest(ii2_ctx *ctx) {
 int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words) {
     if (!ctx || !out || !ctx->d_debug) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
-    const uint64_t have = (uint64_t)ctx->cu_count * 8 * 8;
+    const uint64_t have = (uint64_t)2048 * 8;
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_debug, std::min(n_words, have) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return II2_OK;
@@ -797,6 +844,8 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
     else if (k == "union.dense") ctx->opt_union_dense = value;
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
+    else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
+    else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

@@ -39,6 +39,8 @@ struct ii2_ctx {
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
+    int64_t opt_intersect_dense = 1;    // dense 2..4-list queries go to the wave-streaming kernels (intersect_dense.hip)
+    int64_t opt_dense_bpw = 0;          // driver blocks per wave there (0 = default)
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
@@ -145,6 +147,29 @@ struct IntersectParams {
     uint32_t op_union;           // 1: OR instead of AND — fixed doc-range tiles [u_base + t * u_span, ...], every list searched per tile
     uint32_t u_base, u_span, u_max;
 };
+
+// dense streaming intersection (intersect_dense.hip)
+constexpr uint32_t DENSE_MAXL = 4;             // lists it takes
+constexpr uint32_t DENSE_CAPW = 8192;          // docs per LDS window of a wave
+struct DenseParams {
+    ListView lists[DENSE_MAXL];  // lists[0] is the driver (fewest blocks)
+    uint32_t n_lists;
+    uint32_t bpw;                // driver blocks per wave (a multiple of 4)
+    uint32_t n_waves;            // waves with work; the grid is ceil(n_waves / 4) workgroups
+    uint32_t n_meta;             // entries of meta (4 per workgroup)
+    uint32_t base32;             // first doc of the driver & ~31: origin of the result bitmap
+    uint32_t tomb_nwords;
+    const uint32_t *tomb;        // may be null
+    uint32_t *bitmap;            // result bits; wave w's slot starts at word ((its first doc & ~31) - base32) / 32 + w
+    uint4 *meta;                 // per wave {first doc & ~31, words, ids, -}
+    uint32_t *wg_sum;            // ids per workgroup
+    uint32_t *out;
+    uint64_t out_cap;
+    uint64_t *d_count;
+    unsigned long long *debug;   // optional per-workgroup cycle counters [2048][8] (diagnostics)
+    uint32_t debug_expand;       // the counters are the expand kernel's (option debug.stamps = 2), else the tile kernel's
+};
+hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
 hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s);

@@ -1,0 +1,470 @@
+// intersect_dense.hip — intersection of lists that are DENSE TOGETHER (the 2-term query over a 100M-doc index of
+// BASELINE configs[1] and its relatives), gfx950, wave64, no MFMA.
+//
+// The general tile kernel (intersect.hip) spends ~40 % of its time at workgroup barriers and needs a partition
+// pre-pass and a per-64-tile sum pass around it.  Here every WAVE is on its own:
+//   * a wave owns a run of consecutive driver blocks and streams through it four blocks (one 16-lane DPP row per
+//     block, 16 gap bytes per lane, loaded straight from HBM in decode layout) at a time — a ROUND;
+//   * where the other lists enter the wave's doc range is found once (64-ary search of their skip tables); after
+//     that the wave keeps 64 skip entries of every list in registers and advances through them two-pointer style:
+//     no descriptors, no partition kernel, no search per tile;
+//   * a round marks the postings of every list in wave-private LDS bitmaps ((M << gap) | 1 builds the mask of four
+//     postings in registers, one 64-bit shift positions it, at most two ds_or per four postings), ANDs them, clears
+//     the tombstoned bits and stores the result words into the wave's slot of a result bitmap (1 bit per doc) in HBM;
+//   * waves never wait for each other: no workgroup barrier inside the loop, no inter-workgroup hand-off.
+// A second kernel turns the result bitmap into the ascending id array: the offset of a wave's ids is the sum of the
+// workgroup counts before it plus the wave counts inside its workgroup — computed in that kernel's prologue (no
+// separate sum pass).
+//
+// Exact for any input the general kernel accepts (multi-byte gaps, short blocks, sparse stretches take slower
+// paths inside the same loop); the host only picks this kernel when the driver is dense enough for the result
+// bitmap to be small (api.cpp).
+#include <algorithm>
+
+#include "dv1_device.h"
+#include "internal.h"
+
+namespace ii2 {
+
+constexpr uint32_t DN_GU = 128;                               // guard bits below and above a window
+constexpr uint32_t DN_CAPW = DENSE_CAPW;                      // docs a window covers (multiple of 32)
+constexpr uint32_t DN_NW = ((DN_CAPW + 2 * DN_GU) / 32 + 2 + 3) & ~3u;    // words of one LDS bitmap (a multiple of 4: 16-byte clears)
+constexpr uint32_t DN_WAVE_LDS = 2 * DN_NW + 4;               // two bitmaps + the carry word (+ pad)
+
+// first index i in [0, n) with skip[i].first_doc > x, searched 64 ways per round by the whole wave
+__device__ __forceinline__ uint32_t wave_skip_upper_bound(const ii2_skip *__restrict__ skip, uint32_t n, uint32_t x) {
+    const uint32_t l = (uint32_t)lane_id();
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t sp = hi - lo;
+        const uint32_t st = (sp + 63u) >> 6;
+        const uint32_t pos = lo + l * st;
+        const bool in = pos < hi;
+        const uint32_t f = in ? skip[pos].first_doc : 0u;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(in && f <= x));     // probes are ascending: the matches are a prefix
+        const uint32_t nin = (uint32_t)__popcll(__ballot(in));
+        if (st == 1u) return cnt < nin ? lo + cnt : hi;
+        const uint32_t nlo = cnt ? lo + (cnt - 1u) * st + 1u : lo;
+        hi = cnt < nin ? lo + cnt * st : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// Five consecutive skip entries of a list as SCALARS: the tables are read-only for the kernel, so they are read through
+// the constant address space (s_load, scalar cache) — a pass needs its four blocks' entries plus the next one's byte
+// offset, and everything the generator decides from them (how many rows are valid, where the round ends) is SALU work.
+typedef __attribute__((address_space(4))) const uint32_t *cu32p;
+struct Ent5 { uint32_t f[5], o[5]; };
+__device__ __forceinline__ Ent5 ent_load(const ii2_skip *skip, uint32_t nblk, uint32_t at) {
+    cu32p s = (cu32p)(uintptr_t)skip;
+    Ent5 e;
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; k++) {
+        const uint32_t i = at + k < nblk ? at + k : nblk;      // entry nblk is readable: its byte_off bounds the last block's payload
+        e.f[k] = s[2u * i];
+        e.o[k] = s[2u * i + 1u];
+    }
+    return e;
+}
+__device__ __forceinline__ uint32_t row_sel(uint32_t row, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+    return row == 0u ? a0 : row == 1u ? a1 : row == 2u ? a2 : a3;
+}
+
+// One PASS = up to four blocks of one list (one per 16-lane row) against one window.  The wave's work is a sequence of
+// passes produced by a small generator (scalar code over the skip entries); the 16 payload bytes of every lane for
+// pass k + 1 are fetched before pass k is marked, so a wave always has one HBM request in flight.
+struct Pass {
+    const uint8_t *payload;      // wave-uniform
+    uint32_t wlo, wspan;         // the window the pass marks into (wave-uniform)
+    uint32_t flags;              // PF_* (wave-uniform)
+    uint32_t nvalid;             // rows with a block (wave-uniform)
+    bool rv;                     // per lane: my row has a block
+    uint32_t f, q0, q1;          // per lane: my row's first doc and payload byte range
+};
+enum : uint32_t { PF_VALID = 1u, PF_FIRST = 2u, PF_LAST = 4u, PF_TOB = 8u, PF_FOLD = 16u, PF_FULL = 32u };
+// first / last pass of a window, marks into B, fold B into A first, every valid row is a full block of 255 payload bytes
+
+template <uint32_t NL>
+__global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
+    __shared__ __align__(16) uint32_t lds[4][DN_WAVE_LDS];
+    __shared__ uint32_t wcnt[4];
+    const int l = lane_id();
+    const uint32_t wv = uni(threadIdx.x >> 6);
+    const uint32_t rl = (uint32_t)l & 15u, row = (uint32_t)l >> 4;
+    const uint32_t w = blockIdx.x * 4u + wv;                 // this wave's number in doc order
+    uint32_t *bmA = lds[wv], *bmB = bmA + DN_NW, *carry = bmB + DN_NW;
+    const ListView drv = p.lists[0];
+    const uint32_t b0 = w * p.bpw;
+    const uint32_t b1 = b0 + p.bpw < drv.nblk ? b0 + p.bpw : drv.nblk;
+    uint32_t count = 0, mlo_w = 0, nwords_w = 0;
+    // diagnostics only (option debug.stamps): cycles of this wave per part of the loop
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    const bool stamps = p.debug != nullptr && !p.debug_expand;
+#define II2_STAMP(i)                                                    \
+    if (stamps) {                                                       \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();    \
+        tacc[i] += tn_ - tprev;                                         \
+        tprev = tn_;                                                    \
+    }
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
+
+    if (b0 < b1) {                                           // wave-uniform
+        Ent5 E = ent_load(drv.skip, drv.nblk, b0);           // entries the next gen() call consumes
+        const uint32_t drv_last = uni(*drv.last_doc);
+        const uint32_t lo_w = E.f[0];
+        const uint32_t hi_w = b1 < drv.nblk ? ((cu32p)(uintptr_t)drv.skip)[2u * b1] - 1u : drv_last;
+        mlo_w = lo_w & ~31u;
+        nwords_w = ((hi_w - mlo_w) >> 5) + 1u;
+        uint32_t *slot = p.bitmap + (size_t)((mlo_w - p.base32) >> 5) + w;      // slots of neighbouring waves never overlap (+ w)
+        if (l == 0) { carry[0] = 0u; carry[1] = 0xFFFFFFFFu; }
+
+        // where the other lists enter this wave's doc range: the last block that starts at or before lo_w
+        uint32_t a[NL > 1 ? NL - 1 : 1];
+#pragma unroll
+        for (uint32_t j = 1; j < NL; j++) {
+            const uint32_t ub = uni(wave_skip_upper_bound(p.lists[j].skip, p.lists[j].nblk, lo_w));
+            a[j - 1] = ub ? ub - 1u : 0u;
+        }
+
+        // ---- the pass generator: scalar state, scalar loads ----
+        uint32_t gb = b0;                     // driver block of the round being generated
+        uint32_t g_hi = 0, g_wlo = 0;         // its last doc; the window being generated
+        uint32_t g_stage = 0;                 // 0: driver pass next; j >= 1: passes of list j
+        uint32_t g_cur = 0;                   // next block of list g_stage
+        bool g_new = true;                    // E holds the driver entries of a round whose range is not set up yet
+        bool g_first = false;                 // next pass of list g_stage is its first in this window
+        bool g_done = false;
+        auto gen = [&]() -> Pass {
+            Pass P;
+            P.payload = drv.payload; P.flags = 0u; P.nvalid = 0u; P.rv = false; P.f = 0u; P.q0 = 0u; P.q1 = 0u;
+            P.wlo = 0u; P.wspan = 0u;
+            if (g_done) return P;
+            if (g_stage == 0u) {
+                const uint32_t nbk = b1 - gb < 4u ? b1 - gb : 4u;
+                if (g_new) {
+                    g_hi = gb + nbk < drv.nblk ? row_sel(nbk - 1u, E.f[1], E.f[2], E.f[3], E.f[4]) - 1u : drv_last;
+                    g_wlo = E.f[0] & ~31u;
+                    g_new = false;
+                }
+            }
+            P.wlo = g_wlo;
+            P.wspan = g_hi - g_wlo < DN_CAPW ? g_hi - g_wlo : DN_CAPW - 1u;
+            const uint32_t j = g_stage;
+            uint32_t nvalid;
+            if (j == 0u) {
+                nvalid = b1 - gb < 4u ? b1 - gb : 4u;
+                P.flags = PF_VALID | PF_FIRST;
+            } else {
+                const uint32_t whi = g_wlo + P.wspan;
+                const uint32_t nblk_j = p.lists[j].nblk;
+                P.payload = p.lists[j].payload;
+                nvalid = 0u;                                                  // first docs ascend: the valid rows are a prefix
+#pragma unroll
+                for (uint32_t r = 0; r < 4u; r++)
+                    if (nvalid == r && g_cur + r < nblk_j && E.f[r] <= whi) nvalid = r + 1u;
+                P.flags = PF_VALID | PF_TOB | ((g_first && j > 1u) ? PF_FOLD : 0u);
+                g_first = false;
+            }
+            bool full = true;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; r++) full = full && (r >= nvalid || E.o[r + 1u] - E.o[r] == 255u);
+            if (full) P.flags |= PF_FULL;
+            P.nvalid = nvalid;
+            P.rv = row < nvalid;
+            P.f = row_sel(row, E.f[0], E.f[1], E.f[2], E.f[3]);
+            P.q0 = row_sel(row, E.o[0], E.o[1], E.o[2], E.o[3]);
+            P.q1 = row_sel(row, E.o[1], E.o[2], E.o[3], E.o[4]);
+            // advance; the entries of the next pass are requested now and used one pass later
+            uint32_t nj = j, ncur = g_cur + nvalid;
+            if (j == 0u) {
+                if (NL == 1u) nj = NL;             // (single list: the window is complete)
+                else { nj = 1u; ncur = a[0]; g_first = true; }
+            } else if (nvalid < 4u) {              // list j is done for this window; its last block in the window may reach past it
+#pragma unroll
+                for (uint32_t jj = 1; jj < NL; jj++)
+                    if (jj == j && ncur > a[jj - 1] + 1u) a[jj - 1] = ncur - 1u;
+                nj = j + 1u;
+                if (nj < NL) {
+#pragma unroll
+                    for (uint32_t jj = 1; jj < NL; jj++) if (jj == nj) ncur = a[jj - 1];
+                    g_first = true;
+                }
+            }
+            if (nj >= NL) {                        // window complete
+                P.flags |= PF_LAST;
+                nj = 0u;
+                if (g_hi - g_wlo < DN_CAPW) {      // round complete
+                    gb += 4u;
+                    g_new = true;
+                    if (gb >= b1) g_done = true;
+                } else g_wlo += DN_CAPW;
+                ncur = gb;
+            }
+            g_stage = nj;
+            g_cur = ncur;
+            if (!g_done) E = ent_load(p.lists[nj].skip, p.lists[nj].nblk, ncur);
+            return P;
+        };
+        auto fetch = [&](const Pass &P) -> uint4 {
+            const uint32_t len = P.rv ? P.q1 - P.q0 : 0u;
+            uint4 g = make_uint4(0, 0, 0, 0);
+            if (len > 16u * rl) __builtin_memcpy(&g, P.payload + P.q0 + 16u * rl, 16);     // segments carry 16 bytes of padding
+            return g;
+        };
+
+        // ---- marking one pass: four blocks, one per 16-lane row, into bm for the window [wlo, wlo + wspan]; exact for any block ----
+        auto mark_rows = [&](const Pass &P, uint4 g, uint32_t *bm) {
+            const uint32_t wlo = P.wlo, wspan = P.wspan;
+            const bool rv = P.rv;
+            const uint32_t f = P.f;
+            const uint32_t len = rv ? P.q1 - P.q0 : 0u;
+            const uint32_t myoff = 16u * rl;
+            const uint32_t nb = len > myoff ? (len - myoff < 16u ? len - myoff : 16u) : 0u;
+            if (P.flags & PF_FULL) {                 // 255 bytes per row: only the row's last lane has a byte that is not its own
+                if (rl == 15u) g.w &= 0x00FFFFFFu;
+            } else if (nb < 16u) {
+                const uint32_t n0 = nb < 4u ? nb : 4u, n1 = nb < 4u ? 0u : (nb < 8u ? nb - 4u : 4u);
+                const uint32_t n2 = nb < 8u ? 0u : (nb < 12u ? nb - 8u : 4u), n3 = nb < 12u ? 0u : nb - 12u;
+                g.x &= n0 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n0)) - 1u);
+                g.y &= n1 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n1)) - 1u);
+                g.z &= n2 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n2)) - 1u);
+                g.w &= n3 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n3)) - 1u);
+            }
+            auto setbit = [&](uint32_t id, bool valid) {                       // exact range test: any id, any gap
+                const uint32_t d = id - wlo;
+                if (valid && d <= wspan) atomicOr(&bm[(d + DN_GU) >> 5], 1u << ((d + DN_GU) & 31u));
+            };
+            // rows whose block has multi-byte gaps (or more than 256 payload bytes): the general one-wave-per-block decoder
+            const bool hard = rv && (len > 256u || (((g.x | g.y | g.z | g.w) & 0x80808080u) != 0u));
+            const unsigned long long hm = __ballot(hard);
+            if (hm != 0ull) {
+#pragma unroll 1
+                for (int r = 0; r < 4; r++) {
+                    if (((hm >> (16 * r)) & 0xFFFFull) == 0ull) continue;
+                    const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)f, 16 * r), q0r = (uint32_t)__builtin_amdgcn_readlane((int)P.q0, 16 * r),
+                                   q1r = (uint32_t)__builtin_amdgcn_readlane((int)P.q1, 16 * r);
+                    decode_block_wave4(GlobalBytes{P.payload}, q0r, q1r, fq,
+                                       [&](uint32_t, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                                           setbit(id0, mask & 1u); setbit(id1, mask & 2u); setbit(id2, mask & 4u); setbit(id3, mask & 8u);
+                                       });
+                }
+            }
+            const bool rowhard = ((hm >> (16u * row)) & 0xFFFFull) != 0ull;
+            const bool live = rv && !rowhard;
+            const uint32_t ww[4] = {g.x, g.y, g.z, g.w};
+            uint32_t ss[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) ss[k] = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u);
+            const uint32_t s = live ? ss[0] + ss[1] + ss[2] + ss[3] : 0u;
+            const uint32_t incl = row_incl_scan(s);
+            const uint32_t base = f + incl - s;                                  // id of the posting right before my bytes
+            const uint32_t u = base - wlo + DN_GU;                               // its (guard-shifted) position, mod 2^32
+            const uint32_t smax = max(max(ss[0], ss[1]), max(ss[2], ss[3]));
+            const bool narrow = smax <= 31u;                                     // every group of four postings fits a 32-bit mask
+            // narrow lanes span < 128 docs: one that starts outside [wlo - GU, wlo + wspan] lies wholly outside the window
+            const bool fast = live && narrow && u <= wspan + DN_GU;
+            if (fast) {
+                // a group's mask starts AT the posting before it (bit 0 = position q: the block's first doc for the row's
+                // first lane, else a posting an earlier group already set — setting it again is harmless), so no separate
+                // store for posting 0 and no add per group
+                uint32_t q = u;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = ww[k];
+                    uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;                 // posting 3 and posting 2's slot
+                    M = (M << ((x >> 16) & 31u)) | 1u;
+                    M = (M << ((x >> 8) & 31u)) | 1u;
+                    M = (M << (x & 31u)) | 1u;                                   // bit 0: the posting before the group
+                    const unsigned long long MM = (unsigned long long)M << (q & 31u);
+                    uint32_t *dst = bm + (q >> 5);                               // q < wspan + 2 GU: no clamp needed
+                    atomicOr(dst, (uint32_t)MM);
+                    if ((uint32_t)(MM >> 32)) atomicOr(dst + 1, (uint32_t)(MM >> 32));
+                    q += ss[k];
+                }
+            }
+            if (__ballot(live && !narrow) != 0ull) {                             // rare: wide gaps, posting by posting
+                if (live && !narrow) {
+                    uint32_t id = base;
+                    setbit(f, rl == 0u);
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        id += (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                        setbit(id, (uint32_t)k < nb);
+                    }
+                }
+            }
+        };
+
+        auto finalise = [&](uint32_t wlo, uint32_t wspan) {
+            // AND, tombstones, count, store to the wave's slot (wave-private LDS: program order is enough); two words per lane
+            const uint32_t nw = (wspan >> 5) + 1u;
+            const uint32_t sbase = (wlo - mlo_w) >> 5;
+            for (uint32_t i = 2u * (uint32_t)l; i < nw; i += 128u) {
+                const uint2 ra = *reinterpret_cast<const uint2 *>(&bmA[DN_GU / 32u + i]);
+                uint32_t r0 = ra.x, r1 = ra.y;
+                if (NL > 1u) {
+                    const uint2 rb = *reinterpret_cast<const uint2 *>(&bmB[DN_GU / 32u + i]);
+                    r0 &= rb.x; r1 &= rb.y;
+                }
+                const bool has1 = i + 1u < nw;
+                if (!has1) r1 = 0u;
+                if ((wspan & 31u) != 31u) {
+                    const uint32_t tm = (2u << (wspan & 31u)) - 1u;
+                    if (i == nw - 1u) r0 &= tm;
+                    if (i + 1u == nw - 1u) r1 &= tm;
+                }
+                if (p.tomb) {
+                    const uint32_t tw = (wlo >> 5) + i;
+                    if (tw < p.tomb_nwords) r0 &= ~p.tomb[tw];
+                    if (has1 && tw + 1u < p.tomb_nwords) r1 &= ~p.tomb[tw + 1u];
+                }
+                count += (uint32_t)__popc(r0) + (uint32_t)__popc(r1);
+                // the word that holds this round's first doc may also hold the previous round's last docs
+                if (i == 0u && carry[1] == sbase) r0 |= carry[0];
+                slot[sbase + i] = r0;
+                if (has1) slot[sbase + i + 1u] = r1;
+                if (i == nw - 1u) { carry[0] = r0; carry[1] = sbase + i; }
+                if (has1 && i + 1u == nw - 1u) { carry[0] = r1; carry[1] = sbase + i + 1u; }
+            }
+        };
+        auto clear = [&](uint32_t *bm, uint32_t ncl) {       // 16 bytes per lane
+            for (uint32_t i = 4u * (uint32_t)l; i < ncl; i += 256u) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
+        };
+
+        Pass P = gen();
+        uint4 g = fetch(P);
+        II2_STAMP(0)          // prologue: searches, first entries, first fetch issued
+        while (P.flags & PF_VALID) {
+            if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            II2_STAMP(2)      // waiting for the prefetched payload
+            const Pass Q = gen();
+            const uint4 gq = fetch(Q);                        // in flight while P is marked
+            II2_STAMP(1)      // generator + fetch issue
+            const uint32_t nw = (P.wspan >> 5) + 1u;
+            const uint32_t ncl = nw + 2u * (DN_GU / 32u) + 2u;   // <= DN_NW - 2; cleared in 4-word steps
+            if (P.flags & PF_FIRST) { clear(bmA, ncl); clear(bmB, ncl); }
+            if (P.flags & PF_FOLD) {
+                for (uint32_t i = (uint32_t)l; i < nw; i += 64u) bmA[DN_GU / 32u + i] &= bmB[DN_GU / 32u + i];
+                clear(bmB, ncl);
+            }
+            II2_STAMP(3)      // clear / fold
+            if (P.nvalid != 0u) mark_rows(P, g, (P.flags & PF_TOB) ? bmB : bmA);
+            II2_STAMP(4)      // mark
+            if (P.flags & PF_LAST) finalise(P.wlo, P.wspan);
+            II2_STAMP(5)      // finalise
+            P = Q;
+            g = gq;
+        }
+        count = wave_sum(count);
+    }
+    if (stamps && l == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&p.debug[(uint64_t)(blockIdx.x % 2048u) * 8u + i], tacc[i]);
+#undef II2_STAMP
+    if (l == 0) {
+        wcnt[wv] = count;
+        if (w < p.n_meta) p.meta[w] = make_uint4(mlo_w, nwords_w, count, 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) p.wg_sum[blockIdx.x] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+// ---- expand: the waves' result bitmaps -> the final ascending id array --------------------------------------
+// Workgroup g expands the slots of tile workgroup g (same decomposition).  Its output offset = the counts of the
+// workgroups before it, summed here by all 256 threads (a few thousand words) — no separate scan launch.
+constexpr uint32_t DX_PRE = 8;              // slot words a lane fetches up front (covers 512 words per wave; longer slots loop)
+__global__ __launch_bounds__(256) void k_dense_expand(DenseParams p) {
+    __shared__ __align__(16) uint16_t stage[4][2048];       // ids of a round as offsets from the round's first doc
+    __shared__ unsigned long long wsum[4];
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
+    const uint32_t w0 = blockIdx.x * 4u;
+    const uint32_t w = w0 + (uint32_t)wv;
+    unsigned long long tacc[4] = {0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    const bool stamps = p.debug != nullptr && p.debug_expand;
+#define II2_STAMP(i)                                                    \
+    if (stamps) {                                                       \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();    \
+        tacc[i] += tn_ - tprev;                                         \
+        tprev = tn_;                                                    \
+    }
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
+    // this wave's slot words first: they are independent of the offset arithmetic below
+    const uint4 m = w < p.n_meta ? p.meta[w] : make_uint4(0, 0, 0, 0);
+    const uint32_t *slot = p.bitmap + (size_t)((m.x - p.base32) >> 5) + w;
+    uint32_t pre[DX_PRE];
+#pragma unroll
+    for (uint32_t k = 0; k < DX_PRE; k++) {
+        const uint32_t i = 64u * k + (uint32_t)l;
+        pre[k] = (m.z != 0u && i < m.y) ? slot[i] : 0u;
+    }
+    unsigned long long mine = 0;
+    for (uint32_t g = (uint32_t)tid; g < blockIdx.x; g += 256u) mine += p.wg_sum[g];
+    for (int d = 32; d >= 1; d >>= 1) mine += (unsigned long long)__shfl_xor((long long)mine, d, 64);
+    if (l == 0) wsum[wv] = mine;
+    uint32_t before = 0;                        // ids of the waves of this workgroup before mine
+    for (uint32_t v = 0; v < (uint32_t)wv; v++) before += p.meta[w0 + v].z;
+    __syncthreads();
+    unsigned long long off = wsum[0] + wsum[1] + wsum[2] + wsum[3] + before;
+    if (blockIdx.x == gridDim.x - 1u && wv == 3 && l == 0) *p.d_count = off + m.z;     // the last wave: the total
+    if (m.y == 0u || m.z == 0u) return;
+    if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    II2_STAMP(0)      // prologue: meta, slot words, offsets
+    uint16_t *st = stage[wv];
+    // 64 words per round: at most 2048 ids staged (16-bit offsets), then written out 16 bytes per lane
+    auto emit = [&](uint32_t bits, uint32_t i0) {
+        const uint32_t pc = (uint32_t)__popc(bits);
+        const uint32_t incl = wave_incl_scan(pc);
+        const uint32_t tot = wave_bcast(incl, 63);
+        II2_STAMP(1)  // scan
+        if (tot == 0u) return;
+        uint32_t q = incl - pc;
+        const uint32_t lanebase = 32u * (uint32_t)l;
+        while (bits) {
+            st[q++] = (uint16_t)(lanebase + (uint32_t)__ffs((int)bits) - 1u);
+            bits &= bits - 1u;
+        }
+        II2_STAMP(2)  // stage
+        const uint32_t rbase = m.x + 32u * i0;                      // first doc of the round
+        for (uint32_t c = 4u * (uint32_t)l; c < tot; c += 256u) {
+            const uint2 pk = *reinterpret_cast<const uint2 *>(&st[c]);
+            const uint4 ids = make_uint4(rbase + (pk.x & 0xFFFFu), rbase + (pk.x >> 16), rbase + (pk.y & 0xFFFFu), rbase + (pk.y >> 16));
+            if (c + 4u <= tot && off + c + 4u <= p.out_cap) {
+                uint32_t *dst = p.out + off + c;
+                __builtin_memcpy(dst, &ids, 16);                    // one 16-byte store, any 4-byte alignment
+            } else {
+                const uint32_t v[4] = {ids.x, ids.y, ids.z, ids.w};
+                for (uint32_t k = 0; k < 4u; k++)
+                    if (c + k < tot && off + c + k < p.out_cap) p.out[off + c + k] = v[k];
+            }
+        }
+        off += tot;
+        II2_STAMP(3)  // flush
+    };
+#pragma unroll
+    for (uint32_t k = 0; k < DX_PRE; k++)
+        if (64u * k < m.y) emit(pre[k], 64u * k);
+    for (uint32_t i0 = 64u * DX_PRE; i0 < m.y; i0 += 64u) {
+        const uint32_t i = i0 + (uint32_t)l;
+        emit(i < m.y ? slot[i] : 0u, i0);
+    }
+    if (stamps && l == 0)
+        for (int i = 0; i < 4; i++) atomicAdd(&p.debug[(uint64_t)(blockIdx.x % 2048u) * 8u + i], tacc[i]);
+#undef II2_STAMP
+}
+
+hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+    if (ev0) (void)hipEventRecord(ev0, s);
+    const uint32_t grid = (p.n_waves + 3u) / 4u;
+    if (p.n_lists == 2u) hipLaunchKernelGGL(k_dense_tiles<2u>, dim3(grid), dim3(256), 0, s, p);
+    else if (p.n_lists == 3u) hipLaunchKernelGGL(k_dense_tiles<3u>, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_dense_tiles<4u>, dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(k_dense_expand, dim3(grid), dim3(256), 0, s, p);
+    if (ev1) (void)hipEventRecord(ev1, s);
+    return hipGetLastError();
+}
+
+}  // namespace ii2

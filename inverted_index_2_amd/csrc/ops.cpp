@@ -186,7 +186,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
-        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)ctx->cu_count * 8 * 8 * sizeof(unsigned long long)) != hipSuccess)
+        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }

@@ -7,6 +7,7 @@ Nothing here computes postings on the CPU — every operator is a call into libi
 from __future__ import annotations
 
 import ctypes as C
+import sys
 from typing import Optional, Sequence
 
 import numpy as np
@@ -76,7 +77,8 @@ class DeviceArray:
 
     def __del__(self):
         try:
-            self.free()
+            if not sys.is_finalizing():      # at interpreter exit the HIP runtime may already be gone
+                self.free()
         except Exception:
             pass
 
@@ -185,7 +187,7 @@ class Context:
         """lists: [(Segment, list_index), ...].  Returns (DeviceArray ids, count)."""
         segs, idx = self._listargs(lists)
         if cap is None:
-            cap = min(s.list_blocks(i) for s, i in lists) * 256 if out is None else out.count
+            cap = min(s.list_blocks(i, self) for s, i in lists) * 256 if out is None else out.count
         if out is None:
             out = self.empty(max(cap, 1))
         cnt = C.c_uint64()
@@ -201,7 +203,7 @@ class Context:
         """PrefixSearch's append + sort + compact (inverted_index.go:274-292)."""
         segs, idx = self._listargs(lists)
         if out is None:
-            out = self.empty(max(sum(s.list_blocks(i) for s, i in lists) * 256, 1))
+            out = self.empty(max(sum(s.list_blocks(i, self) for s, i in lists) * 256, 1))
         cnt = C.c_uint64()
         self._ck(self.lib.ii2_union(self.h, len(lists), segs, idx, tomb.h if tomb else None, _ptr(out), out.count, C.byref(cnt)))
         return out, cnt.value
@@ -301,10 +303,12 @@ class Segment:
         self.info = info
         self._blk_off = None
 
-    def list_blocks(self, i: int) -> int:
+    def list_blocks(self, i: int, ctx: Optional["Context"] = None) -> int:
+        """Blocks of list i.  A segment belongs to its device, not to the context that made it: any live context works."""
         if self._blk_off is None:
+            c = ctx if ctx is not None and ctx.h else self.ctx
             blk = np.zeros(self.info.n_lists + 1, np.uint32)
-            self.ctx._ck(self.ctx.lib.ii2_seg_export(self.ctx.h, self.h, _ptr(blk), None, None))
+            c._ck(c.lib.ii2_seg_export(c.h, self.h, _ptr(blk), None, None))
             self._blk_off = blk
         return int(self._blk_off[i + 1] - self._blk_off[i])
 
@@ -324,12 +328,12 @@ class Segment:
 
     def free(self) -> None:
         if self.h:
-            self.ctx.lib.ii2_seg_free(self.h)
+            self.ctx.lib.ii2_seg_free(self.h)      # needs no context: the segment knows its device
             self.h = None
 
     def __del__(self):
         try:
-            if self.ctx.h:
+            if not sys.is_finalizing():      # at interpreter exit the HIP runtime may already be gone
                 self.free()
         except Exception:
             pass
@@ -346,7 +350,7 @@ class Tombstones:
 
     def __del__(self):
         try:
-            if self.ctx.h:
+            if self.ctx.h and not sys.is_finalizing():
                 self.free()
         except Exception:
             pass

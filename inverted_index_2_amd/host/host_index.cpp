@@ -214,11 +214,28 @@ class Shard {
         return a;
     }
 
+    // The library merges at most II2_MAX_LISTS segments per call; the reference has no such bound (mCount is the
+    // caller's), so more are folded in rounds: the union is associative, and the tombstone filter and the empty-term
+    // drop only have to happen in the last round.
+    void fold_to_limit(ii2_ctx *ctx, std::vector<std::shared_ptr<SegHandle>> &views) const {
+        while (views.size() > II2_MAX_LISTS) {
+            std::vector<const ii2_seg *> hs;
+            for (size_t i = 0; i < II2_MAX_LISTS; i++) hs.push_back(views[i]->h);
+            ii2_seg *m = nullptr;
+            ii2_merge_stats st;
+            std::memset(&st, 0, sizeof st);
+            ck(ctx, ii2_merge_segments_to_seg(ctx, II2_MAX_LISTS, hs.data(), nullptr, &m, &st), "s: merge");
+            views.erase(views.begin(), views.begin() + II2_MAX_LISTS);
+            if (m) views.insert(views.begin(), std::make_shared<SegHandle>(m));
+        }
+    }
+
     std::vector<TermValues> merged(const std::vector<const Segment *> &segs, const Term *min, const Term *max,
                                    const std::vector<uint32_t> *removed) const {
         std::vector<TermValues> out;
         Aligned a = align(ctx_, segs, min, max);
         if (a.views.empty()) return out;
+        fold_to_limit(ctx_, a.views);
         TombHandle tomb;
         if (removed && !removed->empty()) ck(ctx_, ii2_tomb_create(ctx_, removed->data(), removed->size(), II2_HOST, &tomb.h), "s: merge");
         std::vector<const ii2_seg *> hs;
@@ -252,6 +269,7 @@ class Shard {
     bool merged_segment(ii2_ctx *ctx, const std::vector<const Segment *> &segs, const std::vector<uint32_t> &removed, Segment *out) const {
         Aligned a = align(ctx, segs, nullptr, nullptr);
         if (a.views.empty()) return false;
+        fold_to_limit(ctx, a.views);
         TombHandle tomb;
         if (!removed.empty()) ck(ctx, ii2_tomb_create(ctx, removed.data(), removed.size(), II2_HOST, &tomb.h), "s: merge");
         std::vector<const ii2_seg *> hs;
