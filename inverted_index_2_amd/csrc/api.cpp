@@ -619,16 +619,15 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     // blocks, no partition pass, no workgroup barriers (intersect_dense.hip).  The driver must be dense enough for
     // the 1-bit-per-doc result bitmap to stay small next to the payload.
     if (ctx->opt_intersect_dense && ctx->opt_intersect_g <= 0 && n >= 2 && n <= DENSE_MAXL && nblk0 >= 1024 &&
-        per_block_span > 0 && per_block_span <= 2048.0) {
+        per_block_span > 0 && per_block_span <= 1100.0) {
         DenseParams dp;
         std::memset(&dp, 0, sizeof dp);
         for (uint32_t i = 0; i < n; i++) dp.lists[i] = views[i];
         dp.n_lists = n;
-        // one generation of waves: the tile kernel holds 8 waves per SIMD (<= 64 VGPRs), and a second, partly filled round of
-        // workgroups would cost as much as a full one
-        const uint32_t resident = (uint32_t)ctx->cu_count * 4u * 8u;
-        uint32_t bpw = ctx->opt_dense_bpw > 0 ? (uint32_t)ctx->opt_dense_bpw : std::max<uint32_t>(8u, (nblk0 + resident - 1u) / resident);
-        bpw = std::min<uint32_t>(std::max<uint32_t>((bpw + 3u) & ~3u, 4u), 60u);
+        // a wave's passes take 16 driver blocks each; one round (16 blocks) per wave by default: more, shorter waves balance
+        // better than fewer, longer ones (measured on Zipf rank pairs 1/2 ... 2/3/5), and waves never wait for each other
+        uint32_t bpw = ctx->opt_dense_bpw > 0 ? (uint32_t)ctx->opt_dense_bpw : 16u;
+        bpw = std::min<uint32_t>(std::max<uint32_t>((bpw + 15u) & ~15u, 16u), 1024u);
         dp.bpw = bpw;
         dp.n_waves = (nblk0 + bpw - 1) / bpw;
         const uint32_t grid = (dp.n_waves + 3u) / 4u;

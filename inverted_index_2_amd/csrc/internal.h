@@ -150,7 +150,7 @@ struct IntersectParams {
 
 // dense streaming intersection (intersect_dense.hip)
 constexpr uint32_t DENSE_MAXL = 4;             // lists it takes
-constexpr uint32_t DENSE_CAPW = 8192;          // docs per LDS window of a wave
+constexpr uint32_t DENSE_CAPW = 16384;         // docs per LDS window of a wave
 struct DenseParams {
     ListView lists[DENSE_MAXL];  // lists[0] is the driver (fewest blocks)
     uint32_t n_lists;

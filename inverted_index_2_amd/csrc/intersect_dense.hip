@@ -26,7 +26,8 @@
 
 namespace ii2 {
 
-constexpr uint32_t DN_GU = 128;                               // guard bits below and above a window
+constexpr uint32_t DN_ROWS = 16;                              // blocks per pass: one per row of four lanes, 64 payload bytes per lane
+constexpr uint32_t DN_GU = 512;                               // guard bits below and above a window (a lane of narrow groups spans < 512 docs)
 constexpr uint32_t DN_CAPW = DENSE_CAPW;                      // docs a window covers (multiple of 32)
 constexpr uint32_t DN_NW = ((DN_CAPW + 2 * DN_GU) / 32 + 2 + 3) & ~3u;    // words of one LDS bitmap (a multiple of 4: 16-byte clears)
 constexpr uint32_t DN_WAVE_LDS = 2 * DN_NW + 4;               // two bitmaps + the carry word (+ pad)
@@ -53,29 +54,10 @@ __device__ __forceinline__ uint32_t wave_skip_upper_bound(const ii2_skip *__rest
 
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// Five consecutive skip entries of a list as SCALARS: the tables are read-only for the kernel, so they are read through
-// the constant address space (s_load, scalar cache) — a pass needs its four blocks' entries plus the next one's byte
-// offset, and everything the generator decides from them (how many rows are valid, where the round ends) is SALU work.
-typedef __attribute__((address_space(4))) const uint32_t *cu32p;
-struct Ent5 { uint32_t f[5], o[5]; };
-__device__ __forceinline__ Ent5 ent_load(const ii2_skip *skip, uint32_t nblk, uint32_t at) {
-    cu32p s = (cu32p)(uintptr_t)skip;
-    Ent5 e;
-#pragma unroll
-    for (uint32_t k = 0; k < 5u; k++) {
-        const uint32_t i = at + k < nblk ? at + k : nblk;      // entry nblk is readable: its byte_off bounds the last block's payload
-        e.f[k] = s[2u * i];
-        e.o[k] = s[2u * i + 1u];
-    }
-    return e;
-}
-__device__ __forceinline__ uint32_t row_sel(uint32_t row, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
-    return row == 0u ? a0 : row == 1u ? a1 : row == 2u ? a2 : a3;
-}
-
-// One PASS = up to four blocks of one list (one per 16-lane row) against one window.  The wave's work is a sequence of
-// passes produced by a small generator (scalar code over the skip entries); the 16 payload bytes of every lane for
-// pass k + 1 are fetched before pass k is marked, so a wave always has one HBM request in flight.
+// One PASS = up to sixteen blocks of one list against one window: a row of four lanes per block, 64 payload bytes
+// per lane.  The wave's work is a sequence of passes; a pass needs its blocks' skip entries (one 16-byte load per
+// lane: my row's entry and the next one) and then its payload (four 16-byte loads per lane).  Both are requested one
+// pass ahead: while pass k is marked, the payload of pass k + 1 and the entries of pass k + 2 are in flight.
 struct Pass {
     const uint8_t *payload;      // wave-uniform
     uint32_t wlo, wspan;         // the window the pass marks into (wave-uniform)
@@ -84,8 +66,8 @@ struct Pass {
     bool rv;                     // per lane: my row has a block
     uint32_t f, q0, q1;          // per lane: my row's first doc and payload byte range
 };
-enum : uint32_t { PF_VALID = 1u, PF_FIRST = 2u, PF_LAST = 4u, PF_TOB = 8u, PF_FOLD = 16u, PF_FULL = 32u };
-// first / last pass of a window, marks into B, fold B into A first, every valid row is a full block of 255 payload bytes
+enum : uint32_t { PF_VALID = 1u, PF_FIRST = 2u, PF_LAST = 4u, PF_TOB = 8u, PF_FOLD = 16u };
+// first / last pass of a window, marks into B, fold B into A first
 
 template <uint32_t NL>
 __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
@@ -93,7 +75,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
     __shared__ uint32_t wcnt[4];
     const int l = lane_id();
     const uint32_t wv = uni(threadIdx.x >> 6);
-    const uint32_t rl = (uint32_t)l & 15u, row = (uint32_t)l >> 4;
+    const uint32_t rl = (uint32_t)l & 3u, row = (uint32_t)l >> 2;
     const uint32_t w = blockIdx.x * 4u + wv;                 // this wave's number in doc order
     uint32_t *bmA = lds[wv], *bmB = bmA + DN_NW, *carry = bmB + DN_NW;
     const ListView drv = p.lists[0];
@@ -113,10 +95,18 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
     if (b0 < b1) {                                           // wave-uniform
-        Ent5 E = ent_load(drv.skip, drv.nblk, b0);           // entries the next gen() call consumes
+        // my row's skip entry and the next one, for the blocks [at, at + 16) of a list (indices clamped onto the readable entry nblk)
+        auto ent_load = [&](uint32_t j, uint32_t at) -> uint4 {
+            const ListView L = p.lists[j];
+            const uint32_t i0 = at + row < L.nblk ? at + row : L.nblk;
+            const uint32_t i1 = i0 < L.nblk ? i0 + 1u : L.nblk;
+            const ii2_skip e0 = L.skip[i0], e1 = L.skip[i1];
+            return make_uint4(e0.first_doc, e0.byte_off, e1.first_doc, e1.byte_off);
+        };
+        uint4 E = ent_load(0u, b0);                          // entries the next gen() call consumes
         const uint32_t drv_last = uni(*drv.last_doc);
-        const uint32_t lo_w = E.f[0];
-        const uint32_t hi_w = b1 < drv.nblk ? ((cu32p)(uintptr_t)drv.skip)[2u * b1] - 1u : drv_last;
+        const uint32_t lo_w = uni(E.x);                      // (row 0 = block b0)
+        const uint32_t hi_w = b1 < drv.nblk ? uni(drv.skip[b1].first_doc) - 1u : drv_last;
         mlo_w = lo_w & ~31u;
         nwords_w = ((hi_w - mlo_w) >> 5) + 1u;
         uint32_t *slot = p.bitmap + (size_t)((mlo_w - p.base32) >> 5) + w;      // slots of neighbouring waves never overlap (+ w)
@@ -130,7 +120,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             a[j - 1] = ub ? ub - 1u : 0u;
         }
 
-        // ---- the pass generator: scalar state, scalar loads ----
+        // ---- the pass generator ----
         uint32_t gb = b0;                     // driver block of the round being generated
         uint32_t g_hi = 0, g_wlo = 0;         // its last doc; the window being generated
         uint32_t g_stage = 0;                 // 0: driver pass next; j >= 1: passes of list j
@@ -140,50 +130,39 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
         bool g_done = false;
         auto gen = [&]() -> Pass {
             Pass P;
-            P.payload = drv.payload; P.flags = 0u; P.nvalid = 0u; P.rv = false; P.f = 0u; P.q0 = 0u; P.q1 = 0u;
+            P.payload = drv.payload; P.flags = 0u; P.nvalid = 0u; P.rv = false; P.f = E.x; P.q0 = E.y; P.q1 = E.w;
             P.wlo = 0u; P.wspan = 0u;
             if (g_done) return P;
-            if (g_stage == 0u) {
-                const uint32_t nbk = b1 - gb < 4u ? b1 - gb : 4u;
-                if (g_new) {
-                    g_hi = gb + nbk < drv.nblk ? row_sel(nbk - 1u, E.f[1], E.f[2], E.f[3], E.f[4]) - 1u : drv_last;
-                    g_wlo = E.f[0] & ~31u;
-                    g_new = false;
-                }
-            }
-            P.wlo = g_wlo;
-            P.wspan = g_hi - g_wlo < DN_CAPW ? g_hi - g_wlo : DN_CAPW - 1u;
             const uint32_t j = g_stage;
             uint32_t nvalid;
             if (j == 0u) {
-                nvalid = b1 - gb < 4u ? b1 - gb : 4u;
+                nvalid = b1 - gb < DN_ROWS ? b1 - gb : DN_ROWS;
+                if (g_new) {      // the round's doc range: first doc of its first block ... one before the first doc of the block after its last
+                    const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)E.z, (int)(4u * (nvalid - 1u)));
+                    g_hi = gb + nvalid < drv.nblk ? nf - 1u : drv_last;
+                    g_wlo = uni(E.x) & ~31u;
+                    g_new = false;
+                }
                 P.flags = PF_VALID | PF_FIRST;
-            } else {
+            }
+            P.wlo = g_wlo;
+            P.wspan = g_hi - g_wlo < DN_CAPW ? g_hi - g_wlo : DN_CAPW - 1u;
+            if (j != 0u) {
                 const uint32_t whi = g_wlo + P.wspan;
-                const uint32_t nblk_j = p.lists[j].nblk;
                 P.payload = p.lists[j].payload;
-                nvalid = 0u;                                                  // first docs ascend: the valid rows are a prefix
-#pragma unroll
-                for (uint32_t r = 0; r < 4u; r++)
-                    if (nvalid == r && g_cur + r < nblk_j && E.f[r] <= whi) nvalid = r + 1u;
+                const bool rvj = g_cur + row < p.lists[j].nblk && E.x <= whi;   // first docs ascend: the valid rows are a prefix
+                nvalid = (uint32_t)__popcll(__ballot(rvj)) >> 2;
                 P.flags = PF_VALID | PF_TOB | ((g_first && j > 1u) ? PF_FOLD : 0u);
                 g_first = false;
             }
-            bool full = true;
-#pragma unroll
-            for (uint32_t r = 0; r < 4u; r++) full = full && (r >= nvalid || E.o[r + 1u] - E.o[r] == 255u);
-            if (full) P.flags |= PF_FULL;
             P.nvalid = nvalid;
             P.rv = row < nvalid;
-            P.f = row_sel(row, E.f[0], E.f[1], E.f[2], E.f[3]);
-            P.q0 = row_sel(row, E.o[0], E.o[1], E.o[2], E.o[3]);
-            P.q1 = row_sel(row, E.o[1], E.o[2], E.o[3], E.o[4]);
             // advance; the entries of the next pass are requested now and used one pass later
             uint32_t nj = j, ncur = g_cur + nvalid;
             if (j == 0u) {
                 if (NL == 1u) nj = NL;             // (single list: the window is complete)
                 else { nj = 1u; ncur = a[0]; g_first = true; }
-            } else if (nvalid < 4u) {              // list j is done for this window; its last block in the window may reach past it
+            } else if (nvalid < DN_ROWS) {         // list j is done for this window; its last block in the window may reach past it
 #pragma unroll
                 for (uint32_t jj = 1; jj < NL; jj++)
                     if (jj == j && ncur > a[jj - 1] + 1u) a[jj - 1] = ncur - 1u;
@@ -198,7 +177,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                 P.flags |= PF_LAST;
                 nj = 0u;
                 if (g_hi - g_wlo < DN_CAPW) {      // round complete
-                    gb += 4u;
+                    gb += DN_ROWS;
                     g_new = true;
                     if (gb >= b1) g_done = true;
                 } else g_wlo += DN_CAPW;
@@ -206,95 +185,122 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             }
             g_stage = nj;
             g_cur = ncur;
-            if (!g_done) E = ent_load(p.lists[nj].skip, p.lists[nj].nblk, ncur);
+            if (!g_done) E = ent_load(nj, ncur);
             return P;
         };
-        auto fetch = [&](const Pass &P) -> uint4 {
+        struct Bytes { uint4 g[4]; };
+        auto fetch = [&](const Pass &P) -> Bytes {
             const uint32_t len = P.rv ? P.q1 - P.q0 : 0u;
-            uint4 g = make_uint4(0, 0, 0, 0);
-            if (len > 16u * rl) __builtin_memcpy(&g, P.payload + P.q0 + 16u * rl, 16);     // segments carry 16 bytes of padding
-            return g;
+            Bytes B;
+            const uint8_t *src = P.payload + P.q0 + 64u * rl;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                B.g[k] = make_uint4(0, 0, 0, 0);
+                if (len > 64u * rl + 16u * k) __builtin_memcpy(&B.g[k], src + 16u * k, 16);   // segments carry 16 bytes of padding
+            }
+            return B;
         };
 
-        // ---- marking one pass: four blocks, one per 16-lane row, into bm for the window [wlo, wlo + wspan]; exact for any block ----
-        auto mark_rows = [&](const Pass &P, uint4 g, uint32_t *bm) {
+        // ---- marking one pass into bm for the window [wlo, wlo + wspan]; exact for any block ----
+        auto mark_rows = [&](const Pass &P, const Bytes &B, uint32_t *bm) {
             const uint32_t wlo = P.wlo, wspan = P.wspan;
             const bool rv = P.rv;
             const uint32_t f = P.f;
             const uint32_t len = rv ? P.q1 - P.q0 : 0u;
-            const uint32_t myoff = 16u * rl;
-            const uint32_t nb = len > myoff ? (len - myoff < 16u ? len - myoff : 16u) : 0u;
-            if (P.flags & PF_FULL) {                 // 255 bytes per row: only the row's last lane has a byte that is not its own
-                if (rl == 15u) g.w &= 0x00FFFFFFu;
-            } else if (nb < 16u) {
-                const uint32_t n0 = nb < 4u ? nb : 4u, n1 = nb < 4u ? 0u : (nb < 8u ? nb - 4u : 4u);
-                const uint32_t n2 = nb < 8u ? 0u : (nb < 12u ? nb - 8u : 4u), n3 = nb < 12u ? 0u : nb - 12u;
-                g.x &= n0 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n0)) - 1u);
-                g.y &= n1 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n1)) - 1u);
-                g.z &= n2 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n2)) - 1u);
-                g.w &= n3 >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n3)) - 1u);
+            const uint32_t myoff = 64u * rl;
+            const uint32_t nb = len > myoff ? (len - myoff < 64u ? len - myoff : 64u) : 0u;   // my bytes that belong to the block
+            uint32_t ww[16] = {B.g[0].x, B.g[0].y, B.g[0].z, B.g[0].w, B.g[1].x, B.g[1].y, B.g[1].z, B.g[1].w,
+                               B.g[2].x, B.g[2].y, B.g[2].z, B.g[2].w, B.g[3].x, B.g[3].y, B.g[3].z, B.g[3].w};
+            if (__ballot(rv && len != 255u) == 0ull) {      // full blocks: only the row's last lane holds a byte that is not its own
+                if (rl == 3u) ww[15] &= 0x00FFFFFFu;
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; k++) {
+                    const uint32_t n = nb > 4u * k ? (nb - 4u * k < 4u ? nb - 4u * k : 4u) : 0u;
+                    ww[k] &= n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
+                }
             }
             auto setbit = [&](uint32_t id, bool valid) {                       // exact range test: any id, any gap
                 const uint32_t d = id - wlo;
                 if (valid && d <= wspan) atomicOr(&bm[(d + DN_GU) >> 5], 1u << ((d + DN_GU) & 31u));
             };
             // rows whose block has multi-byte gaps (or more than 256 payload bytes): the general one-wave-per-block decoder
-            const bool hard = rv && (len > 256u || (((g.x | g.y | g.z | g.w) & 0x80808080u) != 0u));
+            uint32_t any = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) any |= ww[k];
+            const bool hard = rv && (len > 256u || (any & 0x80808080u) != 0u);
             const unsigned long long hm = __ballot(hard);
             if (hm != 0ull) {
 #pragma unroll 1
-                for (int r = 0; r < 4; r++) {
-                    if (((hm >> (16 * r)) & 0xFFFFull) == 0ull) continue;
-                    const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)f, 16 * r), q0r = (uint32_t)__builtin_amdgcn_readlane((int)P.q0, 16 * r),
-                                   q1r = (uint32_t)__builtin_amdgcn_readlane((int)P.q1, 16 * r);
+                for (uint32_t r = 0; r < DN_ROWS; r++) {
+                    if (((hm >> (4u * r)) & 0xFull) == 0ull) continue;
+                    const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)(4u * r)), q0r = (uint32_t)__builtin_amdgcn_readlane((int)P.q0, (int)(4u * r)),
+                                   q1r = (uint32_t)__builtin_amdgcn_readlane((int)P.q1, (int)(4u * r));
                     decode_block_wave4(GlobalBytes{P.payload}, q0r, q1r, fq,
                                        [&](uint32_t, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
                                            setbit(id0, mask & 1u); setbit(id1, mask & 2u); setbit(id2, mask & 4u); setbit(id3, mask & 8u);
                                        });
                 }
             }
-            const bool rowhard = ((hm >> (16u * row)) & 0xFFFFull) != 0ull;
+            const bool rowhard = ((hm >> (4u * row)) & 0xFull) != 0ull;
             const bool live = rv && !rowhard;
-            const uint32_t ww[4] = {g.x, g.y, g.z, g.w};
-            uint32_t ss[4];
+            // prefix of the gap sums over my sixteen groups of four postings: pre[k] = docs from the posting before my bytes to group k's last posting
+            uint32_t pre[16];
+            uint32_t acc = 0, wide = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) ss[k] = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u);
-            const uint32_t s = live ? ss[0] + ss[1] + ss[2] + ss[3] : 0u;
-            const uint32_t incl = row_incl_scan(s);
-            const uint32_t base = f + incl - s;                                  // id of the posting right before my bytes
+            for (uint32_t k = 0; k < 16u; k++) {
+                const uint32_t nx = __builtin_amdgcn_sad_u8(ww[k], 0u, acc);
+                wide |= nx - acc;                                               // a group sum >= 32 sets a bit above bit 4
+                acc = nx;
+                pre[k] = nx;
+            }
+            // exclusive scan of the lane sums inside the row's four lanes (quad permutes)
+            const uint32_t s = live ? acc : 0u;
+            const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x90 /* quad_perm [0,0,1,2] */, 0xf, 0xf, false);
+            const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x40 /* quad_perm [0,0,0,1] */, 0xf, 0xf, false);
+            const uint32_t s3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)s, 0x00 /* quad_perm [0,0,0,0] */, 0xf, 0xf, false);
+            const uint32_t excl = rl == 0u ? 0u : rl == 1u ? s1 : rl == 2u ? s1 + s2 : s1 + s2 + s3;
+            const uint32_t base = f + excl;                                      // id of the posting right before my bytes
             const uint32_t u = base - wlo + DN_GU;                               // its (guard-shifted) position, mod 2^32
-            const uint32_t smax = max(max(ss[0], ss[1]), max(ss[2], ss[3]));
-            const bool narrow = smax <= 31u;                                     // every group of four postings fits a 32-bit mask
-            // narrow lanes span < 128 docs: one that starts outside [wlo - GU, wlo + wspan] lies wholly outside the window
-            const bool fast = live && narrow && u <= wspan + DN_GU;
-            if (fast) {
+            // A lane whose groups of four postings all span < 32 docs spans < 512 docs in all: if it starts outside
+            // [wlo - GU, wlo + wspan] it lies wholly outside the window and is skipped.  A lane with a wider group is kept
+            // whatever its start; when it starts outside that range every one of its groups is placed posting by posting.
+            const bool inrange = u <= wspan + DN_GU;
+            const bool haswide = wide >= 32u;
+            const bool act = live && (inrange || haswide);
+            const bool exactlane = haswide && !inrange;
+            const uint32_t lim = wspan + 2u * DN_GU - 64u;                       // a position in the upper guard: where out-of-window groups are parked
+            if (act) {
                 // a group's mask starts AT the posting before it (bit 0 = position q: the block's first doc for the row's
-                // first lane, else a posting an earlier group already set — setting it again is harmless), so no separate
-                // store for posting 0 and no add per group
-                uint32_t q = u;
+                // first lane, else a posting an earlier group already set — setting it again is harmless)
+                uint32_t q = u, prev = 0u;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (uint32_t k = 0; k < 16u; k++) {
                     const uint32_t x = ww[k];
-                    uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;                 // posting 3 and posting 2's slot
+                    const bool isw = exactlane || pre[k] - prev >= 32u;          // the four gaps do not fit one 32-bit mask
+                    uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;
                     M = (M << ((x >> 16) & 31u)) | 1u;
                     M = (M << ((x >> 8) & 31u)) | 1u;
                     M = (M << (x & 31u)) | 1u;                                   // bit 0: the posting before the group
-                    const unsigned long long MM = (unsigned long long)M << (q & 31u);
-                    uint32_t *dst = bm + (q >> 5);                               // q < wspan + 2 GU: no clamp needed
-                    atomicOr(dst, (uint32_t)MM);
-                    if ((uint32_t)(MM >> 32)) atomicOr(dst + 1, (uint32_t)(MM >> 32));
-                    q += ss[k];
-                }
-            }
-            if (__ballot(live && !narrow) != 0ull) {                             // rare: wide gaps, posting by posting
-                if (live && !narrow) {
-                    uint32_t id = base;
-                    setbit(f, rl == 0u);
+                    M = isw ? 0u : M;
+                    const uint32_t qc = q < lim ? q : lim;                       // groups beyond the window: harmless bits in the guard
+                    const uint32_t sh = qc & 31u;
+                    uint32_t *dst = bm + (qc >> 5);
+                    atomicOr(dst, M << sh);
+                    atomicOr(dst + 1, (M >> 1) >> (31u - sh));                   // the part that spills into the next word (0 for most)
+                    if (__ballot(isw) != 0ull) {                                 // rare (a few groups per thousand): posting by posting, exact range test
+                        if (isw) {
+                            uint32_t d = q - DN_GU;                              // doc - wlo of the posting before the group (mod 2^32)
+                            if (k == 0u && rl == 0u && d <= wspan) atomicOr(&bm[(d + DN_GU) >> 5], 1u << ((d + DN_GU) & 31u));   // the block's first doc
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        id += (ww[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                        setbit(id, (uint32_t)k < nb);
+                            for (uint32_t j = 0; j < 4u; j++) {
+                                d += (x >> (8u * j)) & 0xFFu;
+                                if (4u * k + j < nb && d <= wspan) atomicOr(&bm[(d + DN_GU) >> 5], 1u << ((d + DN_GU) & 31u));
+                            }
+                        }
                     }
+                    prev = pre[k];
+                    q = u + prev;
                 }
             }
         };
@@ -336,13 +342,13 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
         };
 
         Pass P = gen();
-        uint4 g = fetch(P);
+        Bytes B = fetch(P);
         II2_STAMP(0)          // prologue: searches, first entries, first fetch issued
         while (P.flags & PF_VALID) {
             if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             II2_STAMP(2)      // waiting for the prefetched payload
             const Pass Q = gen();
-            const uint4 gq = fetch(Q);                        // in flight while P is marked
+            const Bytes Bq = fetch(Q);                        // in flight while P is marked
             II2_STAMP(1)      // generator + fetch issue
             const uint32_t nw = (P.wspan >> 5) + 1u;
             const uint32_t ncl = nw + 2u * (DN_GU / 32u) + 2u;   // <= DN_NW - 2; cleared in 4-word steps
@@ -352,12 +358,12 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                 clear(bmB, ncl);
             }
             II2_STAMP(3)      // clear / fold
-            if (P.nvalid != 0u) mark_rows(P, g, (P.flags & PF_TOB) ? bmB : bmA);
+            if (P.nvalid != 0u) mark_rows(P, B, (P.flags & PF_TOB) ? bmB : bmA);
             II2_STAMP(4)      // mark
             if (P.flags & PF_LAST) finalise(P.wlo, P.wspan);
             II2_STAMP(5)      // finalise
             P = Q;
-            g = gq;
+            B = Bq;
         }
         count = wave_sum(count);
     }

@@ -1,0 +1,102 @@
+"""GPU: the wave-streaming dense intersection (csrc/intersect_dense.hip, chosen by the host for 2..4 lists whose
+driver is dense) against numpy / the oracle — bit-exact id sequences, with the general tile kernels (option
+intersect.dense = 0) as a second opinion.  Inputs are built to reach every path of the kernel: full blocks of
+one-byte gaps, groups of four postings spanning more than 31 docs, multi-byte gaps and sparse stretches inside a dense
+list (windows that split), short last blocks, lists from different segments, tombstones, ids next to 2^32."""
+import numpy as np
+import pytest
+
+from inverted_index_2_amd import synth
+from oracle import oracle as orc
+from tests.gpu_util import ctx, sorted_unique  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def bernoulli(rng, p, lo, hi):
+    return (np.flatnonzero(rng.random(hi - lo) < p) + lo).astype(np.uint32)
+
+
+def _check(ctx, lists, removed=None, split=False):
+    want = lists[0]
+    for x in lists[1:]:
+        want = np.intersect1d(want, x, assume_unique=True)
+    if removed is not None:
+        want = np.setdiff1d(want, removed, assume_unique=True)
+    want = want.astype(np.uint32)
+    tomb = ctx.tombstones(removed) if removed is not None else None
+    if split:
+        segs = [ctx.encode_lists([l]) for l in lists]
+        ls = [(s, 0) for s in segs]
+    else:
+        seg = ctx.encode_lists(lists)
+        ls = [(seg, i) for i in range(len(lists))]
+    out = ctx.empty(min(l.size for l in lists) + 16)
+    for dense in (1, 0):
+        ctx.set_option("intersect.dense", dense)
+        _, n = ctx.intersect(ls, tomb=tomb, out=out)
+        got = out.download(n)
+        assert n == want.size, (dense, n, want.size)
+        assert np.array_equal(got, want), dense
+    ctx.set_option("intersect.dense", 1)
+    for bpw in (32, 64):                           # longer waves: several rounds per wave, carried boundary words
+        ctx.set_option("intersect.dense_bpw", bpw)
+        _, n = ctx.intersect(ls, tomb=tomb, out=out)
+        assert n == want.size and np.array_equal(out.download(n), want), bpw
+    ctx.set_option("intersect.dense_bpw", 0)
+    return want
+
+
+@pytest.mark.parametrize("ps", [(0.5, 0.33), (0.3, 0.9), (0.26, 0.3), (0.5, 0.4, 0.3), (0.9, 0.5, 0.35, 0.3)])
+def test_dense_bernoulli_lists(ctx, ps):
+    rng = np.random.default_rng(int(sum(ps) * 1000))
+    U = 1_600_000                                   # >= 1024 driver blocks at these densities
+    lists = [bernoulli(rng, p, 0, U) for p in ps]
+    want = _check(ctx, lists)
+    assert want.size > 1000
+    removed = bernoulli(rng, 0.02, 0, U)
+    _check(ctx, lists, removed=removed)
+    _check(ctx, lists, split=True)
+
+
+def test_dense_with_sparse_stretches_and_multibyte_gaps(ctx):
+    # dense lists with holes: empty stretches (gaps of 300 .. 200k docs -> two- and three-byte varints, windows that split),
+    # a stretch where one list thins out to 1 % (groups of four postings far wider than 31 docs) and a short last block
+    rng = np.random.default_rng(77)
+    U = 2_400_000
+    a, b = bernoulli(rng, 0.45, 0, U), bernoulli(rng, 0.35, 0, U)
+    def punch(x, holes):
+        keep = np.ones(x.size, bool)
+        for lo, hi in holes:
+            keep &= ~((x >= lo) & (x < hi))
+        return x[keep]
+    a = punch(a, [(100_000, 100_300), (500_000, 700_000), (1_000_000, 1_020_000)])
+    b = punch(b, [(90_000, 130_000), (1_500_000, 1_500_900), (2_000_000, 2_000_040)])
+    thin = (b >= 1_200_000) & (b < 1_400_000) & (rng.random(b.size) > 0.03)
+    b = b[~thin]
+    b = np.union1d(b, a[(a >= 1_200_000) & (a < 1_400_000)][::7]).astype(np.uint32)
+    _check(ctx, [a, b])
+    _check(ctx, [a, b], removed=bernoulli(rng, 0.01, 0, U))
+    _check(ctx, [b, a, bernoulli(rng, 0.6, 0, U)])
+
+
+def test_dense_lists_next_to_the_top_of_the_id_space(ctx):
+    rng = np.random.default_rng(5)
+    base = (1 << 32) - 1_200_000
+    a, b = bernoulli(rng, 0.5, base, (1 << 32)), bernoulli(rng, 0.4, base, (1 << 32))
+    a = np.union1d(a, np.asarray([0xFFFFFFFF, 0xFFFFFFFE], np.uint32)).astype(np.uint32)
+    b = np.union1d(b, np.asarray([0xFFFFFFFF, 5, 17], np.uint32)).astype(np.uint32)       # one list also starts near 0: a 4G-doc gap
+    _check(ctx, [a, b])
+
+
+def test_dense_zipf_pairs_match_the_oracle(ctx):
+    D = 6_000_000
+    lists = [synth.zipf_list(r, D) for r in (2, 3)]
+    removed = synth.geometric_postings(0.01, D, synth.term_seed(10**6))
+    want = _check(ctx, lists, removed=removed)
+    assert np.array_equal(want, orc.intersect(lists, removed))
+    # identical lists, a subset, disjoint halves
+    _check(ctx, [lists[0], lists[0].copy()])
+    _check(ctx, [lists[0], lists[0][::3].copy(), lists[1]])
+    lo, hi = lists[0][lists[0] < D // 2], lists[1][lists[1] >= D // 2]
+    _check(ctx, [lo, hi])
