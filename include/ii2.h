@@ -111,6 +111,30 @@ int ii2_seg_export(ii2_ctx *ctx, const ii2_seg *seg, uint32_t *blk_off, ii2_skip
  * k segments before a merge (terms a segment lacks become empty slots) and drops emptied terms after
  * one.  Selected indices must ascend and may only skip empty lists between two selected ones. */
 int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64_t *src_list, ii2_seg **out);
+/* ---- term alignment on the device -------------------------------------------------------- */
+/* Replaces the k-way walk over the segments' term dictionaries that feeds the merging iterator
+ * (shard.go:253-278, file/reader.go:33-71; order = file.CompareTermValues = bytes.Compare,
+ * file/types.go:24-26).  Input, host memory: k sorted, duplicate-free dictionaries, flat —
+ * term_bytes, term_off[n_all + 1] (byte offsets of the terms), seg_first[k + 1] (index in term_off
+ * of each dictionary's first term; seg_first[0] = 0, seg_first[k] = n_all).  The result stays on
+ * the device: the union dictionary (n_union terms, ascending) and, per dictionary, which of its
+ * terms is which union term. */
+typedef struct ii2_align ii2_align;
+int ii2_align_terms(ii2_ctx *ctx, uint32_t k, const uint8_t *term_bytes, const uint64_t *term_off,
+                    const uint64_t *seg_first, ii2_align **out);
+int ii2_align_info(const ii2_align *a, uint64_t *n_union, uint32_t *k);
+/* rep[n_union]: index (into term_off) of one input term equal to union term u, in union order;
+ * src_list[k * n_union]: row s = for every union term the term of dictionary s equal to it (index
+ * inside that dictionary) or -1.  Either may be NULL. */
+int ii2_align_export(ii2_ctx *ctx, const ii2_align *a, uint64_t *rep, int64_t *src_list);
+/* The term-aligned view of `src` for dictionary s of the alignment, built on the device: n_union
+ * slots, slot u = list first_list + (index of union term u in dictionary s), or empty.  The
+ * dictionary must describe the consecutive lists [first_list, first_list + its size) of src.
+ * Same result as ii2_seg_select with row s of src_list, without the mapping ever visiting the host. */
+int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a, uint32_t s,
+                           uint64_t first_list, ii2_seg **out);
+void ii2_align_free(ii2_align *a);
+
 int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info);
 void ii2_seg_free(ii2_seg *seg);
 

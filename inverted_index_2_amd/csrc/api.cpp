@@ -438,6 +438,7 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *out = nullptr;
+    if (int rc0 = ii2_seg_host_blk_off(ctx, src)) return rc0;
     // selected lists must ascend, and only empty lists may be skipped between two selected ones
     std::vector<uint32_t> blk(n_out + 1, 0);
     int64_t prev = -1;
@@ -478,6 +479,45 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     *out = seg.release();
     return II2_OK;
 }
+
+}  // extern "C"
+
+// host mirror of blk_off, fetched on first use (views built on the device do not have one)
+int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg) {
+    std::lock_guard<std::mutex> sg(seg->span_mu);
+    if (seg->h_blk_off.size() == seg->n_lists + 1) return II2_OK;
+    std::vector<uint32_t> h(seg->n_lists + 1);
+    HIP_TRY(ctx, hipMemcpyAsync(h.data(), seg->d_blk_off, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const_cast<ii2_seg *>(seg)->h_blk_off.swap(h);
+    return II2_OK;
+}
+
+// a view over src's store whose four per-slot arrays were built on the device (align.hip); takes ownership of them
+int ii2_seg_adopt_view(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, uint32_t *d_blk_off, uint32_t *d_cnt, uint32_t *d_last_doc,
+                       uint32_t *d_blk_list, ii2_seg **out) {
+    ii2_seg *seg = new (std::nothrow) ii2_seg();
+    if (!seg) {
+        (void)hipFree(d_blk_off); (void)hipFree(d_cnt); (void)hipFree(d_last_doc); (void)hipFree(d_blk_list);
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    }
+    seg->device = ctx->device;
+    seg->store = src->store;
+    seg->d_skip = src->d_skip;
+    seg->d_payload = src->d_payload;
+    seg->n_lists = n_out;
+    seg->n_blocks = src->n_blocks;
+    seg->n_bytes = src->n_bytes;
+    seg->n_postings = src->n_postings;      // upper bound, as for ii2_seg_select
+    seg->d_blk_off = d_blk_off;
+    seg->d_cnt = d_cnt;
+    seg->d_last_doc = d_last_doc;
+    seg->d_blk_list = d_blk_list;
+    *out = seg;
+    return II2_OK;
+}
+
+extern "C" {
 
 void ii2_seg_free(ii2_seg *seg) {
     if (!seg) return;
@@ -546,6 +586,7 @@ void ii2_tomb_free(ii2_tomb *t) {
 static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListView *v) {
     if (!seg || idx >= seg->n_lists) return fail(ctx, II2_EINVAL, "list index out of range");
     if (seg->device != ctx->device) return fail(ctx, II2_EINVAL, "segment lives on another device");
+    if (int rc = ii2_seg_host_blk_off(ctx, seg)) return rc;
     const uint32_t b0 = seg->h_blk_off[idx], b1 = seg->h_blk_off[idx + 1];
     v->skip = seg->d_skip + b0;
     v->payload = seg->d_payload;

@@ -89,6 +89,7 @@ struct ii2_tomb {
 };
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
+int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg);   // fills seg->h_blk_off on first use (thread-safe)
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);   // false when profiling is off
 // union through the intersection tiles (OR); *taken = false when the lists are too sparse for it (caller merges instead)
 int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx, const ii2_tomb *tomb,
@@ -217,14 +218,17 @@ struct MergeSegs {
     uint32_t k;
     uint32_t pad0;
     uint64_t n_terms;
-    uint32_t seg_b0[MAX_LISTS];       // first block of every segment's term range
-    uint32_t seg_cum[MAX_LISTS + 1];  // prefix of the segments' block counts (global block numbering)
+    // device table written by k_mseg_blocks (no host round trip): [0, k) first block of every segment's term range,
+    // [k, 2k] prefix of the segments' block counts (global block numbering; [2k] = total)
+    const uint32_t *segtab;
+    uint32_t total_ub;                // host-side upper bound of the total (sizes grids and scratch)
+    uint32_t pad1;
 };
 static_assert(sizeof(MergeSegs) <= 4000, "MergeSegs is passed by value as a kernel argument");
 
 struct MergeParams {
     uint32_t k;
-    uint32_t n_tiles;
+    uint32_t n_tiles_ub;          // host-side upper bound of the tile count (sizes grids and per-tile arrays)
     uint64_t n_terms;
     const uint32_t *tomb;
     const uint32_t *tomb_summary;  // 1 bit per 16 docs: most bit tests stop at this small, L2-resident array
@@ -238,13 +242,14 @@ struct MergeParams {
     const unsigned long long *poff;   // [k * (n_terms+1)] position in raw of list (s, t)
     const uint4 *rng;                 // [2 * n_tiles * k] the slice of list (s, t0) inside the tile's doc range (k_merge_tile_ranges)
     const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' input counts: scratch slot of each term
-    uint32_t *tmp;                // scratch: parked survivors
-    uint32_t *tile_count;         // [n_tiles+1] survivors per tile
-    unsigned long long *tile_slot;   // [n_tiles] where in tmp the tile parked them
+    const uint32_t *n_tiles_dev;  // the tile count, computed on the device by the plan kernels
+    uint32_t *tmp;                // scratch: leaves of an oversized tile wait here until the tile's output offset is known
+    unsigned long long *tile_state;  // [n_tiles] chained scan over the tiles: bits 63..62 = 1 (this tile's count) / 2 (inclusive prefix), rest = value
+    uint32_t *tile_ticket;        // next tile to hand out (tiles are claimed in order, so a tile only ever waits for tiles that are running)
     uint32_t *out_counts;         // [n_terms] survivors per term (zeroed by the host)
     uint32_t *out_values;
     uint64_t out_cap;
-    uint64_t *d_total;            // total survivors
+    uint64_t *d_total;            // [0] total survivors, [3] != 0: the chained scan gave up waiting (reported as an error)
     unsigned long long *debug;    // optional diagnostics words
 };
 hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s);
@@ -254,14 +259,13 @@ hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, con
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0 = nullptr,
                               hipEvent_t ev1 = nullptr);
-hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *out, hipStream_t s);
+hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *segtab, hipStream_t s);
 hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s);
 hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s);
 hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
                              uint32_t grid_rows, hipStream_t s);
-hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, uint32_t *ends, void *rng, hipStream_t s);
-hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s);
-hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
+hipError_t launch_merge_tile_ranges(const MergeParams &p, const MergeSegs &ms, const void *desc, uint32_t *ends, void *rng, hipStream_t s);
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 
 }  // namespace ii2

@@ -36,10 +36,11 @@ static_assert(NBK == 8u * MT && NBK + 4u <= 2u * OFFMAX, "bucket counters alias 
 // ---- pass 1: decode everything once --------------------------------------------------------
 // global block g of the merge input -> (segment, block of that segment)
 __device__ __forceinline__ uint32_t seg_of_gblock(const MergeSegs &p, uint32_t g) {
-    uint32_t lo = 0, hi = p.k;          // seg_cum[lo] <= g < seg_cum[hi]
+    const uint32_t *cum = p.segtab + p.k;
+    uint32_t lo = 0, hi = p.k;          // cum[lo] <= g < cum[hi]
     while (hi - lo > 1u) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (p.seg_cum[mid] <= g) lo = mid; else hi = mid;
+        if (cum[mid] <= g) lo = mid; else hi = mid;
     }
     return lo;
 }
@@ -54,10 +55,14 @@ __global__ void k_mlist_counts(MergeSegs p, uint32_t *__restrict__ lc) {
     lc[i] = t < p.n_terms ? p.segs[s].cnt[t] : 0u;
 }
 
-// first block of every segment's term range and the end of it: [2s] = blk_off[0], [2s+1] = blk_off[T]
-__global__ void k_mseg_blocks(MergeSegs p, uint32_t *__restrict__ out) {
+// segtab: [s] = first block of segment s's term range, [k + s] = blocks of the segments before s, [2k] = all blocks (one wave)
+__global__ void k_mseg_blocks(MergeSegs p, uint32_t *__restrict__ segtab) {
     const uint32_t s = threadIdx.x;
-    if (s < p.k) { out[2 * s] = p.segs[s].blk_off[0]; out[2 * s + 1] = p.segs[s].blk_off[p.n_terms]; }
+    uint32_t b0 = 0, cnt = 0;
+    if (s < p.k) { b0 = p.segs[s].blk_off[0]; cnt = p.segs[s].blk_off[p.n_terms] - b0; }
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (s < p.k) { segtab[s] = b0; segtab[p.k + s] = incl - cnt; }
+    if (s == 63u) segtab[2u * p.k] = incl;
 }
 
 // Every block but a list's last holds II2_DV1_BLOCK postings, so block j of list (s, t) decodes to
@@ -71,10 +76,10 @@ struct BlkRef { bool valid, big; uint32_t s, q0, q1, first; unsigned long long p
 __device__ __forceinline__ BlkRef blk_ref(const MergeSegs &p, const unsigned long long *__restrict__ poff, uint64_t g, bool want_pos) {
     BlkRef r;
     r.valid = false; r.big = false; r.s = 0; r.q0 = 0; r.q1 = 0; r.first = 0; r.pos = 0;
-    if (g >= p.seg_cum[p.k]) return r;
+    if (g >= p.segtab[2u * p.k]) return r;
     const uint32_t s = seg_of_gblock(p, (uint32_t)g);
     const SegView sv = p.segs[s];
-    const uint32_t b = p.seg_b0[s] + ((uint32_t)g - p.seg_cum[s]);
+    const uint32_t b = p.segtab[s] + ((uint32_t)g - p.segtab[p.k + s]);
     const uint32_t t = sv.blk_list[b] - sv.list_base;
     if (t >= p.n_terms) return r;
     const ii2_skip e0 = sv.skip[b];
@@ -203,7 +208,7 @@ __global__ void k_merge_term_tile(MergeParams p, const uint32_t *__restrict__ nt
 __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile,
                                   uint4 *__restrict__ desc) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= p.n_tiles) return;
+    if (tile >= *p.n_tiles_dev) return;
     // last term whose first tile <= tile
     uint64_t lo = 0, hi = p.n_terms;           // term_tile[lo] <= tile < term_tile[hi] (term_tile[n_terms] = n_tiles)
     while (hi - lo > 1) {
@@ -248,19 +253,31 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
     }
 }
 
-// ends[tile * k + s] = postings of list (s, t0) with doc <= the tile's upper bound (large-term tiles only)
-__global__ void k_merge_tile_ends(MergeParams p, const uint4 *__restrict__ desc, uint32_t *__restrict__ ends) {
+// ends[tile * k + s] = postings of list (s, t0) with doc <= the tile's upper bound (large-term tiles only).
+// Two levels: the block is found in the segment's skip table (8 bytes per 256 postings, cache-resident), only the last
+// eight steps touch the decoded list itself — the searches over the raw arrays used to fetch 0.8 GB per merge.
+__global__ void k_merge_tile_ends(MergeParams p, MergeSegs ms, const uint4 *__restrict__ desc, uint32_t *__restrict__ ends) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)p.n_tiles * p.k) return;
+    if (i >= (uint64_t)*p.n_tiles_dev * p.k) return;
     const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
     const uint4 td = desc[tile];
     if (td.z == 0u && td.w == 0xFFFFFFFFu) return;           // whole lists: nothing to search
     const uint64_t n1 = p.n_terms + 1;
     const uint64_t beg = p.poff[s * n1 + td.x], end = p.poff[s * n1 + td.y];
-    const uint32_t *lst = p.raw + beg;
-    uint32_t lo = 0, hi = (uint32_t)(end - beg);
-    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
-    ends[i] = lo;
+    const uint32_t len = (uint32_t)(end - beg);
+    const SegView sv = ms.segs[s];
+    const uint32_t b_lo = sv.blk_off[td.x], b_hi = sv.blk_off[td.x + 1u];
+    uint32_t a = b_lo, b = b_hi;                              // first block of the list whose first doc is > td.w
+    while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (sv.skip[mid].first_doc <= td.w) a = mid + 1u; else b = mid; }
+    uint32_t res = 0;
+    if (a > b_lo) {                                           // block a - 1 starts at or before td.w: the boundary lies inside it (or at its end)
+        const uint32_t base = (a - 1u - b_lo) * II2_DV1_BLOCK;
+        const uint32_t *lst = p.raw + beg + base;
+        uint32_t lo = 0, hi = len - base < II2_DV1_BLOCK ? len - base : II2_DV1_BLOCK;
+        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
+        res = base + lo;
+    }
+    ends[i] = res;
 }
 
 // where every segment's list enters and leaves a tile's doc range: rng[2 * (tile * k + s)] =
@@ -268,7 +285,7 @@ __global__ void k_merge_tile_ends(MergeParams p, const uint4 *__restrict__ desc,
 // rng[.. + 1] = (first doc, last doc of the slice, -, -).  A range starts where the previous tile of the term ended.
 __global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, const uint32_t *__restrict__ ends, uint4 *__restrict__ rng) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)p.n_tiles * p.k) return;
+    if (i >= (uint64_t)*p.n_tiles_dev * p.k) return;
     const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
     const uint4 td = desc[tile];
     const uint64_t n1 = p.n_terms + 1;
@@ -304,6 +321,9 @@ struct __align__(16) MergeSmem {
     uint32_t n_in;
     uint32_t rank;                      // input postings of the tile's term(s) that precede the tile's doc range
     uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
+    uint32_t next_tile;                 // tile claimed for the next round of the loop
+    uint32_t pad2;
+    unsigned long long excl;            // output offset of the current tile (chained scan)
 };
 
 // block-wide exclusive scan of one value per thread (MT threads); returns exclusive prefix, total in *tot
@@ -338,7 +358,16 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
     }
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
-    for (uint32_t tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
+    // Tiles are handed out in order by a ticket counter: a tile then only ever waits (chained scan below) for tiles
+    // with smaller numbers, which running workgroups hold — no assumption about which workgroups are resident.
+    const uint32_t n_tiles = *p.n_tiles_dev;
+    if (tid == 0) sm.next_tile = atomicAdd(p.tile_ticket, 1u);
+    __syncthreads();
+    for (;;) {
+        const uint32_t tile = sm.next_tile;
+        if (tile >= n_tiles) break;
+        __syncthreads();
+        if (tid == 0) sm.next_tile = atomicAdd(p.tile_ticket, 1u);     // the next ticket is in flight during this tile
         const uint4 td = tile_desc[tile];
         const uint32_t t0 = td.x, t1 = td.y;
         const uint32_t nt = t1 - t0;
@@ -844,25 +873,25 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
 
         const uint32_t dlo = td.z, dhi = td.w;
         const bool root_full = dlo == 0u && dhi == 0xFFFFFFFFu;
-        // The tile parks its survivors in the scratch array at the input rank of its first posting
-        // (term slots start at the prefix of the terms' input counts), which no other tile can reach:
-        // survivors never outnumber the inputs that precede the next tile.  A later pass packs them.
+        // Survivors go straight to their final place: the tile's output offset is the number of survivors of all tiles
+        // before it, obtained by a chained scan over the tiles (each tile publishes its count, then sums its
+        // predecessors' counts back to the nearest tile that already knows its own inclusive prefix).  Only the leaves
+        // of an oversized tile wait in scratch (at the input rank of the tile's first posting) until that offset is known.
         const unsigned long long term_slot = p.ub_prefix[t0];
         unsigned long long slot = term_slot;
-        uint32_t total = 0;
+        uint32_t total = 0, outbuf = 0;
+        bool direct = false;
         if (dlo <= dhi) {
-            uint32_t outbuf = 0;
             const bool fits = load_range(dlo, dhi, true);
             slot = term_slot + sm.rank;                  // rank of the range start (0 for whole-term tiles)
             if (fits) {
                 // range tiles of a large term leave its count to k_merge_large_counts: an atomicAdd per tile would put
                 // thousands of same-address device atomics in flight (the top terms own most tiles)
                 total = merge_range(&outbuf, root_full, false);
-                const uint32_t *V = sm.vals[outbuf];
-                for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
+                direct = true;
             } else {
                 // the range holds more than LDS (a term whose lists are clustered differently): bisect the
-                // doc range; leaves are handled in doc order and appended to the tile's slot.
+                // doc range; leaves are handled in doc order and appended to the tile's scratch slot.
                 uint32_t sp = 1;
                 __syncthreads();
                 if (tid == 0) { sm.stk[0][0] = dlo; sm.stk[0][1] = dhi; }
@@ -889,36 +918,76 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                 }
             }
         }
-        if (tid == 0) { p.tile_count[tile] = total; p.tile_slot[tile] = slot; }
+        II2_STAMP(6)          // (G: leaves parked)
+        // ---- chained scan: wave 0 publishes the count and looks back ----
         __syncthreads();
-        II2_STAMP(6)          // G: park survivors
+        if (wv == 0) {
+            constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
+            unsigned long long excl = 0;
+            if (tile > 0u) {
+                if (l == 0) __hip_atomic_store(&p.tile_state[tile], (1ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                long long idx = (long long)tile - 1;      // nearest predecessor not summed yet
+                unsigned spins = 0;
+                for (;;) {
+                    const long long j = idx - l;
+                    unsigned long long v = 2ull << 62;    // before tile 0: a prefix of 0
+                    if (j >= 0) v = __hip_atomic_load(&p.tile_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t flag = (uint32_t)(v >> 62);
+                    const unsigned long long pfx = __ballot(flag == 2u), rdy = __ballot(flag != 0u);
+                    const int fp = pfx ? __ffsll((long long)pfx) - 1 : 64;          // nearest tile that knows its inclusive prefix
+                    const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
+                    if ((rdy & need) != need) {           // a nearer tile has not even published its count yet
+                        __builtin_amdgcn_s_sleep(8);
+                        if (++spins > (1u << 24)) {       // seconds: something is badly wrong — report instead of hanging the GPU
+                            if (l == 0) atomicAdd((unsigned long long *)&p.d_total[3], 1ull);
+                            break;
+                        }
+                        continue;
+                    }
+                    unsigned long long val = l <= fp ? (v & VMASK) : 0ull;
+                    for (int d = 32; d >= 1; d >>= 1) val += (unsigned long long)__shfl_xor((long long)val, d, 64);
+                    excl += val;
+                    if (fp < 64) break;
+                    idx -= 64;
+                }
+            }
+            if (l == 0) {
+                __hip_atomic_store(&p.tile_state[tile], (2ull << 62) | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sm.excl = excl;
+                if (tile == n_tiles - 1u) p.d_total[0] = excl + total;
+            }
+        }
+        __syncthreads();
+        {
+            const unsigned long long excl = sm.excl;
+            if (direct) {
+                const uint32_t *V = sm.vals[outbuf];
+                for (uint32_t q = (uint32_t)tid; q < total; q += MT)
+                    if (excl + q < p.out_cap) p.out_values[excl + q] = V[q];
+            } else if (total) {
+                __threadfence();                          // the leaves were written by other threads of this workgroup
+                __syncthreads();
+                for (uint32_t q = (uint32_t)tid; q < total; q += MT)
+                    if (excl + q < p.out_cap) p.out_values[excl + q] = __builtin_nontemporal_load(&p.tmp[slot + q]);
+            }
+        }
+        __syncthreads();
+        II2_STAMP(7)          // H: chained scan + write-out
     }
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
 #undef II2_STAMP
 }
 
-// packs the parked survivors: tile t's ids go to out[off[t] ...]
-__global__ __launch_bounds__(256) void k_merge_pack(const uint32_t *__restrict__ tmp, const unsigned long long *__restrict__ slot,
-                                                    const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ off, uint32_t n_tiles,
-                                                    uint32_t *__restrict__ out, uint64_t out_cap, uint64_t *__restrict__ d_total) {
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint32_t c = cnt[tile];
-        const uint64_t ob = off[tile];
-        const uint32_t *src = tmp + slot[tile];
-        for (uint32_t q = threadIdx.x; q < c; q += 256u)
-            if (ob + q < out_cap) out[ob + q] = src[q];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = off[n_tiles];
-}
-
-// survivors of every large term = survivors of its tiles (tile_off = exclusive scan of the tile counts)
-__global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile, const uint64_t *__restrict__ tile_off,
-                                     uint64_t n_terms, uint32_t *__restrict__ out_counts) {
+// survivors of every large term = survivors of its tiles, read off the chained scan's inclusive prefixes
+__global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile,
+                                     const unsigned long long *__restrict__ tile_state, uint64_t n_terms, uint32_t *__restrict__ out_counts) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_terms || ntl[t] == 0u) return;
+    constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
     const uint32_t a = term_tile[t];
-    out_counts[t] = (uint32_t)(tile_off[a + ntl[t]] - tile_off[a]);
+    const unsigned long long hi = tile_state[a + ntl[t] - 1u] & VMASK, lo = a ? tile_state[a - 1u] & VMASK : 0ull;
+    out_counts[t] = (uint32_t)(hi - lo);
 }
 
 // one atomic per workgroup, few workgroups: a single address sustains only ~90 device atomics per microsecond
@@ -937,8 +1006,8 @@ __global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *__restric
 
 static unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_mseg_blocks, dim3(1), dim3(64), 0, s, p, out);
+hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *segtab, hipStream_t s) {
+    hipLaunchKernelGGL(k_mseg_blocks, dim3(1), dim3(64), 0, s, p, segtab);
     return hipGetLastError();
 }
 hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s) {
@@ -946,24 +1015,24 @@ hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s) 
     return hipGetLastError();
 }
 hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s) {
-    const uint64_t total = p.seg_cum[p.k];
+    const uint64_t total = p.total_ub;
     if (total == 0) return hipSuccess;
     hipLaunchKernelGGL(k_mbig_count, dim3(grid_for(total)), dim3(256), 0, s, p, wgcnt);
     return hipGetLastError();
 }
 hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
                              uint32_t grid_rows, hipStream_t s) {
-    const uint64_t total = p.seg_cum[p.k];
+    const uint64_t total = p.total_ub;
     if (total == 0) return hipSuccess;
     const unsigned nwg = grid_for(total);
     hipLaunchKernelGGL(k_mdec_lane, dim3(nwg), dim3(256), 0, s, p, poff, raw, wgbase, (uint4 *)ent0, (uint2 *)ent1);
     hipLaunchKernelGGL(k_mdec_rows, dim3(grid_rows), dim3(256), 0, s, p, raw, (const uint4 *)ent0, (const uint2 *)ent1, wgbase + nwg);
     return hipGetLastError();
 }
-hipError_t launch_merge_tile_ranges(const MergeParams &p, const void *desc, uint32_t *ends, void *rng, hipStream_t s) {
-    if (p.n_tiles == 0) return hipSuccess;
-    const unsigned g = grid_for((uint64_t)p.n_tiles * p.k);
-    hipLaunchKernelGGL(k_merge_tile_ends, dim3(g), dim3(256), 0, s, p, (const uint4 *)desc, ends);
+hipError_t launch_merge_tile_ranges(const MergeParams &p, const MergeSegs &ms, const void *desc, uint32_t *ends, void *rng, hipStream_t s) {
+    if (p.n_tiles_ub == 0) return hipSuccess;
+    const unsigned g = grid_for((uint64_t)p.n_tiles_ub * p.k);
+    hipLaunchKernelGGL(k_merge_tile_ends, dim3(g), dim3(256), 0, s, p, ms, (const uint4 *)desc, ends);
     hipLaunchKernelGGL(k_merge_tile_ranges, dim3(g), dim3(256), 0, s, p, (const uint4 *)desc, (const uint32_t *)ends, (uint4 *)rng);
     return hipGetLastError();
 }
@@ -982,27 +1051,20 @@ hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, con
     return hipGetLastError();
 }
 hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s) {
-    if (p.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
+    if (p.n_tiles_ub == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles_ub)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
     return hipGetLastError();
 }
-hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s) {
-    if (p.n_terms == 0 || p.n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, ntl, term_tile, tile_off, p.n_terms, p.out_counts);
-    return hipGetLastError();
-}
-hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s) {
-    if (p.n_tiles == 0) return hipSuccess;
-    const uint32_t g = p.n_tiles < 16384u ? p.n_tiles : 16384u;
-    hipLaunchKernelGGL(k_merge_pack, dim3(g), dim3(256), 0, s, (const uint32_t *)p.tmp, (const unsigned long long *)p.tile_slot,
-                       (const uint32_t *)p.tile_count, tile_off, p.n_tiles, p.out_values, p.out_cap, p.d_total);
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, hipStream_t s) {
+    if (p.n_terms == 0 || p.n_tiles_ub == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, ntl, term_tile, (const unsigned long long *)p.tile_state, p.n_terms, p.out_counts);
     return hipGetLastError();
 }
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (p.n_tiles == 0) return hipSuccess;
+    if (p.n_tiles_ub == 0) return hipSuccess;
     if (ev0) (void)hipEventRecord(ev0, s);
-    if (p.k == 16u) hipLaunchKernelGGL(k_merge_tiles<16u>, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
-    else hipLaunchKernelGGL(k_merge_tiles<0u>, dim3(grid < p.n_tiles ? grid : p.n_tiles), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
+    if (p.k == 16u) hipLaunchKernelGGL(k_merge_tiles<16u>, dim3(grid < p.n_tiles_ub ? grid : p.n_tiles_ub), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
+    else hipLaunchKernelGGL(k_merge_tiles<0u>, dim3(grid < p.n_tiles_ub ? grid : p.n_tiles_ub), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
     if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }

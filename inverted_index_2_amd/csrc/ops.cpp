@@ -41,13 +41,18 @@ template <class T> static T *carve(uint8_t *&cursor, size_t count) {
     return p;
 }
 
-// Core: k SegViews over n_terms aligned term slots -> d_out_off (u64[n_terms+1], may be null),
-// d_out_values.  Blocking (reads back the tile count, then total / surviving terms).
-static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n_terms, const ii2_tomb *tomb,
-                      uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
+// Core: k SegViews over n_terms aligned term slots -> d_out_off (u64[n_terms+1], may be null), d_out_values.
+// blocks_ub / postings_ub: host-side upper bounds of the views' blocks and postings — every grid and every scratch
+// array is sized from them, so the call enqueues all its kernels without a single host round trip and only reads three
+// scalars back at the end.
+static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n_terms, uint64_t blocks_ub, uint64_t postings_ub,
+                      const ii2_tomb *tomb, uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
     hipStream_t st = ctx->stream;
     const uint64_t T = n_terms;
     if (T >= (1ull << 31) - 2) return fail(ctx, II2_ERANGE, "too many term slots");
+    if (blocks_ub >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many input blocks");
+    if (postings_ub >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: more than 2^32 input postings in one call");
+    if (tomb && tomb->device != ctx->device) return fail(ctx, II2_EINVAL, "tombstones live on another device");
     MergeParams p;
     std::memset(&p, 0, sizeof p);
     MergeSegs ms;
@@ -55,6 +60,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     for (uint32_t s = 0; s < k; s++) ms.segs[s] = views[s];
     ms.k = k;
     ms.n_terms = T;
+    ms.total_ub = (uint32_t)blocks_ub;
     p.k = k;
     p.n_terms = T;
     p.tomb = tomb ? tomb->d_words : nullptr;
@@ -70,37 +76,28 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.wmin = (cap + nt_max - 1u) / nt_max;  // <= cap / wmin <= nt_max terms per batch
     if (p.wmin > p.small_max) p.wmin = p.small_max;
     p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : (cap / 4u) * 3u;   // exact counts: leave slack for uneven lists
+    // upper bound of the tile count (the exact one is computed on the device and stays there): a large term has more than
+    // small_max postings and takes ceil(u / large_tile) tiles; a batch ends when its weight passes batch_q or a large term
+    // interrupts the run of small ones
+    const uint64_t n_large_ub = postings_ub / ((uint64_t)p.small_max + 1u);
+    const uint64_t tiles_ub64 = postings_ub / p.large_tile + n_large_ub + (postings_ub + T * p.wmin) / p.batch_q + n_large_ub + 4;
+    if (tiles_ub64 >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many tiles");
+    p.n_tiles_ub = (uint32_t)tiles_ub64;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;          // option profile.events: the pair brackets the WHOLE call, first launch to last
     if (ii2_profile_pair(ctx, &e0, &e1)) (void)hipEventRecord(e0, st);
-    // ---- pass 1: decode every input list once into a raw scratch array (grow-only aux buffers) ----
-    auto grow = [&](uint8_t *&buf, size_t &cap, size_t bytes) -> bool {
-        if (bytes <= cap) return true;
+    auto grow = [&](uint8_t *&buf, size_t &bcap, size_t bytes) -> bool {
+        if (bytes <= bcap) return true;
         (void)hipStreamSynchronize(st);
         if (buf) (void)hipFree(buf);
         buf = nullptr;
-        cap = 0;
+        bcap = 0;
         const size_t want = align_up(bytes + bytes / 8, 1 << 20);
         if (hipMalloc((void **)&buf, want) != hipSuccess) return false;
-        cap = want;
+        bcap = want;
         return true;
     };
-    {
-        uint32_t *d_sb = (uint32_t *)(ctx->d_mail + 16);
-        uint32_t h_sb[2 * MAX_LISTS];
-        HIP_TRY(ctx, launch_mseg_blocks(ms, d_sb, st));
-        HIP_TRY(ctx, hipMemcpyAsync(h_sb, d_sb, 2 * k * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        uint64_t cum = 0;
-        for (uint32_t s = 0; s < k; s++) {
-            ms.seg_b0[s] = h_sb[2 * s];
-            ms.seg_cum[s] = (uint32_t)cum;
-            cum += h_sb[2 * s + 1] - h_sb[2 * s];
-        }
-        if (cum >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many input blocks");
-        ms.seg_cum[k] = (uint32_t)cum;
-    }
-    const size_t totalB = ms.seg_cum[k];
+    const size_t totalB = (size_t)blocks_ub;
     const size_t n1 = (size_t)T + 1;
     const size_t nl = (size_t)k * n1;
     const size_t scan_b = scan_temp_bytes(std::max<size_t>(nl + 1, totalB + 1));
@@ -109,7 +106,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     size_t need = align_up((totalB + 1) * sizeof(uint4)) + align_up((totalB + 1) * sizeof(uint2)) + 2 * align_up((nwg + 1) * sizeof(uint32_t)) +
                   align_up(nl * sizeof(uint32_t)) +
                   align_up(nl * sizeof(uint64_t)) + 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) +
-                  scan_b + 4096;
+                  align_up((2 * MAX_LISTS + 2) * sizeof(uint32_t)) + scan_b + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     uint8_t *cur = ctx->ws;
@@ -129,17 +126,29 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint32_t *d_cnt = carve<uint32_t>(cur, n1);
     uint64_t *d_wpre = carve<uint64_t>(cur, n1);
     uint64_t *d_ubpre = carve<uint64_t>(cur, n1);
+    uint32_t *d_segtab = carve<uint32_t>(cur, 2 * MAX_LISTS + 2);
     void *d_scan = cur;
+    if (!grow(ctx->aux2, ctx->aux2_cap, (postings_ub + 64) * sizeof(uint32_t))) return fail(ctx, II2_ENOMEM, "merge raw scratch allocation failed");
+    uint32_t *d_raw = (uint32_t *)ctx->aux2;
+    // per-tile arrays and the scratch in which the leaves of oversized tiles wait
+    const size_t nt1 = (size_t)p.n_tiles_ub + 1;
+    const size_t aux_need = align_up(64) + align_up(nt1 * 16) + align_up(nt1 * sizeof(uint64_t)) +
+                            align_up(nt1 * k * 2 * sizeof(uint4)) + align_up(nt1 * k * sizeof(uint32_t)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
+    if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
+    uint8_t *ac = ctx->aux;
+    p.tile_ticket = carve<uint32_t>(ac, 16);               // (zeroed together with the scan states: one memset from the allocation's start)
+    p.tile_state = (unsigned long long *)carve<uint64_t>(ac, nt1);
+    void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
+    uint4 *d_rng = carve<uint4>(ac, nt1 * k * 2);
+    uint32_t *d_ends = carve<uint32_t>(ac, nt1 * k);
+    p.tmp = carve<uint32_t>(ac, postings_ub + 64);
 
+    // ---- pass 1: decode every input list once into a raw scratch array ----
+    ms.segtab = d_segtab;
+    HIP_TRY(ctx, launch_mseg_blocks(ms, d_segtab, st));
     // list (s, t) goes to raw[poff[s, t] ...]: the segments know their lists' posting counts
     HIP_TRY(ctx, launch_mlist_counts(ms, d_lc, st));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_lc, (uint64_t *)d_poff, nl, st));
-    uint64_t n_in = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_in, d_poff + (nl - 1), sizeof n_in, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (n_in >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: more than 2^32 input postings in one call");
-    if (!grow(ctx->aux2, ctx->aux2_cap, (n_in + 64) * sizeof(uint32_t))) return fail(ctx, II2_ENOMEM, "merge raw scratch allocation failed");
-    uint32_t *d_raw = (uint32_t *)ctx->aux2;
     HIP_TRY(ctx, hipMemsetAsync(d_wgcnt + nwg, 0, sizeof(uint32_t), st));
     HIP_TRY(ctx, launch_mbig_count(ms, d_wgcnt, st));
     HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_wgcnt, d_wgbase, nwg + 1, st));
@@ -155,35 +164,15 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, launch_merge_heads(p, d_ntl, d_wpre, d_head, st));
     HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
     HIP_TRY(ctx, launch_merge_term_tile(p, d_ntl, d_head, d_hpre, d_lpre, d_tt, st));
-    uint32_t n_tiles = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&n_tiles, d_tt + T, sizeof n_tiles, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    p.n_tiles = n_tiles;
+    p.n_tiles_dev = d_tt + T;                   // term_tile[T] = number of tiles
     p.ub_prefix = (const unsigned long long *)d_ubpre;
-
-    // ---- per-tile arrays and the scratch the tiles park their survivors in ----
-    const size_t nt1 = (size_t)n_tiles + 1;
-    const size_t scan_t = scan_temp_bytes(nt1);
-    const size_t aux_need = align_up(nt1 * 16) + align_up(nt1 * sizeof(uint32_t)) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
-                            align_up(nt1 * k * 2 * sizeof(uint4)) + align_up(nt1 * k * sizeof(uint32_t)) + align_up((n_in + 64) * sizeof(uint32_t)) + 4096;
-    if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
-    uint8_t *ac = ctx->aux;
-    void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
-    p.tile_count = carve<uint32_t>(ac, nt1);
-    p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
-    uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
-    void *d_scan_t = carve<uint8_t>(ac, scan_t);
-    uint4 *d_rng = carve<uint4>(ac, nt1 * k * 2);
-    uint32_t *d_ends = carve<uint32_t>(ac, nt1 * k);
-    p.tmp = carve<uint32_t>(ac, n_in + 64);
-
     HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, d_tile_desc, st));
-    HIP_TRY(ctx, launch_merge_tile_ranges(p, d_tile_desc, d_ends, d_rng, st));
+    HIP_TRY(ctx, launch_merge_tile_ranges(p, ms, d_tile_desc, d_ends, d_rng, st));
     p.rng = d_rng;
     p.out_counts = d_cnt;
     p.out_values = d_out_values;
     p.out_cap = out_cap;
-    p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
+    p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms, [3] chained-scan failure
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
         if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
@@ -192,17 +181,19 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
     HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(p.tile_count + n_tiles, 0, sizeof(uint32_t), st));
-    // 2 workgroups of ~67 KB LDS per CU; each walks tiles w, w+grid, ...
+    HIP_TRY(ctx, hipMemsetAsync(ctx->aux, 0, align_up(64) + align_up(nt1 * sizeof(uint64_t)), st));      // ticket + scan states
+    // 2 workgroups of ~67 KB LDS per CU; tiles are handed out by ticket
     HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
-    HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, d_tile_off, st));
-    HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
+    HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, st));
     HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
     if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
     if (e1) (void)hipEventRecord(e1, st);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 4, p.n_tiles_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint32_t n_tiles = (uint32_t)(ctx->h_mail[4] & 0xFFFFFFFFull);
+    if (n_tiles > p.n_tiles_ub) return fail(ctx, II2_EHIP, "merge: internal error (tile bound exceeded)");
+    if (ctx->h_mail[3]) return fail(ctx, II2_EHIP, "merge: the chained scan over the tiles timed out");
     if (n_tiles == 0) ctx->h_mail[0] = 0;
     if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small (content unspecified)");
     if (stats) {
@@ -228,14 +219,15 @@ static int merge_unlocked(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, 
     if (rc) return rc;
     if (!d_out_values) return fail(ctx, II2_EINVAL, "merge: output buffer is NULL");
     std::vector<SegView> views(k);
-    uint64_t n_in = 0;
+    uint64_t n_in = 0, n_blk = 0;
     for (uint32_t s = 0; s < k; s++) {
         views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt, segs[s]->d_blk_list, 0u, 0u};
-        n_in += segs[s]->n_postings;
+        n_in += segs[s]->n_postings;       // (views made by ii2_seg_select carry their store's totals: upper bounds)
+        n_blk += segs[s]->n_blocks;
     }
     ii2_merge_stats local;
     std::memset(&local, 0, sizeof local);
-    rc = merge_core(ctx, k, views.data(), segs[0]->n_lists, tomb, d_out_off, d_out_values, out_cap, &local);
+    rc = merge_core(ctx, k, views.data(), segs[0]->n_lists, n_blk, n_in, tomb, d_out_off, d_out_values, out_cap, &local);
     if (rc) return rc;
     local.n_in = n_in;
     if (stats) *stats = local;
@@ -282,12 +274,15 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
     if (n == 0 || n > MAX_LISTS || !segs) return fail(ctx, II2_EINVAL, "ii2_union: list count must be 1..64");
     std::vector<SegView> views(n);
     bool any = false;
+    uint64_t blocks_ub = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint64_t li = list_idx ? list_idx[i] : 0;
         if (!segs[i] || segs[i]->device != ctx->device || li >= segs[i]->n_lists) return fail(ctx, II2_EINVAL, "ii2_union: bad list");
+        if (int rc0 = ii2_seg_host_blk_off(ctx, segs[i])) return rc0;
         // a one-term view of the segment: blk_off shifted to the list
         views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_cnt + li, segs[i]->d_blk_list, (uint32_t)li, 0u};
         any |= segs[i]->h_blk_off[li + 1] > segs[i]->h_blk_off[li];
+        blocks_ub += segs[i]->h_blk_off[li + 1] - segs[i]->h_blk_off[li];
     }
     if (!any) { *count = 0; return II2_OK; }
     if (!d_out) return fail(ctx, II2_EINVAL, "ii2_union: output buffer is NULL");
@@ -305,7 +300,7 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
     }
     ii2_merge_stats st;
     std::memset(&st, 0, sizeof st);
-    int rc = merge_core(ctx, n, views.data(), 1, tomb, nullptr, d_out, cap, &st);
+    int rc = merge_core(ctx, n, views.data(), 1, blocks_ub, blocks_ub * II2_DV1_BLOCK, tomb, nullptr, d_out, cap, &st);
     if (rc) return rc;
     *count = st.n_out;
     return II2_OK;

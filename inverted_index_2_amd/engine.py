@@ -176,6 +176,32 @@ class Context:
         self._ck(self.lib.ii2_tomb_create(self.h, _ptr(removed), n, where, C.byref(t)))
         return Tombstones(self, t)
 
+    # ---- term alignment on the device -------------------------------------------------------
+    def align_terms(self, dictionaries) -> "Alignment":
+        """k sorted, duplicate-free term dictionaries (lists of bytes) -> their union, on the device (the k-way term walk of
+        makeIterator, shard.go:253-278, in bytes.Compare order)."""
+        flat = [t for d in dictionaries for t in d]
+        off = np.zeros(len(flat) + 1, np.uint64)
+        if flat:
+            off[1:] = np.cumsum([len(t) for t in flat])
+        blob = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8).copy()
+        first = np.zeros(len(dictionaries) + 1, np.uint64)
+        first[1:] = np.cumsum([len(d) for d in dictionaries])
+        h = C.c_void_p()
+        self._ck(self.lib.ii2_align_terms(self.h, len(dictionaries), _ptr(blob), _ptr(off), _ptr(first), C.byref(h)))
+        return Alignment(self, h, flat)
+
+    def select_aligned(self, seg: "Segment", alignment: "Alignment", s: int, first_list: int = 0) -> "Segment":
+        out = C.c_void_p()
+        self._ck(self.lib.ii2_seg_select_aligned(self.h, seg.h, alignment.h, s, first_list, C.byref(out)))
+        return Segment(self, out)
+
+    def select(self, seg: "Segment", src_list) -> "Segment":
+        src = _np(src_list, np.int64)
+        out = C.c_void_p()
+        self._ck(self.lib.ii2_seg_select(self.h, seg.h, src.size, _ptr(src), C.byref(out)))
+        return Segment(self, out)
+
     # ---- operators ------------------------------------------------------------------------
     def _listargs(self, lists):
         segs = (C.c_void_p * len(lists))(*[s.h for s, _ in lists])
@@ -334,6 +360,36 @@ class Segment:
     def __del__(self):
         try:
             if not sys.is_finalizing():      # at interpreter exit the HIP runtime may already be gone
+                self.free()
+        except Exception:
+            pass
+
+
+class Alignment:
+    """Device-resident result of Context.align_terms (ii2_align)."""
+
+    def __init__(self, ctx: Context, h: C.c_void_p, flat_terms):
+        self.ctx, self.h, self._flat = ctx, h, flat_terms
+        n, k = C.c_uint64(), C.c_uint32()
+        ctx.lib.ii2_align_info(h, C.byref(n), C.byref(k))
+        self.n_union, self.k = n.value, k.value
+
+    def export(self):
+        """(union terms as bytes, src_list int64 [k][n_union])."""
+        rep = np.zeros(max(self.n_union, 1), np.uint64)
+        src = np.zeros(max(self.k * self.n_union, 1), np.int64)
+        self.ctx._ck(self.ctx.lib.ii2_align_export(self.ctx.h, self.h, _ptr(rep), _ptr(src)))
+        terms = [self._flat[int(g)] for g in rep[: self.n_union]]
+        return terms, src[: self.k * self.n_union].reshape(self.k, self.n_union)
+
+    def free(self) -> None:
+        if self.h:
+            self.ctx.lib.ii2_align_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if not sys.is_finalizing():
                 self.free()
         except Exception:
             pass

@@ -189,26 +189,61 @@ class Shard {
         std::vector<std::shared_ptr<SegHandle>> views;
     };
     Aligned align(ii2_ctx *ctx, const std::vector<const Segment *> &segs, const Term *min, const Term *max) const {
+        // every segment's dictionary restricted to [min, max] is a run of consecutive terms (the dictionaries are sorted);
+        // the k-way dictionary merge itself runs on the device (ii2_align_terms) and so does the construction of the
+        // aligned views (ii2_seg_select_aligned): the host only flattens the byte strings
         Aligned a;
-        for (auto *s : segs)
-            for (auto &t : s->terms) {
-                if (min && term_less(t, *min)) continue;
-                if (max && term_less(*max, t)) continue;
-                a.terms.push_back(t);
+        struct Part { const Segment *seg; size_t j0, j1; };
+        std::vector<Part> parts;
+        for (auto *s : segs) {
+            size_t j0 = 0, j1 = s->terms.size();
+            if (min) j0 = std::lower_bound(s->terms.begin(), s->terms.end(), *min, term_less) - s->terms.begin();
+            if (max) j1 = std::upper_bound(s->terms.begin(), s->terms.end(), *max, term_less) - s->terms.begin();
+            if (j0 >= j1) continue;                // segment has nothing in range: skipped (shard.go:257-261)
+            parts.push_back(Part{s, j0, j1});
+        }
+        if (parts.empty()) return a;
+        std::vector<std::shared_ptr<SegHandle>> views;
+        // the library aligns at most II2_MAX_LISTS dictionaries per call: more segments are aligned in groups against the
+        // union of the previous groups (kept as an extra dictionary)... the host mirror keeps it simple and aligns in one
+        // call when it can, else falls back to groups of II2_MAX_LISTS merged pairwise by fold_to_limit's rounds
+        const size_t kmax = II2_MAX_LISTS;
+        if (parts.size() <= kmax) {
+            std::string bytes;
+            std::vector<uint64_t> off{0}, first{0};
+            for (auto &pt : parts) {
+                for (size_t j = pt.j0; j < pt.j1; j++) { bytes += pt.seg->terms[j]; off.push_back(bytes.size()); }
+                first.push_back(off.size() - 1);
             }
+            ii2_align *al = nullptr;
+            ck(ctx, ii2_align_terms(ctx, (uint32_t)parts.size(), (const uint8_t *)bytes.data(), off.data(), first.data(), &al), "index read");
+            struct AlignGuard { ii2_align *h; ~AlignGuard() { ii2_align_free(h); } } guard{al};
+            uint64_t nu = 0;
+            ii2_align_info(al, &nu, nullptr);
+            std::vector<uint64_t> rep(nu);
+            ck(ctx, ii2_align_export(ctx, al, rep.data(), nullptr), "index read");
+            a.terms.reserve(nu);
+            for (uint64_t u = 0; u < nu; u++) a.terms.emplace_back(bytes.data() + off[rep[u]], off[rep[u] + 1] - off[rep[u]]);
+            for (size_t i = 0; i < parts.size(); i++) {
+                ii2_seg *v = nullptr;
+                ck(ctx, ii2_seg_select_aligned(ctx, parts[i].seg->seg->h, al, (uint32_t)i, parts[i].j0, &v), "index read");
+                a.views.push_back(std::make_shared<SegHandle>(v));
+            }
+            return a;
+        }
+        // more than II2_MAX_LISTS segments: union dictionary on the host, views through ii2_seg_select
+        for (auto &pt : parts) a.terms.insert(a.terms.end(), pt.seg->terms.begin() + pt.j0, pt.seg->terms.begin() + pt.j1);
         std::sort(a.terms.begin(), a.terms.end(), term_less);
         a.terms.erase(std::unique(a.terms.begin(), a.terms.end()), a.terms.end());
-        for (auto *s : segs) {
+        for (auto &pt : parts) {
             std::vector<int64_t> src(a.terms.size(), -1);
-            size_t j = 0;
-            bool any = false;
+            size_t j = pt.j0;
             for (size_t i = 0; i < a.terms.size(); i++) {
-                while (j < s->terms.size() && term_less(s->terms[j], a.terms[i])) j++;
-                if (j < s->terms.size() && s->terms[j] == a.terms[i]) { src[i] = (int64_t)j; any = true; }
+                while (j < pt.j1 && term_less(pt.seg->terms[j], a.terms[i])) j++;
+                if (j < pt.j1 && pt.seg->terms[j] == a.terms[i]) src[i] = (int64_t)j;
             }
-            if (!any) continue;                    // segment has nothing in range: skipped (shard.go:257-261)
             ii2_seg *v = nullptr;
-            ck(ctx, ii2_seg_select(ctx, s->seg->h, a.terms.size(), src.data(), &v), "index read");
+            ck(ctx, ii2_seg_select(ctx, pt.seg->seg->h, a.terms.size(), src.data(), &v), "index read");
             a.views.push_back(std::make_shared<SegHandle>(v));
         }
         return a;

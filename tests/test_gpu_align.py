@@ -1,0 +1,114 @@
+"""GPU: term alignment on the device (csrc/align.hip) against the host alignment in
+file.CompareTermValues / bytes.Compare order (file/types.go:24-26, oracle orc_compare_terms): random byte strings with
+shared prefixes, 1-byte and empty terms, \\x00 and \\xff bytes, lengths across several 8-byte chunks; then the aligned
+views it builds feed a merge whose result equals the oracle's."""
+import functools
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.gpu_util import ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def host_align(dicts):
+    union = sorted(set(t for d in dicts for t in d), key=functools.cmp_to_key(orc.compare_terms))
+    pos = {t: i for i, t in enumerate(union)}
+    src = np.full((len(dicts), len(union)), -1, np.int64)
+    for s, d in enumerate(dicts):
+        for j, t in enumerate(d):
+            src[s, pos[t]] = j
+    return union, src
+
+
+def rand_dicts(rng, k, n, alphabet, maxlen):
+    pool = set()
+    assert n <= 0.8 * sum(len(alphabet) ** i for i in range(maxlen + 1)), "not enough distinct strings"
+    while len(pool) < n:
+        ln = int(rng.integers(0, maxlen + 1))
+        pool.add(bytes(rng.choice(alphabet, ln).tolist()))
+    pool = sorted(pool, key=functools.cmp_to_key(orc.compare_terms))
+    dicts = []
+    for _ in range(k):
+        keep = rng.random(len(pool)) < rng.uniform(0.2, 0.9)
+        dicts.append([t for t, m in zip(pool, keep) if m])
+    return dicts
+
+
+@pytest.mark.parametrize("k,n,alphabet,maxlen", [
+    (2, 12, [0x61, 0x62], 3),                     # heavy prefix sharing, empty term possible (15 distinct strings exist)
+    (5, 400, [0x00, 0x01, 0xFF, 0x61], 9),        # \\x00 / \\xff bytes, lengths straddle one 8-byte chunk
+    (16, 3000, list(range(256)), 19),             # any byte, three chunks (the reference's test terms are 2-20 bytes)
+    (64, 2000, [0x61, 0x7A, 0x41], 12),
+    (3, 30, [0xFF], 40),                          # pure length order: \\xff, \\xff\\xff, ... (41 distinct strings exist)
+])
+def test_device_alignment_equals_host_alignment(ctx, k, n, alphabet, maxlen):
+    rng = np.random.default_rng(k * 1000 + n)
+    dicts = rand_dicts(rng, k, n, alphabet, maxlen)
+    want_terms, want_src = host_align(dicts)
+    al = ctx.align_terms(dicts)
+    terms, src = al.export()
+    assert al.n_union == len(want_terms) and terms == want_terms
+    assert np.array_equal(src, want_src)
+
+
+def test_edge_dictionaries(ctx):
+    for dicts in ([[b""], [b""]], [[b"a"], []], [[], []], [[b"a", b"ab", b"b"], [b"", b"a\x00", b"ab"]],
+                  [[b"\xff" * 8, b"\xff" * 9], [b"\xff" * 8 + b"\x00"]]):
+        want_terms, want_src = host_align(dicts)
+        al = ctx.align_terms(dicts)
+        terms, src = al.export()
+        assert terms == want_terms and np.array_equal(src.reshape(want_src.shape), want_src), dicts
+
+
+def test_fixed_width_ids_take_the_one_sort_path(ctx):
+    # the synthetic configs' terms: 8-byte big-endian ids, so byte order = numeric order
+    rng = np.random.default_rng(3)
+    ids = [np.sort(rng.choice(200_000, 60_000, replace=False)) for _ in range(8)]
+    dicts = [[int(x).to_bytes(8, "big") for x in a] for a in ids]
+    al = ctx.align_terms(dicts)
+    terms, src = al.export()
+    union = np.unique(np.concatenate(ids))
+    assert al.n_union == union.size and terms[:3] == [int(x).to_bytes(8, "big") for x in union[:3]]
+    for s in range(8):
+        assert np.array_equal(np.flatnonzero(src[s] >= 0), np.searchsorted(union, ids[s]))
+        assert np.array_equal(src[s][src[s] >= 0], np.arange(ids[s].size))
+
+
+def test_aligned_views_feed_the_merge(ctx):
+    # k segments with their own term dictionaries -> device alignment -> aligned views -> merge == oracle on host-aligned CSR
+    rng = np.random.default_rng(11)
+    k = 6
+    dicts = rand_dicts(rng, k, 900, [0x61, 0x62, 0x63, 0x7A], 7)
+    segs, lists = [], []
+    for d in dicts:
+        ls = [np.unique(rng.integers(0, 50_000, int(rng.integers(1, 700)))).astype(np.uint32) for _ in d]
+        lists.append(ls)
+        segs.append(ctx.encode_lists(ls))
+    union, src = host_align(dicts)
+    al = ctx.align_terms(dicts)
+    views = [ctx.select_aligned(segs[s], al, s) for s in range(k)]
+    host_views = [ctx.select(segs[s], src[s]) for s in range(k)]
+    removed = np.unique(rng.integers(0, 50_000, 800)).astype(np.uint32)
+    tomb = ctx.tombstones(removed)
+    offs, vals = [], []
+    for s in range(k):
+        cnt = [lists[s][j].size if j >= 0 else 0 for j in src[s]]
+        off = np.zeros(len(union) + 1, np.uint64)
+        off[1:] = np.cumsum(cnt)
+        offs.append(off)
+        vals.append(np.concatenate([lists[s][j] for j in src[s] if j >= 0]) if any(j >= 0 for j in src[s]) else np.empty(0, np.uint32))
+    w_off, w_vals, _ = orc.merge_segments(offs, vals, removed)
+    for vs in (views, host_views):
+        out_off, out_vals, st = ctx.merge(vs, tomb)
+        assert np.array_equal(out_off.download(), w_off) and np.array_equal(out_vals.download(int(st.n_out)), w_vals)
+    # a dictionary that is a slice of a segment's terms (range-restricted Read): first_list shifts the view
+    lo = len(dicts[0]) // 3
+    al2 = ctx.align_terms([dicts[0][lo:], dicts[1]])
+    v0 = ctx.select_aligned(segs[0], al2, 0, first_list=lo)
+    po, v = ctx.merge_to_segment([v0])[0].decode()
+    terms2, src2 = al2.export()
+    want = [lists[0][lo + j] if j >= 0 else np.empty(0, np.uint32) for j in src2[0]]
+    assert np.array_equal(v, np.concatenate(want)) and np.array_equal(np.diff(po.astype(np.int64)), [w.size for w in want])
