@@ -243,13 +243,13 @@ struct MergeParams {
     const uint4 *rng;                 // [2 * n_tiles * k] the slice of list (s, t0) inside the tile's doc range (k_merge_tile_ranges)
     const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' input counts: scratch slot of each term
     const uint32_t *n_tiles_dev;  // the tile count, computed on the device by the plan kernels
-    uint32_t *tmp;                // scratch: leaves of an oversized tile wait here until the tile's output offset is known
-    unsigned long long *tile_state;  // [n_tiles] chained scan over the tiles: bits 63..62 = 1 (this tile's count) / 2 (inclusive prefix), rest = value
-    uint32_t *tile_ticket;        // next tile to hand out (tiles are claimed in order, so a tile only ever waits for tiles that are running)
+    uint32_t *tmp;                // scratch: parked survivors
+    uint32_t *tile_count;         // [n_tiles_ub+1] survivors per tile (zeroed by the host: entries past the real tile count stay 0)
+    unsigned long long *tile_slot;   // [n_tiles_ub] where in tmp the tile parked them
     uint32_t *out_counts;         // [n_terms] survivors per term (zeroed by the host)
     uint32_t *out_values;
     uint64_t out_cap;
-    uint64_t *d_total;            // [0] total survivors, [3] != 0: the chained scan gave up waiting (reported as an error)
+    uint64_t *d_total;            // total survivors
     unsigned long long *debug;    // optional diagnostics words
 };
 hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s);
@@ -265,7 +265,8 @@ hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s)
 hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
                              uint32_t grid_rows, hipStream_t s);
 hipError_t launch_merge_tile_ranges(const MergeParams &p, const MergeSegs &ms, const void *desc, uint32_t *ends, void *rng, hipStream_t s);
-hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, hipStream_t s);
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s);
+hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 
 }  // namespace ii2

@@ -321,9 +321,6 @@ struct __align__(16) MergeSmem {
     uint32_t n_in;
     uint32_t rank;                      // input postings of the tile's term(s) that precede the tile's doc range
     uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
-    uint32_t next_tile;                 // tile claimed for the next round of the loop
-    uint32_t pad2;
-    unsigned long long excl;            // output offset of the current tile (chained scan)
 };
 
 // block-wide exclusive scan of one value per thread (MT threads); returns exclusive prefix, total in *tot
@@ -358,16 +355,8 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
     }
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
-    // Tiles are handed out in order by a ticket counter: a tile then only ever waits (chained scan below) for tiles
-    // with smaller numbers, which running workgroups hold — no assumption about which workgroups are resident.
-    const uint32_t n_tiles = *p.n_tiles_dev;
-    if (tid == 0) sm.next_tile = atomicAdd(p.tile_ticket, 1u);
-    __syncthreads();
-    for (;;) {
-        const uint32_t tile = sm.next_tile;
-        if (tile >= n_tiles) break;
-        __syncthreads();
-        if (tid == 0) sm.next_tile = atomicAdd(p.tile_ticket, 1u);     // the next ticket is in flight during this tile
+    const uint32_t n_tiles = *p.n_tiles_dev;       // computed by the plan kernels; the host only knows an upper bound
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint4 td = tile_desc[tile];
         const uint32_t t0 = td.x, t1 = td.y;
         const uint32_t nt = t1 - t0;
@@ -873,25 +862,28 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
 
         const uint32_t dlo = td.z, dhi = td.w;
         const bool root_full = dlo == 0u && dhi == 0xFFFFFFFFu;
-        // Survivors go straight to their final place: the tile's output offset is the number of survivors of all tiles
-        // before it, obtained by a chained scan over the tiles (each tile publishes its count, then sums its
-        // predecessors' counts back to the nearest tile that already knows its own inclusive prefix).  Only the leaves
-        // of an oversized tile wait in scratch (at the input rank of the tile's first posting) until that offset is known.
+        // The tile parks its survivors in the scratch array at the input rank of its first posting
+        // (term slots start at the prefix of the terms' input counts), which no other tile can reach:
+        // survivors never outnumber the inputs that precede the next tile.  A later pass packs them.
+        // (Tried in round 2: writing survivors straight to their final place through a chained scan over the tiles — with
+        // ~500 tiles in flight every tile waits for its slowest predecessor; the scan + write-out took 61 % of a workgroup's
+        // time and the merge went from 4.3 to 7.3 ms.  Tiles must stay independent.)
         const unsigned long long term_slot = p.ub_prefix[t0];
         unsigned long long slot = term_slot;
-        uint32_t total = 0, outbuf = 0;
-        bool direct = false;
+        uint32_t total = 0;
         if (dlo <= dhi) {
+            uint32_t outbuf = 0;
             const bool fits = load_range(dlo, dhi, true);
             slot = term_slot + sm.rank;                  // rank of the range start (0 for whole-term tiles)
             if (fits) {
                 // range tiles of a large term leave its count to k_merge_large_counts: an atomicAdd per tile would put
                 // thousands of same-address device atomics in flight (the top terms own most tiles)
                 total = merge_range(&outbuf, root_full, false);
-                direct = true;
+                const uint32_t *V = sm.vals[outbuf];
+                for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
             } else {
                 // the range holds more than LDS (a term whose lists are clustered differently): bisect the
-                // doc range; leaves are handled in doc order and appended to the tile's scratch slot.
+                // doc range; leaves are handled in doc order and appended to the tile's slot.
                 uint32_t sp = 1;
                 __syncthreads();
                 if (tid == 0) { sm.stk[0][0] = dlo; sm.stk[0][1] = dhi; }
@@ -918,76 +910,37 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                 }
             }
         }
-        II2_STAMP(6)          // (G: leaves parked)
-        // ---- chained scan: wave 0 publishes the count and looks back ----
+        if (tid == 0) { p.tile_count[tile] = total; p.tile_slot[tile] = slot; }
         __syncthreads();
-        if (wv == 0) {
-            constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
-            unsigned long long excl = 0;
-            if (tile > 0u) {
-                if (l == 0) __hip_atomic_store(&p.tile_state[tile], (1ull << 62) | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                long long idx = (long long)tile - 1;      // nearest predecessor not summed yet
-                unsigned spins = 0;
-                for (;;) {
-                    const long long j = idx - l;
-                    unsigned long long v = 2ull << 62;    // before tile 0: a prefix of 0
-                    if (j >= 0) v = __hip_atomic_load(&p.tile_state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t flag = (uint32_t)(v >> 62);
-                    const unsigned long long pfx = __ballot(flag == 2u), rdy = __ballot(flag != 0u);
-                    const int fp = pfx ? __ffsll((long long)pfx) - 1 : 64;          // nearest tile that knows its inclusive prefix
-                    const unsigned long long need = fp >= 63 ? ~0ull : ((2ull << fp) - 1ull);
-                    if ((rdy & need) != need) {           // a nearer tile has not even published its count yet
-                        __builtin_amdgcn_s_sleep(8);
-                        if (++spins > (1u << 24)) {       // seconds: something is badly wrong — report instead of hanging the GPU
-                            if (l == 0) atomicAdd((unsigned long long *)&p.d_total[3], 1ull);
-                            break;
-                        }
-                        continue;
-                    }
-                    unsigned long long val = l <= fp ? (v & VMASK) : 0ull;
-                    for (int d = 32; d >= 1; d >>= 1) val += (unsigned long long)__shfl_xor((long long)val, d, 64);
-                    excl += val;
-                    if (fp < 64) break;
-                    idx -= 64;
-                }
-            }
-            if (l == 0) {
-                __hip_atomic_store(&p.tile_state[tile], (2ull << 62) | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sm.excl = excl;
-                if (tile == n_tiles - 1u) p.d_total[0] = excl + total;
-            }
-        }
-        __syncthreads();
-        {
-            const unsigned long long excl = sm.excl;
-            if (direct) {
-                const uint32_t *V = sm.vals[outbuf];
-                for (uint32_t q = (uint32_t)tid; q < total; q += MT)
-                    if (excl + q < p.out_cap) p.out_values[excl + q] = V[q];
-            } else if (total) {
-                __threadfence();                          // the leaves were written by other threads of this workgroup
-                __syncthreads();
-                for (uint32_t q = (uint32_t)tid; q < total; q += MT)
-                    if (excl + q < p.out_cap) p.out_values[excl + q] = __builtin_nontemporal_load(&p.tmp[slot + q]);
-            }
-        }
-        __syncthreads();
-        II2_STAMP(7)          // H: chained scan + write-out
+        II2_STAMP(6)          // G: park survivors
     }
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
 #undef II2_STAMP
 }
 
-// survivors of every large term = survivors of its tiles, read off the chained scan's inclusive prefixes
-__global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile,
-                                     const unsigned long long *__restrict__ tile_state, uint64_t n_terms, uint32_t *__restrict__ out_counts) {
+// packs the parked survivors: tile t's ids go to out[off[t] ...]
+__global__ __launch_bounds__(256) void k_merge_pack(const uint32_t *__restrict__ tmp, const unsigned long long *__restrict__ slot,
+                                                    const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ off, const uint32_t *__restrict__ n_tiles_dev,
+                                                    uint32_t *__restrict__ out, uint64_t out_cap, uint64_t *__restrict__ d_total) {
+    const uint32_t n_tiles = *n_tiles_dev;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t c = cnt[tile];
+        const uint64_t ob = off[tile];
+        const uint32_t *src = tmp + slot[tile];
+        for (uint32_t q = threadIdx.x; q < c; q += 256u)
+            if (ob + q < out_cap) out[ob + q] = src[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = off[n_tiles];
+}
+
+// survivors of every large term = survivors of its tiles (tile_off = exclusive scan of the tile counts)
+__global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile, const uint64_t *__restrict__ tile_off,
+                                     uint64_t n_terms, uint32_t *__restrict__ out_counts) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_terms || ntl[t] == 0u) return;
-    constexpr unsigned long long VMASK = (1ull << 62) - 1ull;
     const uint32_t a = term_tile[t];
-    const unsigned long long hi = tile_state[a + ntl[t] - 1u] & VMASK, lo = a ? tile_state[a - 1u] & VMASK : 0ull;
-    out_counts[t] = (uint32_t)(hi - lo);
+    out_counts[t] = (uint32_t)(tile_off[a + ntl[t]] - tile_off[a]);
 }
 
 // one atomic per workgroup, few workgroups: a single address sustains only ~90 device atomics per microsecond
@@ -1055,9 +1008,16 @@ hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, con
     hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles_ub)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
     return hipGetLastError();
 }
-hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, hipStream_t s) {
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s) {
     if (p.n_terms == 0 || p.n_tiles_ub == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, ntl, term_tile, (const unsigned long long *)p.tile_state, p.n_terms, p.out_counts);
+    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, ntl, term_tile, tile_off, p.n_terms, p.out_counts);
+    return hipGetLastError();
+}
+hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s) {
+    if (p.n_tiles_ub == 0) return hipSuccess;
+    const uint32_t g = p.n_tiles_ub < 16384u ? p.n_tiles_ub : 16384u;
+    hipLaunchKernelGGL(k_merge_pack, dim3(g), dim3(256), 0, s, (const uint32_t *)p.tmp, (const unsigned long long *)p.tile_slot,
+                       (const uint32_t *)p.tile_count, tile_off, p.n_tiles_dev, p.out_values, p.out_cap, p.d_total);
     return hipGetLastError();
 }
 hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {

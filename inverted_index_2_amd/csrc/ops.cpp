@@ -132,12 +132,15 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint32_t *d_raw = (uint32_t *)ctx->aux2;
     // per-tile arrays and the scratch in which the leaves of oversized tiles wait
     const size_t nt1 = (size_t)p.n_tiles_ub + 1;
-    const size_t aux_need = align_up(64) + align_up(nt1 * 16) + align_up(nt1 * sizeof(uint64_t)) +
+    const size_t scan_t = scan_temp_bytes(nt1);
+    const size_t aux_need = align_up(nt1 * sizeof(uint32_t)) + align_up(nt1 * 16) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
                             align_up(nt1 * k * 2 * sizeof(uint4)) + align_up(nt1 * k * sizeof(uint32_t)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
     if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
-    p.tile_ticket = carve<uint32_t>(ac, 16);               // (zeroed together with the scan states: one memset from the allocation's start)
-    p.tile_state = (unsigned long long *)carve<uint64_t>(ac, nt1);
+    p.tile_count = carve<uint32_t>(ac, nt1);               // (first in the allocation: zeroed by one memset from its start)
+    p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
+    uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
+    void *d_scan_t = carve<uint8_t>(ac, scan_t);
     void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
     uint4 *d_rng = carve<uint4>(ac, nt1 * k * 2);
     uint32_t *d_ends = carve<uint32_t>(ac, nt1 * k);
@@ -172,7 +175,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.out_counts = d_cnt;
     p.out_values = d_out_values;
     p.out_cap = out_cap;
-    p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms, [3] chained-scan failure
+    p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
         if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
@@ -181,10 +184,12 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
     HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->aux, 0, align_up(64) + align_up(nt1 * sizeof(uint64_t)), st));      // ticket + scan states
-    // 2 workgroups of ~67 KB LDS per CU; tiles are handed out by ticket
+    HIP_TRY(ctx, hipMemsetAsync(p.tile_count, 0, align_up(nt1 * sizeof(uint32_t)), st));      // tiles past the real count contribute 0 to the scan
+    // 2 workgroups of ~67 KB LDS per CU; each walks tiles w, w+grid, ...
     HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st));
-    HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
+    HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, d_tile_off, st));
+    HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
     HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
     if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
     if (e1) (void)hipEventRecord(e1, st);
@@ -193,7 +198,6 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint32_t n_tiles = (uint32_t)(ctx->h_mail[4] & 0xFFFFFFFFull);
     if (n_tiles > p.n_tiles_ub) return fail(ctx, II2_EHIP, "merge: internal error (tile bound exceeded)");
-    if (ctx->h_mail[3]) return fail(ctx, II2_EHIP, "merge: the chained scan over the tiles timed out");
     if (n_tiles == 0) ctx->h_mail[0] = 0;
     if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small (content unspecified)");
     if (stats) {

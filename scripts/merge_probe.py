@@ -25,8 +25,8 @@ nwg = 512
 buf = (C.c_uint64 * (nwg * 8))()
 ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, nwg * 8))
 arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
-names = ["A ranges/table", "E1 bucket fold", "E2 single-term pairwise", "D gather", "E3 multi-term fold", "F filter/compact", "G park", "-"]
+names = ["A ranges/table", "E1 bucket fold", "E2 single-term pairwise", "D gather", "E3 multi-term fold", "F filter/compact", "G leaves", "H scan + write-out"]
 tot = arr.sum(axis=1).mean()
 print("mean cycles per WG", tot, "tiles per WG", st.n_tiles / nwg)
-for i, nm in enumerate(names[:7]):
+for i, nm in enumerate(names[:8]):
     print(f"  {nm:18s} {arr[:, i].mean():12.0f}  {100 * arr[:, i].mean() / tot:5.1f}%")
