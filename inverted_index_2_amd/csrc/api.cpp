@@ -596,6 +596,26 @@ static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListVi
     return II2_OK;
 }
 
+// first doc, first doc of the last block and last doc of a non-empty list: fetched once per (segment, list), then cached
+static int list_span(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, const ListView &v, ii2_seg::ListSpan *out) {
+    {
+        std::lock_guard<std::mutex> sg(seg->span_mu);
+        auto hit = seg->span_cache.find(idx);
+        if (hit != seg->span_cache.end()) { *out = hit->second; return II2_OK; }
+    }
+    ii2_skip e[2];
+    uint32_t last = 0;
+    hipStream_t st = ctx->stream;
+    HIP_TRY(ctx, hipMemcpyAsync(&e[0], v.skip, sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&e[1], v.skip + (v.nblk - 1), sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&last, v.last_doc, sizeof last, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    *out = ii2_seg::ListSpan{e[0].first_doc, e[1].first_doc, last};
+    std::lock_guard<std::mutex> sg(seg->span_mu);
+    seg->span_cache[idx] = *out;
+    return II2_OK;
+}
+
 static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
                               const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count) {
     if (n == 0 || n > MAX_LISTS || !segs || !d_count) return fail(ctx, II2_EINVAL, "ii2_intersect: bad argument");
@@ -614,7 +634,16 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         return II2_OK;
     }
     if (!d_out) return fail(ctx, II2_EINVAL, "ii2_intersect: output buffer is NULL");
-    std::stable_sort(views.begin(), views.end(), [](const ListView &a, const ListView &b) { return a.nblk < b.nblk; });
+    std::vector<uint32_t> order(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return views[a].nblk < views[b].nblk; });
+    std::vector<const ii2_seg *> vseg(n);
+    std::vector<uint64_t> vidx(n);
+    {
+        std::vector<ListView> sorted(n);
+        for (uint32_t i = 0; i < n; i++) { sorted[i] = views[order[i]]; vseg[i] = segs[order[i]]; vidx[i] = list_idx ? list_idx[order[i]] : 0; }
+        views.swap(sorted);
+    }
     for (uint32_t i = 0; i < n; i++) p.lists[i] = views[i];
     p.n_lists = n;
     const uint32_t nblk0 = views[0].nblk;
@@ -624,30 +653,8 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     uint32_t dense_first_doc = 0, dense_last_doc = 0;
     if (ctx->opt_intersect_g > 0) G = (uint32_t)std::min<int64_t>(ctx->opt_intersect_g, ISECT_GMAX);
     else if (nblk0 > 1) {
-        const ii2_seg *dseg = nullptr;
-        uint64_t didx = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            const uint64_t li = list_idx ? list_idx[i] : 0;
-            if (segs[i]->d_skip + segs[i]->h_blk_off[li] == views[0].skip) { dseg = segs[i]; didx = li; break; }
-        }
         ii2_seg::ListSpan ends;
-        bool cached = false;
-        {
-            std::lock_guard<std::mutex> sg(dseg->span_mu);
-            auto hit = dseg->span_cache.find(didx);
-            if (hit != dseg->span_cache.end()) { ends = hit->second; cached = true; }
-        }
-        if (!cached) {
-            ii2_skip e[2];
-            uint32_t last = 0;
-            HIP_TRY(ctx, hipMemcpyAsync(&e[0], views[0].skip, sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(&e[1], views[0].skip + (nblk0 - 1), sizeof(ii2_skip), hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(&last, views[0].last_doc, sizeof last, hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipStreamSynchronize(st));
-            ends = {e[0].first_doc, e[1].first_doc, last};
-            std::lock_guard<std::mutex> sg(dseg->span_mu);
-            dseg->span_cache[didx] = ends;
-        }
+        if (int rc = list_span(ctx, vseg[0], vidx[0], views[0], &ends)) return rc;
         const double per_block = (double)(ends.last_block_first_doc - ends.first_doc) / (double)(nblk0 - 1);
         per_block_span = per_block;
         dense_first_doc = ends.first_doc;
@@ -663,7 +670,13 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         per_block_span > 0 && per_block_span <= 1100.0) {
         DenseParams dp;
         std::memset(&dp, 0, sizeof dp);
-        for (uint32_t i = 0; i < n; i++) dp.lists[i] = views[i];
+        for (uint32_t i = 0; i < n; i++) {
+            dp.lists[i] = views[i];
+            ii2_seg::ListSpan sp;
+            if (int rc = list_span(ctx, vseg[i], vidx[i], views[i], &sp)) return rc;
+            dp.first_doc[i] = sp.first_doc;
+            dp.last_doc[i] = sp.last_doc;
+        }
         dp.n_lists = n;
         // a wave's passes take 16 driver blocks each; one round (16 blocks) per wave by default: more, shorter waves balance
         // better than fewer, longer ones (measured on Zipf rank pairs 1/2 ... 2/3/5), and waves never wait for each other

@@ -154,8 +154,9 @@ constexpr uint32_t DENSE_MAXL = 4;             // lists it takes
 constexpr uint32_t DENSE_CAPW = 16384;         // docs per LDS window of a wave
 struct DenseParams {
     ListView lists[DENSE_MAXL];  // lists[0] is the driver (fewest blocks)
+    uint32_t first_doc[DENSE_MAXL], last_doc[DENSE_MAXL];   // of every list (host copies: starting guess of the block search)
     uint32_t n_lists;
-    uint32_t bpw;                // driver blocks per wave (a multiple of 4)
+    uint32_t bpw;                // driver blocks per wave (a multiple of 16)
     uint32_t n_waves;            // waves with work; the grid is ceil(n_waves / 4) workgroups
     uint32_t n_meta;             // entries of meta (4 per workgroup)
     uint32_t base32;             // first doc of the driver & ~31: origin of the result bitmap

@@ -116,7 +116,23 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
         uint32_t a[NL > 1 ? NL - 1 : 1];
 #pragma unroll
         for (uint32_t j = 1; j < NL; j++) {
-            const uint32_t ub = uni(wave_skip_upper_bound(p.lists[j].skip, p.lists[j].nblk, lo_w));
+            // one probe of 64 entries around a linear guess first (the lists of a dense query are close to uniform: it nearly
+            // always brackets the answer and costs one memory round trip instead of three); the full search otherwise
+            const ListView L = p.lists[j];
+            const uint32_t fj = p.first_doc[j], lj = p.last_doc[j];
+            uint32_t ub = 0xFFFFFFFFu;
+            if (L.nblk > 64u && lj > fj) {
+                const uint64_t rel = lo_w > fj ? (uint64_t)(lo_w - fj) : 0ull;
+                uint64_t gss = rel * L.nblk / ((uint64_t)(lj - fj) + 1ull);
+                if (gss > L.nblk) gss = L.nblk;
+                uint32_t wb = gss > 32ull ? (uint32_t)gss - 32u : 0u;
+                if (wb + 64u > L.nblk) wb = L.nblk - 64u;
+                const uint32_t fdoc = L.skip[wb + (uint32_t)l].first_doc;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(fdoc <= lo_w));   // first docs ascend: the matches are a prefix
+                if ((cnt > 0u || wb == 0u) && (cnt < 64u || wb + 64u == L.nblk)) ub = wb + cnt;
+            }
+            if (ub == 0xFFFFFFFFu) ub = wave_skip_upper_bound(L.skip, L.nblk, lo_w);
+            ub = uni(ub);
             a[j - 1] = ub ? ub - 1u : 0u;
         }
 
@@ -270,6 +286,11 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             const bool act = live && (inrange || haswide);
             const bool exactlane = haswide && !inrange;
             const uint32_t lim = wspan + 2u * DN_GU - 64u;                       // a position in the upper guard: where out-of-window groups are parked
+            // the bitmap's place inside the workgroup's LDS array is folded into the position (the array's own address is a
+            // link-time constant that ends up in the ds instruction's offset field: no address add per group)
+            uint32_t *lds_all = &lds[0][0];
+            const uint32_t bmbits = (uint32_t)(bm - lds_all) * 32u;
+            auto lds_word = [&](uint32_t q) -> uint32_t * { return lds_all + ((bmbits + q) >> 5); };
             if (act) {
                 // a group's mask starts AT the posting before it (bit 0 = position q: the block's first doc for the row's
                 // first lane, else a posting an earlier group already set — setting it again is harmless)
@@ -277,7 +298,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
 #pragma unroll
                 for (uint32_t k = 0; k < 16u; k++) {
                     const uint32_t x = ww[k];
-                    const bool isw = exactlane || pre[k] - prev >= 32u;          // the four gaps do not fit one 32-bit mask
+                    const bool isw = exactlane || pre[k] - prev >= 32u;          // the four gaps do not fit one 32-bit mask: placed by the loop below
                     uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;
                     M = (M << ((x >> 16) & 31u)) | 1u;
                     M = (M << ((x >> 8) & 31u)) | 1u;
@@ -285,12 +306,24 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                     M = isw ? 0u : M;
                     const uint32_t qc = q < lim ? q : lim;                       // groups beyond the window: harmless bits in the guard
                     const uint32_t sh = qc & 31u;
-                    uint32_t *dst = bm + (qc >> 5);
+                    uint32_t *dst = lds_word(qc);
                     atomicOr(dst, M << sh);
                     atomicOr(dst + 1, (M >> 1) >> (31u - sh));                   // the part that spills into the next word (0 for most)
-                    if (__ballot(isw) != 0ull) {                                 // rare (a few groups per thousand): posting by posting, exact range test
+                    prev = pre[k];
+                    q = u + prev;
+                }
+            }
+            // groups of four postings wider than 31 docs (a few per thousand in lists this dense) and every group of a lane that
+            // starts outside the window but has such a group: posting by posting, exact range test.  Skipped when no lane has one.
+            if (__ballot(act && haswide) != 0ull) {
+                uint32_t prev = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; k++) {
+                    const bool isw = act && haswide && (exactlane || pre[k] - prev >= 32u);
+                    if (__ballot(isw) != 0ull) {
                         if (isw) {
-                            uint32_t d = q - DN_GU;                              // doc - wlo of the posting before the group (mod 2^32)
+                            const uint32_t x = ww[k];
+                            uint32_t d = u + prev - DN_GU;                       // doc - wlo of the posting before the group (mod 2^32)
                             if (k == 0u && rl == 0u && d <= wspan) atomicOr(&bm[(d + DN_GU) >> 5], 1u << ((d + DN_GU) & 31u));   // the block's first doc
 #pragma unroll
                             for (uint32_t j = 0; j < 4u; j++) {
@@ -300,7 +333,6 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                         }
                     }
                     prev = pre[k];
-                    q = u + prev;
                 }
             }
         };
