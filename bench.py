@@ -58,16 +58,14 @@ def cores_available():
 
 
 def pmc_traffic(name):
-    """HBM bytes per pass from the PMC passes kept under profiles/ (same command, same workload) — a recorded figure,
-    not a counter of this run; the JSON says so (`traffic_source`)."""
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
-        try:
-            with open(path) as f:
-                return json.load(f)["hbm_bytes_per_pass_corrected"], os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+    """HBM bytes per pass from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the same
+    workload, scripts/pmc_run.sh) — a recorded figure, not a counter of this run; the JSON says so (`traffic_source`)."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name)
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_pass_corrected"], os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def cpu_baseline_intersect(lists, removed, reps, threads=1):
@@ -408,7 +406,8 @@ def bench_merge(job):
                "sample": "the whole workload once (%d postings in, %.1f s): oracle worker pool over term ranges, pairwise "
                          "concat+sort+compact fold and binary-search tombstone filter (oracle/ii2_oracle.c); this run is "
                          "also the correctness check of the GPU result" % (n_in, cdt)}
-    del offs, vals
+    host_offs = offs
+    del vals
     steps = args.merge_steps or min(args.steps, 10)
     dt, dev_ms, dev_n = time_merges(job, segs, tomb, out_off, out_vals, steps)
     alg = merge_alg_bytes(segs, T, k, args.docs, int(st.n_out))
@@ -431,6 +430,45 @@ def bench_merge(job):
     }
     if cpu is not None:
         res["cpu_baseline"] = cpu
+    # end to end with the term alignment on the device: every segment keeps only the terms it really holds
+    # (its own dictionary of 8-byte big-endian term ids); ii2_align_terms merges the k dictionaries, ii2_seg_select_aligned
+    # builds the aligned views, then the same merge runs on them
+    n_out_ref = int(st.n_out)
+    chk_ref = int(out_vals.download(min(n_out_ref, 1 << 22)).astype(np.uint64).sum())
+    try:
+        dict_ids, compact = [], []
+        for o, sg in zip(host_offs, segs):
+            present = np.flatnonzero(np.diff(o.astype(np.int64)) > 0)
+            dict_ids.append(present.astype(">u8"))
+            po, vv = sg.decode()
+            compact.append(ctx.encode(np.concatenate([[0], np.cumsum(np.diff(po.astype(np.int64))[present])]).astype(np.uint64), vv))
+            del po, vv
+        blob = np.frombuffer(b"".join(d.tobytes() for d in dict_ids), dtype=np.uint8)
+        n_all = sum(d.size for d in dict_ids)
+        toff = (np.arange(n_all + 1, dtype=np.uint64) * np.uint64(8))
+        first = np.concatenate([[0], np.cumsum([d.size for d in dict_ids])]).astype(np.uint64)
+        job.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        al = ctx.align_terms_flat(blob, toff, first)
+        t1 = time.perf_counter()
+        views = [ctx.select_aligned(c, al, i) for i, c in enumerate(compact)]
+        t2 = time.perf_counter()
+        _, _, st2 = ctx.merge(views, tomb, out_off, out_vals)
+        t3 = time.perf_counter()
+        ok = int(st2.n_out) == n_out_ref and al.n_union == T and \
+            int(out_vals.download(min(n_out_ref, 1 << 22)).astype(np.uint64).sum()) == chk_ref
+        res["end_to_end_with_device_alignment"] = {
+            "dictionary_terms_in": int(n_all), "union_terms": int(al.n_union), "align_ms": (t1 - t0) * 1e3, "select_views_ms": (t2 - t1) * 1e3,
+            "merge_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3, "value": n_in / (t3 - t0), "unit": "postings/s",
+            "note": "align_ms includes the upload of the flat dictionaries (host buffers, PCIe); one run, wall clock",
+            "check": "same result as the pre-aligned merge" if ok else "MISMATCH"}
+        if not ok:
+            job.rc = 5
+        for v in views + compact:
+            v.free()
+        al.free()
+    except Exception as e:  # noqa: BLE001 — the timed figures above stand on their own
+        res["end_to_end_with_device_alignment"] = {"error": repr(e)}
     for s in segs:
         s.free()
     out_off.free()

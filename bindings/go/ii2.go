@@ -97,37 +97,58 @@ func (c *Ctx) MergeAligned(k int, nTerms uint64, segOff, segBase []uint64, value
 	return outOff, outVals[:st.n_out], uint64(st.n_terms_out), nil
 }
 
+// Alignment is the device-resident result of AlignTerms.
+type Alignment struct {
+	h      *C.ii2_align
+	NUnion uint64
+	K      int
+}
+
 // AlignTerms replaces the k-way term-dictionary walk of makeIterator (shard.go:253-278,
-// bytes.Compare order of file/types.go:24-26): the k sorted dictionaries are given flat
-// (termBytes, termOff[nAll+1], segFirst[k+1] = first term of each segment in termOff);
-// it returns the union dictionary as indices into the input terms (one representative per
-// distinct term) and, per segment, srcList[s*nUnion+u] = list of segment s that holds union
-// term u, or -1.
-func (c *Ctx) AlignTerms(termBytes []byte, termOff []uint64, segFirst []uint64) (rep []uint64, srcList []int64, err error) {
-	k := len(segFirst) - 1
-	nAll := len(termOff) - 1
-	rep = make([]uint64, nAll)
-	srcList = make([]int64, k*nAll)
-	var nUnion C.uint64_t
+// bytes.Compare order of file/types.go:24-26) with one call: the k sorted dictionaries are
+// given flat (termBytes, termOff[nAll+1], segFirst[k+1] = index in termOff of each
+// dictionary's first term); the union dictionary and the per-segment mapping stay on the GPU.
+func (c *Ctx) AlignTerms(termBytes []byte, termOff []uint64, segFirst []uint64) (*Alignment, error) {
 	var tb *C.uint8_t
 	if len(termBytes) > 0 {
 		tb = (*C.uint8_t)(unsafe.Pointer(&termBytes[0]))
 	}
+	var a *C.ii2_align
+	if rc := C.ii2_align_terms(c.h, C.uint32_t(len(segFirst)-1), tb, u64ptr(termOff), u64ptr(segFirst), &a); rc != 0 {
+		return nil, c.err("align", rc)
+	}
+	var n C.uint64_t
+	var k C.uint32_t
+	C.ii2_align_info(a, &n, &k)
+	return &Alignment{h: a, NUnion: uint64(n), K: int(k)}, nil
+}
+
+// Export copies the alignment out: rep[u] = index (into termOff) of one input term equal to union
+// term u; srcList[s*NUnion+u] = index inside dictionary s of the term equal to union term u, or -1.
+func (c *Ctx) Export(a *Alignment) (rep []uint64, srcList []int64, err error) {
+	rep = make([]uint64, a.NUnion)
+	srcList = make([]int64, uint64(a.K)*a.NUnion)
 	var sl *C.int64_t
 	if len(srcList) > 0 {
 		sl = (*C.int64_t)(unsafe.Pointer(&srcList[0]))
 	}
-	rc := C.ii2_align_terms(c.h, C.uint32_t(k), tb, u64ptr(termOff), u64ptr(segFirst), u64ptr(rep), sl, &nUnion)
-	if rc != 0 {
-		return nil, nil, c.err("align", rc)
+	if rc := C.ii2_align_export(c.h, a.h, u64ptr(rep), sl); rc != 0 {
+		return nil, nil, c.err("align export", rc)
 	}
-	n := int(nUnion)
-	out := make([]int64, k*n)
-	for s := 0; s < k; s++ { // the library packs rows with stride nAll; repack with stride nUnion
-		copy(out[s*n:(s+1)*n], srcList[s*nAll:s*nAll+n])
-	}
-	return rep[:n], out, nil
+	return rep, srcList, nil
 }
+
+// SelectAligned builds, on the GPU, the term-aligned view of a resident segment for dictionary s
+// of the alignment (firstList = list of seg that corresponds to the dictionary's first term).
+func (c *Ctx) SelectAligned(seg *Segment, a *Alignment, s int, firstList uint64) (*Segment, error) {
+	var v *C.ii2_seg
+	if rc := C.ii2_seg_select_aligned(c.h, seg.h, a.h, C.uint32_t(s), C.uint64_t(firstList), &v); rc != 0 {
+		return nil, c.err("select", rc)
+	}
+	return &Segment{v}, nil
+}
+
+func (a *Alignment) Free() { C.ii2_align_free(a.h); a.h = nil }
 
 // Union replaces PrefixSearch's append + slices.Sort + slices.Compact (inverted_index.go:274-292).
 func (c *Ctx) Union(listOff []uint64, values, removed []uint32) ([]uint32, error) {

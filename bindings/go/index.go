@@ -60,11 +60,16 @@ func ShardMerge(c *Ctx, s HostShard, reqCount, mCount int) (mergedSegmentsLen in
 	}
 	defer s.Release()
 	tb, toff, first := s.Dictionaries(nil, nil)
-	rep, src, err := c.AlignTerms(tb, toff, first) // k-way dictionary merge on the device
+	al, err := c.AlignTerms(tb, toff, first) // k-way dictionary merge on the device
 	if err != nil {
 		return 0, fmt.Errorf("s: merge: %w", err)
 	}
-	nT := uint64(len(rep))
+	defer al.Free()
+	rep, src, err := c.Export(al)
+	if err != nil {
+		return 0, fmt.Errorf("s: merge: %w", err)
+	}
+	nT := al.NUnion
 	segOff := make([]uint64, 0, uint64(n)*(nT+1))
 	segBase := make([]uint64, 1, n+1)
 	var values []uint32
@@ -166,12 +171,18 @@ func (it *readIterator) Close() error {
 // read-locked all segments (readLockAll, segments.go:32).
 func ShardRead(c *Ctx, s HostShard, nSegs int, min, max []byte) (Iterator[TermValues], error) {
 	tb, toff, first := s.Dictionaries(min, max)
-	rep, src, err := c.AlignTerms(tb, toff, first)
+	al, err := c.AlignTerms(tb, toff, first)
 	if err != nil {
 		s.Release()
 		return nil, fmt.Errorf("index read: %w", err)
 	}
-	nT := uint64(len(rep))
+	defer al.Free()
+	rep, src, err := c.Export(al)
+	if err != nil {
+		s.Release()
+		return nil, fmt.Errorf("index read: %w", err)
+	}
+	nT := al.NUnion
 	var segOff, segBase []uint64
 	var values []uint32
 	segBase = append(segBase, 0)

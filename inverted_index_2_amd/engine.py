@@ -191,6 +191,13 @@ class Context:
         self._ck(self.lib.ii2_align_terms(self.h, len(dictionaries), _ptr(blob), _ptr(off), _ptr(first), C.byref(h)))
         return Alignment(self, h, flat)
 
+    def align_terms_flat(self, term_bytes: np.ndarray, term_off: np.ndarray, seg_first: np.ndarray) -> "Alignment":
+        """Same, from flat arrays (u8 bytes, u64 offsets [n_all + 1], u64 first term of each dictionary [k + 1])."""
+        blob, off, first = _np(term_bytes, np.uint8), _np(term_off, np.uint64), _np(seg_first, np.uint64)
+        h = C.c_void_p()
+        self._ck(self.lib.ii2_align_terms(self.h, first.size - 1, _ptr(blob), _ptr(off), _ptr(first), C.byref(h)))
+        return Alignment(self, h, None)
+
     def select_aligned(self, seg: "Segment", alignment: "Alignment", s: int, first_list: int = 0) -> "Segment":
         out = C.c_void_p()
         self._ck(self.lib.ii2_seg_select_aligned(self.h, seg.h, alignment.h, s, first_list, C.byref(out)))
@@ -379,7 +386,7 @@ class Alignment:
         rep = np.zeros(max(self.n_union, 1), np.uint64)
         src = np.zeros(max(self.k * self.n_union, 1), np.int64)
         self.ctx._ck(self.ctx.lib.ii2_align_export(self.ctx.h, self.h, _ptr(rep), _ptr(src)))
-        terms = [self._flat[int(g)] for g in rep[: self.n_union]]
+        terms = [self._flat[int(g)] for g in rep[: self.n_union]] if self._flat is not None else rep[: self.n_union].copy()
         return terms, src[: self.k * self.n_union].reshape(self.k, self.n_union)
 
     def free(self) -> None:
