@@ -57,6 +57,18 @@ template <class T> static T *ws_take(ii2_ctx *ctx, size_t count) {
     return p;
 }
 
+void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes) {
+    if (bytes <= ctx->pool_cap[slot] && ctx->pool[slot]) return ctx->pool[slot];
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->pool[slot]) (void)hipFree(ctx->pool[slot]);
+    ctx->pool[slot] = nullptr;
+    ctx->pool_cap[slot] = 0;
+    const size_t want = align_up(bytes + bytes / 8 + 256, 1 << 16);
+    if (hipMalloc((void **)&ctx->pool[slot], want) != hipSuccess) return nullptr;
+    ctx->pool_cap[slot] = want;
+    return ctx->pool[slot];
+}
+
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1) {
     if (ctx->opt_profile_events <= 0) return false;
     if (ctx->prof_calls++ % (uint64_t)ctx->opt_profile_events != 0) return false;   // a timed event pair costs ~10 us of stream idle time
@@ -150,6 +162,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->aux2) (void)hipFree(ctx->aux2);
+    for (uint8_t *q : ctx->pool) if (q) (void)hipFree(q);
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
@@ -252,31 +265,34 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     if (nb_bound >= (1ull << 31)) return fail(ctx, II2_ERANGE, "too many DV1 blocks for one segment");
     if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
-    DevBuf nblk, scan_tmp;
+    // scratch comes out of the context's grow-only workspace (sized by the upper bound of the block count)
     const size_t tmpb = scan_temp_bytes((size_t)std::max<uint64_t>(n_lists + 1, nb_bound + 1));
-    if (nblk.alloc((n_lists + 1) * sizeof(uint32_t)) != hipSuccess || scan_tmp.alloc(tmpb) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "encode scratch allocation failed");
-    HIP_TRY(ctx, launch_enc_list_blocks(d_post_off, n_lists, nblk.as<uint32_t>(), st));
-    HIP_TRY(ctx, scan_excl_u32(scan_tmp.p, tmpb, nblk.as<uint32_t>(), seg->d_blk_off, n_lists + 1, st));
+    if (int rcw = ii2_ws_reserve(ctx, align_up((n_lists + 1) * sizeof(uint32_t)) + align_up(tmpb) + align_up((nb_bound + 1) * sizeof(uint32_t)) +
+                                          align_up((nb_bound + 1) * sizeof(uint64_t)) + 4096))
+        return rcw;
+    uint32_t *d_nblk = ws_take<uint32_t>(ctx, n_lists + 1);
+    void *d_scan_tmp = ws_take<uint8_t>(ctx, tmpb);
+    uint32_t *d_sizes = ws_take<uint32_t>(ctx, nb_bound + 1);
+    uint64_t *d_boff = ws_take<uint64_t>(ctx, nb_bound + 1);
+    HIP_TRY(ctx, launch_enc_list_blocks(d_post_off, n_lists, d_nblk, st));
+    HIP_TRY(ctx, scan_excl_u32(d_scan_tmp, tmpb, d_nblk, seg->d_blk_off, n_lists + 1, st));
     uint32_t nb32 = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&nb32, seg->d_blk_off + n_lists, sizeof nb32, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint64_t nb = nb32;
     seg->n_blocks = nb;
-    DevBuf sizes, boff;
-    if (sizes.alloc((nb + 1) * sizeof(uint32_t)) != hipSuccess || boff.alloc((nb + 1) * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&seg->d_skip, (nb + 1) * sizeof(ii2_skip)) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "encode scratch allocation failed");
-    HIP_TRY(ctx, launch_enc_block_sizes(d_post_off, seg->d_blk_off, n_lists, d_values, nb, sizes.as<uint32_t>(), seg->d_skip, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(scan_tmp.p, tmpb, sizes.as<uint32_t>(), boff.as<uint64_t>(), nb + 1, st));
+    if (hipMalloc((void **)&seg->d_skip, (nb + 1) * sizeof(ii2_skip)) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    HIP_TRY(ctx, launch_enc_block_sizes(d_post_off, seg->d_blk_off, n_lists, d_values, nb, d_sizes, seg->d_skip, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_tmp, tmpb, d_sizes, d_boff, nb + 1, st));
     uint64_t nbytes = 0;
-    HIP_TRY(ctx, hipMemcpyAsync(&nbytes, boff.as<uint64_t>() + nb, sizeof nbytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&nbytes, d_boff + nb, sizeof nbytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (nbytes >= 0xFFFFFFF0ull) return fail(ctx, II2_ERANGE, "segment payload exceeds the 4 GiB DV1 limit; split the segment");
     seg->n_bytes = nbytes;
     if (hipMalloc((void **)&seg->d_payload, nbytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + nbytes, 0, 16, st));
-    HIP_TRY(ctx, launch_enc_write(d_post_off, seg->d_blk_off, n_lists, d_values, nb, boff.as<uint64_t>(), seg->d_skip,
+    HIP_TRY(ctx, launch_enc_write(d_post_off, seg->d_blk_off, n_lists, d_values, nb, d_boff, seg->d_skip,
                                   seg->d_payload, n_postings, st));
     int rc = seg_finish(ctx, seg.get());
     if (rc) return rc;
@@ -288,15 +304,15 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
 int ii2_seg_decode_dev_unlocked(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *d_post_off, uint32_t *d_values) {
     hipStream_t st = ctx->stream;
     const uint64_t nb = seg->n_blocks;
-    DevBuf counts, bpo, scan_tmp;
     const size_t tmpb = scan_temp_bytes((size_t)nb + 1);
-    if (counts.alloc((nb + 1) * sizeof(uint32_t)) != hipSuccess || bpo.alloc((nb + 1) * sizeof(uint64_t)) != hipSuccess ||
-        scan_tmp.alloc(tmpb) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "decode scratch allocation failed");
-    HIP_TRY(ctx, launch_dec_block_counts(seg->d_skip, seg->d_payload, nb, counts.as<uint32_t>(), st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(scan_tmp.p, tmpb, counts.as<uint32_t>(), bpo.as<uint64_t>(), nb + 1, st));
-    if (d_values) HIP_TRY(ctx, launch_dec_write(seg->d_skip, seg->d_payload, nb, bpo.as<uint64_t>(), d_values, st));
-    if (d_post_off) HIP_TRY(ctx, launch_gather_post_off(seg->d_blk_off, bpo.as<uint64_t>(), seg->n_lists, d_post_off, st));
+    if (int rcw = ii2_ws_reserve(ctx, align_up((nb + 1) * sizeof(uint32_t)) + align_up((nb + 1) * sizeof(uint64_t)) + align_up(tmpb) + 4096)) return rcw;
+    uint32_t *d_counts = ws_take<uint32_t>(ctx, nb + 1);
+    uint64_t *d_bpo = ws_take<uint64_t>(ctx, nb + 1);
+    void *d_scan_tmp = ws_take<uint8_t>(ctx, tmpb);
+    HIP_TRY(ctx, launch_dec_block_counts(seg->d_skip, seg->d_payload, nb, d_counts, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_tmp, tmpb, d_counts, d_bpo, nb + 1, st));
+    if (d_values) HIP_TRY(ctx, launch_dec_write(seg->d_skip, seg->d_payload, nb, d_bpo, d_values, st));
+    if (d_post_off) HIP_TRY(ctx, launch_gather_post_off(seg->d_blk_off, d_bpo, seg->n_lists, d_post_off, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return II2_OK;
 }
@@ -318,12 +334,12 @@ int ii2_seg_encode(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *post_off, con
     for (uint64_t l = 0; l < n_lists; l++)
         if (post_off[l + 1] < post_off[l]) return fail(ctx, II2_EINVAL, "ii2_seg_encode: post_off must be non-decreasing");
     if (n && !values) return fail(ctx, II2_EINVAL, "ii2_seg_encode: values is NULL");
-    DevBuf dpo, dv;
-    if (dpo.alloc((n_lists + 1) * sizeof(uint64_t)) != hipSuccess || dv.alloc(n * sizeof(uint32_t)) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "encode staging allocation failed");
-    HIP_TRY(ctx, hipMemcpyAsync(dpo.p, post_off, (n_lists + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    if (n) HIP_TRY(ctx, hipMemcpyAsync(dv.p, values, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    return ii2_seg_encode_dev_unlocked(ctx, n_lists, dpo.as<uint64_t>(), dv.as<uint32_t>(), n, out);
+    uint64_t *dpo = (uint64_t *)ii2_pool_get(ctx, 0, (n_lists + 1) * sizeof(uint64_t));
+    uint32_t *dv = (uint32_t *)ii2_pool_get(ctx, 1, n * sizeof(uint32_t));
+    if (!dpo || !dv) return fail(ctx, II2_ENOMEM, "encode staging allocation failed");
+    HIP_TRY(ctx, hipMemcpyAsync(dpo, post_off, (n_lists + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(dv, values, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    return ii2_seg_encode_dev_unlocked(ctx, n_lists, dpo, dv, n, out);
 }
 
 int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const uint32_t *blk_off, const ii2_skip *skip,
@@ -402,14 +418,14 @@ int ii2_seg_decode(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *post_off, uint32_
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (where == II2_DEVICE) return ii2_seg_decode_dev_unlocked(ctx, seg, post_off, values);
-    DevBuf dpo, dv;
-    if (dpo.alloc((seg->n_lists + 1) * sizeof(uint64_t)) != hipSuccess || dv.alloc(seg->n_postings * sizeof(uint32_t)) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "decode staging allocation failed");
-    int rc = ii2_seg_decode_dev_unlocked(ctx, seg, dpo.as<uint64_t>(), dv.as<uint32_t>());
+    uint64_t *dpo = (uint64_t *)ii2_pool_get(ctx, 0, (seg->n_lists + 1) * sizeof(uint64_t));
+    uint32_t *dv = (uint32_t *)ii2_pool_get(ctx, 1, seg->n_postings * sizeof(uint32_t));
+    if (!dpo || !dv) return fail(ctx, II2_ENOMEM, "decode staging allocation failed");
+    int rc = ii2_seg_decode_dev_unlocked(ctx, seg, dpo, values ? dv : nullptr);
     if (rc) return rc;
-    if (post_off) HIP_TRY(ctx, hipMemcpyAsync(post_off, dpo.p, (seg->n_lists + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (post_off) HIP_TRY(ctx, hipMemcpyAsync(post_off, dpo, (seg->n_lists + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     if (values && seg->n_postings)
-        HIP_TRY(ctx, hipMemcpyAsync(values, dv.p, seg->n_postings * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(values, dv, seg->n_postings * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return II2_OK;
 }
@@ -533,12 +549,12 @@ int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *out = nullptr;
-    DevBuf staged;
     const uint32_t *d_rem = removed;
     if (where == II2_HOST && n) {
-        if (staged.alloc(n * sizeof(uint32_t)) != hipSuccess) return fail(ctx, II2_ENOMEM, "tombstone staging allocation failed");
-        HIP_TRY(ctx, hipMemcpyAsync(staged.p, removed, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-        d_rem = staged.as<uint32_t>();
+        uint32_t *staged = (uint32_t *)ii2_pool_get(ctx, 1, n * sizeof(uint32_t));
+        if (!staged) return fail(ctx, II2_ENOMEM, "tombstone staging allocation failed");
+        HIP_TRY(ctx, hipMemcpyAsync(staged, removed, n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        d_rem = staged;
     }
     uint32_t mx = 0;
     if (n) {

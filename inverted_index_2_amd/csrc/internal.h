@@ -35,6 +35,9 @@ struct ii2_ctx {
     size_t aux_cap = 0;
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
     size_t aux2_cap = 0;
+    // grow-only staging buffers of the encode / decode / merge-to-segment paths (no hipMalloc per call)
+    uint8_t *pool[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pool_cap[4] = {0, 0, 0, 0};
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
@@ -89,6 +92,7 @@ struct ii2_tomb {
 };
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
+void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes);      // grow-only ctx buffer `slot`, at least `bytes` (nullptr: out of memory); ctx->mu held
 int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg);   // fills seg->h_blk_off on first use (thread-safe)
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);   // false when profiling is off
 // union through the intersection tiles (OR); *taken = false when the lists are too sparse for it (caller merges instead)

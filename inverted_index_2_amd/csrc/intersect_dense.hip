@@ -260,15 +260,14 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             }
             const bool rowhard = ((hm >> (4u * row)) & 0xFull) != 0ull;
             const bool live = rv && !rowhard;
-            // prefix of the gap sums over my sixteen groups of four postings: pre[k] = docs from the posting before my bytes to group k's last posting
-            uint32_t pre[16];
+            // sum of my 64 gaps, and whether any of my sixteen groups of four postings spans 32 docs or more (the per-group
+            // sums are recomputed in the loops below: one v_sad_u8 each, cheaper than sixteen live registers)
             uint32_t acc = 0, wide = 0;
 #pragma unroll
             for (uint32_t k = 0; k < 16u; k++) {
-                const uint32_t nx = __builtin_amdgcn_sad_u8(ww[k], 0u, acc);
-                wide |= nx - acc;                                               // a group sum >= 32 sets a bit above bit 4
-                acc = nx;
-                pre[k] = nx;
+                const uint32_t gs = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u);
+                wide |= gs;                                                      // a group sum >= 32 sets a bit above bit 4
+                acc += gs;
             }
             // exclusive scan of the lane sums inside the row's four lanes (quad permutes)
             const uint32_t s = live ? acc : 0u;
@@ -294,11 +293,12 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             if (act) {
                 // a group's mask starts AT the posting before it (bit 0 = position q: the block's first doc for the row's
                 // first lane, else a posting an earlier group already set — setting it again is harmless)
-                uint32_t q = u, prev = 0u;
+                uint32_t q = u;
 #pragma unroll
                 for (uint32_t k = 0; k < 16u; k++) {
                     const uint32_t x = ww[k];
-                    const bool isw = exactlane || pre[k] - prev >= 32u;          // the four gaps do not fit one 32-bit mask: placed by the loop below
+                    const uint32_t gs = __builtin_amdgcn_sad_u8(x, 0u, 0u);
+                    const bool isw = exactlane || gs >= 32u;                     // the four gaps do not fit one 32-bit mask: placed by the loop below
                     uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;
                     M = (M << ((x >> 16) & 31u)) | 1u;
                     M = (M << ((x >> 8) & 31u)) | 1u;
@@ -309,8 +309,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                     uint32_t *dst = lds_word(qc);
                     atomicOr(dst, M << sh);
                     atomicOr(dst + 1, (M >> 1) >> (31u - sh));                   // the part that spills into the next word (0 for most)
-                    prev = pre[k];
-                    q = u + prev;
+                    q += gs;
                 }
             }
             // groups of four postings wider than 31 docs (a few per thousand in lists this dense) and every group of a lane that
@@ -319,7 +318,8 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                 uint32_t prev = 0u;
 #pragma unroll
                 for (uint32_t k = 0; k < 16u; k++) {
-                    const bool isw = act && haswide && (exactlane || pre[k] - prev >= 32u);
+                    const uint32_t gs = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u);
+                    const bool isw = act && haswide && (exactlane || gs >= 32u);
                     if (__ballot(isw) != 0ull) {
                         if (isw) {
                             const uint32_t x = ww[k];
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                             }
                         }
                     }
-                    prev = pre[k];
+                    prev += gs;
                 }
             }
         };

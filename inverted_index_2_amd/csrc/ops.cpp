@@ -259,15 +259,16 @@ int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *se
     uint64_t n_in = 0;
     for (uint32_t s = 0; s < k; s++) n_in += segs[s]->n_postings;
     const uint64_t T = segs[0]->n_lists;
-    DevBuf off, vals;
-    if (off.alloc((T + 1) * sizeof(uint64_t)) != hipSuccess || vals.alloc(n_in * sizeof(uint32_t)) != hipSuccess)
-        return fail(ctx, II2_ENOMEM, "merge output allocation failed");
+    // the merged CSR waits for the encoder in the context's grow-only staging buffers (no hipMalloc per Shard.Merge)
+    uint64_t *off = (uint64_t *)ii2_pool_get(ctx, 2, (T + 1) * sizeof(uint64_t));
+    uint32_t *vals = (uint32_t *)ii2_pool_get(ctx, 3, (n_in + 1) * sizeof(uint32_t));
+    if (!off || !vals) return fail(ctx, II2_ENOMEM, "merge output allocation failed");
     ii2_merge_stats local;
-    rc = merge_unlocked(ctx, k, segs, tomb, off.as<uint64_t>(), vals.as<uint32_t>(), n_in, &local);
+    rc = merge_unlocked(ctx, k, segs, tomb, off, vals, n_in, &local);
     if (rc) return rc;
     if (stats) *stats = local;
     if (local.n_terms_out == 0) return II2_OK;      // shard.go:219-225: nothing survives, no segment is written
-    return ii2_seg_encode_dev_unlocked(ctx, T, off.as<uint64_t>(), vals.as<uint32_t>(), local.n_out, out);
+    return ii2_seg_encode_dev_unlocked(ctx, T, off, vals, local.n_out, out);
 }
 
 int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx, const ii2_tomb *tomb,
@@ -329,17 +330,17 @@ int ii2_merge_host(ii2_ctx *ctx, uint32_t k, uint64_t n_terms, const uint64_t *s
     if (!rc && !out_values && n_in) rc = fail(ctx, II2_EINVAL, "ii2_merge_host: out_values is NULL");
     if (!rc) {
         std::lock_guard<std::mutex> g(ctx->mu);
-        DevBuf off, vals;
         ii2_merge_stats local;
         std::memset(&local, 0, sizeof local);
-        if (off.alloc((n_terms + 1) * sizeof(uint64_t)) != hipSuccess || vals.alloc(n_in * sizeof(uint32_t)) != hipSuccess)
-            rc = fail(ctx, II2_ENOMEM, "merge output allocation failed");
-        if (!rc) rc = merge_unlocked(ctx, k, segs.data(), tomb, off.as<uint64_t>(), vals.as<uint32_t>(), n_in, &local);
+        uint64_t *off = (uint64_t *)ii2_pool_get(ctx, 2, (n_terms + 1) * sizeof(uint64_t));
+        uint32_t *vals = (uint32_t *)ii2_pool_get(ctx, 3, (n_in + 1) * sizeof(uint32_t));
+        if (!off || !vals) rc = fail(ctx, II2_ENOMEM, "merge output allocation failed");
+        if (!rc) rc = merge_unlocked(ctx, k, segs.data(), tomb, off, vals, n_in, &local);
         if (!rc && local.n_out > out_cap) rc = fail(ctx, II2_ECAPACITY, "ii2_merge_host: out_values too small; nothing was written");
         if (!rc) {
-            hipError_t e = hipMemcpyAsync(out_off, off.p, (n_terms + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+            hipError_t e = hipMemcpyAsync(out_off, off, (n_terms + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess && local.n_out)
-                e = hipMemcpyAsync(out_values, vals.p, local.n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+                e = hipMemcpyAsync(out_values, vals, local.n_out * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
             if (e != hipSuccess) { ctx->err = std::string("merge download: ") + hipGetErrorString(e); rc = II2_EHIP; }
             if (stats) *stats = local;
