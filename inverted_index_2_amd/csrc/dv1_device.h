@@ -260,9 +260,10 @@ __device__ __forceinline__ bool decode_rows16(Load16 load16, uint32_t q0, uint32
 // every lane emits the postings that end inside its bytes: emit(idx_in_block, doc_id), posting 0
 // by the row's lane 0.  All 64 lanes must call; rows without a block pass row_valid = false.
 // Reads up to 16 bytes past q1 (segments carry that padding).
+// Returns the number of postings of the lane's row (1 for an invalid row's lanes is meaningless: check row_valid).
 template <class Emit>
-__device__ __forceinline__ void decode_rows16_any(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1, uint32_t first_doc,
-                                                  bool row_valid, Emit emit) {
+__device__ __forceinline__ uint32_t decode_rows16_any(const uint8_t *__restrict__ payload, uint32_t q0, uint32_t q1, uint32_t first_doc,
+                                                      bool row_valid, Emit emit) {
     const uint32_t rl = (uint32_t)lane_id() & 15u;
     const int row_last = lane_id() | 15;
     const uint32_t len = row_valid ? q1 - q0 : 0u;
@@ -308,6 +309,7 @@ __device__ __forceinline__ void decode_rows16_any(const uint8_t *__restrict__ pa
         run_id += (uint32_t)__shfl((int)isum, row_last, 64);
         run_ix += (uint32_t)__shfl((int)icnt, row_last, 64);
     }
+    return run_ix;
 }
 
 // Posting count of a block without decoding ids (1 + terminators).  Wave-uniform result.

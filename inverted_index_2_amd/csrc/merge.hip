@@ -141,8 +141,14 @@ __global__ __launch_bounds__(256) void k_mdec_lane(MergeSegs p, const unsigned l
 
 __global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__restrict__ raw, const uint4 *__restrict__ ent0,
                                                     const uint2 *__restrict__ ent1, const uint32_t *__restrict__ nbig) {
+    // a row's postings are collected in LDS and leave as 16-byte stores: a block is contiguous in raw, but the lanes of its
+    // row hold 16 payload bytes each — a varying number of postings — so storing from the decoder would be one partly
+    // filled 4-byte store instruction per posting of the fullest lane
+    __shared__ __align__(16) uint32_t stage[4][4][II2_DV1_BLOCK];
     const uint32_t n = *nbig;
     const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 4;
+    const uint32_t wv = threadIdx.x >> 6, row = ((uint32_t)threadIdx.x >> 4) & 3u, rl = (uint32_t)threadIdx.x & 15u;
+    uint32_t *st = stage[wv][row];
     for (uint64_t z = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; __ballot(z < n) != 0ull; z += stride) {
         const bool rv = z < n;
         uint32_t q0 = 0, q1 = 0, first = 0;
@@ -157,7 +163,18 @@ __global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__rest
             out = raw + ((unsigned long long)e0.x | ((unsigned long long)e0.y << 32));
             pl = p.segs[e1.y].payload;
         }
-        decode_rows16_any(pl, q0, q1, first, rv, [&](uint32_t ix, uint32_t id) { out[ix] = id; });
+        const uint32_t cnt = decode_rows16_any(pl, q0, q1, first, rv, [&](uint32_t ix, uint32_t id) { st[ix & (II2_DV1_BLOCK - 1u)] = id; });
+        if (rv) {
+            const uint32_t c = cnt < II2_DV1_BLOCK ? cnt : II2_DV1_BLOCK;       // (imported segments are validated: a block holds <= 256)
+            for (uint32_t i = 4u * rl; i < c; i += 64u) {
+                if (i + 4u <= c) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(&st[i]);
+                    __builtin_memcpy(out + i, &v, 16);
+                } else {
+                    for (uint32_t j = i; j < c; j++) out[j] = st[j];
+                }
+            }
+        }
     }
 }
 
@@ -256,6 +273,36 @@ __global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ nt
 // ends[tile * k + s] = postings of list (s, t0) with doc <= the tile's upper bound (large-term tiles only).
 // Two levels: the block is found in the segment's skip table (8 bytes per 256 postings, cache-resident), only the last
 // eight steps touch the decoded list itself — the searches over the raw arrays used to fetch 0.8 GB per merge.
+// first index i in [lo, hi) with get(i) > x, for an ascending sequence that is close to uniform between vlo (a lower bound of
+// get(lo)) and vhi (an upper bound of get(hi - 1)): a linear guess, a doubling walk away from it until x is bracketed, then
+// bisection inside the bracket — a handful of dependent loads instead of log2(hi - lo).  Exact for any ascending input.
+template <class Get>
+__device__ __forceinline__ uint32_t upper_bound_guess(Get get, uint32_t lo, uint32_t hi, uint32_t x, uint32_t vlo, uint32_t vhi) {
+    if (lo >= hi) return lo;
+    if (hi - lo > 4u && vhi > vlo) {
+        const uint64_t rel = x > vlo ? (uint64_t)(x - vlo) : 0ull;
+        uint64_t g64 = (uint64_t)lo + rel * (uint64_t)(hi - lo) / ((uint64_t)(vhi - vlo) + 1ull);
+        uint32_t g = g64 >= hi ? hi - 1u : (uint32_t)g64;
+        if (get(g) <= x) {                                  // answer in (g, hi]: walk up
+            uint32_t a = g + 1u, step = 1u;
+            while (a < hi) {
+                const uint32_t pr = a + step - 1u < hi ? a + step - 1u : hi - 1u;
+                if (get(pr) <= x) { a = pr + 1u; step <<= 1; } else { hi = pr; break; }
+            }
+            lo = a;                                         // get(i) <= x for i < lo; get(hi) > x or hi is the end
+        } else {                                            // answer in [lo, g]: walk down
+            uint32_t b = g, step = 1u;
+            while (b > lo) {
+                const uint32_t pr = b - lo > step ? b - step : lo;
+                if (get(pr) > x) { b = pr; step <<= 1; } else { lo = pr + 1u; break; }
+            }
+            hi = b;
+        }
+    }
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (get(mid) <= x) lo = mid + 1u; else hi = mid; }
+    return lo;
+}
+
 __global__ void k_merge_tile_ends(MergeParams p, MergeSegs ms, const uint4 *__restrict__ desc, uint32_t *__restrict__ ends) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)*p.n_tiles_dev * p.k) return;
@@ -267,15 +314,19 @@ __global__ void k_merge_tile_ends(MergeParams p, MergeSegs ms, const uint4 *__re
     const uint32_t len = (uint32_t)(end - beg);
     const SegView sv = ms.segs[s];
     const uint32_t b_lo = sv.blk_off[td.x], b_hi = sv.blk_off[td.x + 1u];
-    uint32_t a = b_lo, b = b_hi;                              // first block of the list whose first doc is > td.w
-    while (a < b) { const uint32_t mid = a + ((b - a) >> 1); if (sv.skip[mid].first_doc <= td.w) a = mid + 1u; else b = mid; }
     uint32_t res = 0;
-    if (a > b_lo) {                                           // block a - 1 starts at or before td.w: the boundary lies inside it (or at its end)
-        const uint32_t base = (a - 1u - b_lo) * II2_DV1_BLOCK;
-        const uint32_t *lst = p.raw + beg + base;
-        uint32_t lo = 0, hi = len - base < II2_DV1_BLOCK ? len - base : II2_DV1_BLOCK;
-        while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= td.w) lo = mid + 1u; else hi = mid; }
-        res = base + lo;
+    if (b_hi > b_lo) {
+        const uint32_t f0 = sv.skip[b_lo].first_doc, fl = sv.skip[b_hi - 1u].first_doc;
+        // first block of the list whose first doc is > td.w (the doc ids of a large term's list are close to uniform)
+        const uint32_t a = upper_bound_guess([&](uint32_t j) { return sv.skip[j].first_doc; }, b_lo, b_hi, td.w, f0, fl);
+        if (a > b_lo) {                                       // block a - 1 starts at or before td.w: the boundary lies inside it (or at its end)
+            const uint32_t base = (a - 1u - b_lo) * II2_DV1_BLOCK;
+            const uint32_t *lst = p.raw + beg + base;
+            const uint32_t cntb = len - base < II2_DV1_BLOCK ? len - base : II2_DV1_BLOCK;
+            const uint32_t fb = sv.skip[a - 1u].first_doc;
+            const uint32_t fn = a < b_hi ? sv.skip[a].first_doc : (cntb ? lst[cntb - 1u] : fb);
+            res = base + upper_bound_guess([&](uint32_t j) { return lst[j]; }, 0u, cntb, td.w, fb, fn);
+        }
     }
     ends[i] = res;
 }
