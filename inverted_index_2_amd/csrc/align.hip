@@ -180,7 +180,7 @@ int ii2_align_terms(ii2_ctx *ctx, uint32_t k, const uint8_t *term_bytes, const u
     if (n == 0) { *out = a.release(); return II2_OK; }
 
     size_t sort_b = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                        (int)n, 0, 64, (hipStream_t)0);
     const size_t scan_b = scan_temp_bytes((size_t)n + 1);
     const size_t tmp_b = align_up(std::max(sort_b, scan_b));

@@ -791,16 +791,75 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
     std::memset(&p, 0, sizeof p);
     uint32_t m = 0;
     uint64_t total_blocks = 0;
+    const ii2_seg *nz_seg[MAX_LISTS];
+    uint64_t nz_idx[MAX_LISTS];
     for (uint32_t i = 0; i < n; i++) {
         ListView v;
         int rc = make_list_view(ctx, segs[i], list_idx ? list_idx[i] : 0, &v);
         if (rc) return rc;
         if (v.nblk == 0) continue;
+        nz_seg[m] = segs[i];
+        nz_idx[m] = list_idx ? list_idx[i] : 0;
         p.lists[m++] = v;
         total_blocks += v.nblk;
     }
     if (m == 0 || total_blocks < 64) return II2_OK;
     p.n_lists = m;
+    // Few long lists, the longest one dense: the streaming kernel of the dense intersection with OR semantics — every
+    // wave walks its own run of blocks of the longest list (the pacer), the other lists mark into the same bitmap
+    // (intersect_dense.hip).  The lists' ends are cached per (segment, list): no host sync after the first use.
+    if (ctx->opt_union_stream && m >= 2 && m <= DENSE_MAXL) {
+        uint32_t pace = 0;
+        for (uint32_t i = 1; i < m; i++) if (p.lists[i].nblk > p.lists[pace].nblk) pace = i;
+        if (p.lists[pace].nblk >= 1024) {
+            DenseParams dp;
+            std::memset(&dp, 0, sizeof dp);
+            uint32_t u_lo = 0xFFFFFFFFu, u_hi = 0;
+            ii2_seg::ListSpan psp{};
+            for (uint32_t i = 0, o = 1; i < m; i++) {
+                ii2_seg::ListSpan sp;
+                if (int rc = list_span(ctx, nz_seg[i], nz_idx[i], p.lists[i], &sp)) return rc;
+                const uint32_t at = i == pace ? 0u : o++;
+                dp.lists[at] = p.lists[i];
+                dp.first_doc[at] = sp.first_doc;
+                dp.last_doc[at] = sp.last_doc;
+                if (i == pace) psp = sp;
+                u_lo = std::min(u_lo, sp.first_doc);
+                u_hi = std::max(u_hi, sp.last_doc);
+            }
+            const uint32_t nblk0 = dp.lists[0].nblk;
+            const double per_block = (double)(psp.last_block_first_doc - psp.first_doc) / (double)(nblk0 - 1);
+            // the stretches before the pacer's first and after its last doc are one wave's work each: keep them short
+            const uint64_t own = (uint64_t)psp.last_doc - psp.first_doc + 1, all = (uint64_t)u_hi - u_lo + 1;
+            if (per_block > 0 && per_block <= 1100.0 && all <= own + own / 4 + 65536) {
+                dp.n_lists = m;
+                dp.is_union = 1u;
+                dp.u_lo = u_lo;
+                dp.u_hi = u_hi;
+                dp.bpw = 16u;
+                dp.n_waves = (nblk0 + dp.bpw - 1) / dp.bpw;
+                const uint32_t grid = (dp.n_waves + 3u) / 4u;
+                dp.n_meta = grid * 4u;
+                dp.base32 = u_lo & ~31u;
+                const uint64_t bm_words = (((uint64_t)u_hi - dp.base32) >> 5) + 1 + dp.n_meta + 8;
+                size_t need = align_up(bm_words * sizeof(uint32_t)) + align_up((size_t)dp.n_meta * sizeof(uint4)) + align_up((size_t)grid * sizeof(uint32_t)) + 4096;
+                if (int rc = ii2_ws_reserve(ctx, need)) return rc;
+                dp.bitmap = ws_take<uint32_t>(ctx, bm_words);
+                dp.meta = ws_take<uint4>(ctx, dp.n_meta);
+                dp.wg_sum = ws_take<uint32_t>(ctx, grid);
+                dp.tomb = tomb ? tomb->d_words : nullptr;
+                dp.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+                dp.out = d_out;
+                dp.out_cap = cap;
+                dp.d_count = d_count;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                ii2_profile_pair(ctx, &e0, &e1);
+                HIP_TRY(ctx, launch_intersect_dense(dp, st, e0, e1));
+                *taken = true;
+                return II2_OK;
+            }
+        }
+    }
     uint32_t *d_mm = (uint32_t *)(ctx->d_mail + 80);
     uint32_t mm[2] = {0, 0};
     HIP_TRY(ctx, launch_union_range(p, d_mm, st));
@@ -912,6 +971,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
     else if (k == "union.dense") ctx->opt_union_dense = value;
+    else if (k == "union.stream") ctx->opt_union_stream = value;
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;

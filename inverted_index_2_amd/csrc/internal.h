@@ -40,6 +40,7 @@ struct ii2_ctx {
     size_t pool_cap[4] = {0, 0, 0, 0};
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
+    int64_t opt_union_stream = 1;       // ... and, for 2-4 lists paced by a long dense one, through the streaming kernel
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_intersect_dense = 1;    // dense 2..4-list queries go to the wave-streaming kernels (intersect_dense.hip)
@@ -160,6 +161,8 @@ struct DenseParams {
     ListView lists[DENSE_MAXL];  // lists[0] is the driver (fewest blocks)
     uint32_t first_doc[DENSE_MAXL], last_doc[DENSE_MAXL];   // of every list (host copies: starting guess of the block search)
     uint32_t n_lists;
+    uint32_t is_union;           // 1: OR of the lists (lists[0] = the list with the most blocks paces the rounds)
+    uint32_t u_lo, u_hi;         // union: smallest first doc / largest last doc over all lists
     uint32_t bpw;                // driver blocks per wave (a multiple of 16)
     uint32_t n_waves;            // waves with work; the grid is ceil(n_waves / 4) workgroups
     uint32_t n_meta;             // entries of meta (4 per workgroup)

@@ -61,6 +61,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin
 struct Pass {
     const uint8_t *payload;      // wave-uniform
     uint32_t wlo, wspan;         // the window the pass marks into (wave-uniform)
+    uint32_t lowbits;            // union: bits of the window's first word that belong to the round before (wave-uniform)
     uint32_t flags;              // PF_* (wave-uniform)
     uint32_t nvalid;             // rows with a block (wave-uniform)
     bool rv;                     // per lane: my row has a block
@@ -69,7 +70,11 @@ struct Pass {
 enum : uint32_t { PF_VALID = 1u, PF_FIRST = 2u, PF_LAST = 4u, PF_TOB = 8u, PF_FOLD = 16u };
 // first / last pass of a window, marks into B, fold B into A first
 
-template <uint32_t NL>
+// UNION: every list marks into the one bitmap A and the window's result is A itself (OR instead of AND).  The rounds
+// are still paced by list 0 (the host passes the list with the most blocks); the first round of wave 0 starts at the
+// smallest first doc of all lists and the last round ends at the largest last doc, so postings outside the pacing
+// list's own doc range are covered too (long stretches split into windows like any other round).
+template <uint32_t NL, bool UNION>
 __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
     __shared__ __align__(16) uint32_t lds[4][DN_WAVE_LDS];
     __shared__ uint32_t wcnt[4];
@@ -105,8 +110,9 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
         };
         uint4 E = ent_load(0u, b0);                          // entries the next gen() call consumes
         const uint32_t drv_last = uni(*drv.last_doc);
-        const uint32_t lo_w = uni(E.x);                      // (row 0 = block b0)
-        const uint32_t hi_w = b1 < drv.nblk ? uni(drv.skip[b1].first_doc) - 1u : drv_last;
+        const uint32_t end_doc = UNION ? p.u_hi : drv_last;
+        const uint32_t lo_w = (UNION && w == 0u) ? p.u_lo : uni(E.x);          // (row 0 = block b0)
+        const uint32_t hi_w = b1 < drv.nblk ? uni(drv.skip[b1].first_doc) - 1u : end_doc;
         mlo_w = lo_w & ~31u;
         nwords_w = ((hi_w - mlo_w) >> 5) + 1u;
         uint32_t *slot = p.bitmap + (size_t)((mlo_w - p.base32) >> 5) + w;      // slots of neighbouring waves never overlap (+ w)
@@ -139,6 +145,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
         // ---- the pass generator ----
         uint32_t gb = b0;                     // driver block of the round being generated
         uint32_t g_hi = 0, g_wlo = 0;         // its last doc; the window being generated
+        uint32_t g_low = 0;                   // union: the round's first doc - g_wlo while the window is the round's first
         uint32_t g_stage = 0;                 // 0: driver pass next; j >= 1: passes of list j
         uint32_t g_cur = 0;                   // next block of list g_stage
         bool g_new = true;                    // E holds the driver entries of a round whose range is not set up yet
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
         auto gen = [&]() -> Pass {
             Pass P;
             P.payload = drv.payload; P.flags = 0u; P.nvalid = 0u; P.rv = false; P.f = E.x; P.q0 = E.y; P.q1 = E.w;
-            P.wlo = 0u; P.wspan = 0u;
+            P.wlo = 0u; P.wspan = 0u; P.lowbits = 0u;
             if (g_done) return P;
             const uint32_t j = g_stage;
             uint32_t nvalid;
@@ -155,20 +162,23 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                 nvalid = b1 - gb < DN_ROWS ? b1 - gb : DN_ROWS;
                 if (g_new) {      // the round's doc range: first doc of its first block ... one before the first doc of the block after its last
                     const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)E.z, (int)(4u * (nvalid - 1u)));
-                    g_hi = gb + nvalid < drv.nblk ? nf - 1u : drv_last;
-                    g_wlo = uni(E.x) & ~31u;
+                    g_hi = gb + nvalid < drv.nblk ? nf - 1u : end_doc;
+                    const uint32_t lo = (UNION && gb == 0u) ? p.u_lo : uni(E.x);
+                    g_wlo = lo & ~31u;
+                    g_low = lo & 31u;
                     g_new = false;
                 }
                 P.flags = PF_VALID | PF_FIRST;
             }
             P.wlo = g_wlo;
+            if (UNION) P.lowbits = g_low;
             P.wspan = g_hi - g_wlo < DN_CAPW ? g_hi - g_wlo : DN_CAPW - 1u;
             if (j != 0u) {
                 const uint32_t whi = g_wlo + P.wspan;
                 P.payload = p.lists[j].payload;
                 const bool rvj = g_cur + row < p.lists[j].nblk && E.x <= whi;   // first docs ascend: the valid rows are a prefix
                 nvalid = (uint32_t)__popcll(__ballot(rvj)) >> 2;
-                P.flags = PF_VALID | PF_TOB | ((g_first && j > 1u) ? PF_FOLD : 0u);
+                P.flags = UNION ? PF_VALID : (PF_VALID | PF_TOB | ((g_first && j > 1u) ? PF_FOLD : 0u));
                 g_first = false;
             }
             P.nvalid = nvalid;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                     gb += DN_ROWS;
                     g_new = true;
                     if (gb >= b1) g_done = true;
-                } else g_wlo += DN_CAPW;
+                } else { g_wlo += DN_CAPW; g_low = 0u; }
                 ncur = gb;
             }
             g_stage = nj;
@@ -337,19 +347,22 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             }
         };
 
-        auto finalise = [&](uint32_t wlo, uint32_t wspan) {
+        auto finalise = [&](uint32_t wlo, uint32_t wspan, uint32_t lowbits) {
             // AND, tombstones, count, store to the wave's slot (wave-private LDS: program order is enough); two words per lane
             const uint32_t nw = (wspan >> 5) + 1u;
             const uint32_t sbase = (wlo - mlo_w) >> 5;
             for (uint32_t i = 2u * (uint32_t)l; i < nw; i += 128u) {
                 const uint2 ra = *reinterpret_cast<const uint2 *>(&bmA[DN_GU / 32u + i]);
                 uint32_t r0 = ra.x, r1 = ra.y;
-                if (NL > 1u) {
+                if (NL > 1u && !UNION) {
                     const uint2 rb = *reinterpret_cast<const uint2 *>(&bmB[DN_GU / 32u + i]);
                     r0 &= rb.x; r1 &= rb.y;
                 }
                 const bool has1 = i + 1u < nw;
                 if (!has1) r1 = 0u;
+                // union: docs of the first word below the round's first doc were output by the round before (an AND never
+                // sees them: the driver has no posting there)
+                if (UNION && i == 0u) r0 &= ~((1u << lowbits) - 1u);
                 if ((wspan & 31u) != 31u) {
                     const uint32_t tm = (2u << (wspan & 31u)) - 1u;
                     if (i == nw - 1u) r0 &= tm;
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             II2_STAMP(1)      // generator + fetch issue
             const uint32_t nw = (P.wspan >> 5) + 1u;
             const uint32_t ncl = nw + 2u * (DN_GU / 32u) + 2u;   // <= DN_NW - 2; cleared in 4-word steps
-            if (P.flags & PF_FIRST) { clear(bmA, ncl); clear(bmB, ncl); }
+            if (P.flags & PF_FIRST) { clear(bmA, ncl); if (!UNION) clear(bmB, ncl); }
             if (P.flags & PF_FOLD) {
                 for (uint32_t i = (uint32_t)l; i < nw; i += 64u) bmA[DN_GU / 32u + i] &= bmB[DN_GU / 32u + i];
                 clear(bmB, ncl);
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             II2_STAMP(3)      // clear / fold
             if (P.nvalid != 0u) mark_rows(P, B, (P.flags & PF_TOB) ? bmB : bmA);
             II2_STAMP(4)      // mark
-            if (P.flags & PF_LAST) finalise(P.wlo, P.wspan);
+            if (P.flags & PF_LAST) finalise(P.wlo, P.wspan, P.lowbits);
             II2_STAMP(5)      // finalise
             P = Q;
             B = Bq;
@@ -497,9 +510,13 @@ __global__ __launch_bounds__(256) void k_dense_expand(DenseParams p) {
 hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, s);
     const uint32_t grid = (p.n_waves + 3u) / 4u;
-    if (p.n_lists == 2u) hipLaunchKernelGGL(k_dense_tiles<2u>, dim3(grid), dim3(256), 0, s, p);
-    else if (p.n_lists == 3u) hipLaunchKernelGGL(k_dense_tiles<3u>, dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_dense_tiles<4u>, dim3(grid), dim3(256), 0, s, p);
+    if (p.is_union) {
+        if (p.n_lists == 2u) hipLaunchKernelGGL((k_dense_tiles<2u, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.n_lists == 3u) hipLaunchKernelGGL((k_dense_tiles<3u, true>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_dense_tiles<4u, true>), dim3(grid), dim3(256), 0, s, p);
+    } else if (p.n_lists == 2u) hipLaunchKernelGGL((k_dense_tiles<2u, false>), dim3(grid), dim3(256), 0, s, p);
+    else if (p.n_lists == 3u) hipLaunchKernelGGL((k_dense_tiles<3u, false>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_dense_tiles<4u, false>), dim3(grid), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_dense_expand, dim3(grid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();

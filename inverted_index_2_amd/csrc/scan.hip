@@ -12,10 +12,10 @@ struct U32ToU64 {
 
 size_t scan_temp_bytes(size_t n) {
     size_t a = 0, b = 0, c = 0;
-    hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, (hipStream_t)0);
-    hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, (hipStream_t)0);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, a, (const uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, (hipStream_t)0);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, b, (const uint64_t *)nullptr, (uint64_t *)nullptr, (int)n, (hipStream_t)0);
     hipcub::TransformInputIterator<uint64_t, U32ToU64, const uint32_t *> it((const uint32_t *)nullptr, U32ToU64());
-    hipcub::DeviceScan::ExclusiveSum(nullptr, c, it, (uint64_t *)nullptr, (int)n, (hipStream_t)0);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, it, (uint64_t *)nullptr, (int)n, (hipStream_t)0);
     size_t m = a > b ? a : b;
     m = m > c ? m : c;
     return (m + 255) & ~(size_t)255;

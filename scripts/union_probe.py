@@ -1,21 +1,21 @@
-"""Union of the two C2 lists (100M docs): OR tiles (union.dense=1) vs the merge passes."""
-import sys, time, os
+"""GPU probe: union of the two C2 lists (Zipf ranks 2 and 3 over 100M docs): streaming kernel vs the fixed-range OR tiles."""
+import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from inverted_index_2_amd import Context, synth
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
 ctx = Context(0)
-a, b = synth.zipf_list(2, D), synth.zipf_list(3, D)
-seg = ctx.encode_lists([a, b])
-want = np.union1d(a, b)
-out = ctx.empty(a.size + b.size + 512)
-for dense in (1, 0):
-    ctx.set_option("union.dense", dense)
-    _, n = ctx.union([(seg, 0), (seg, 1)], out=out)
-    ok = n == want.size and np.array_equal(out.download(n), want)
-    t = time.time()
-    K = 10
-    for _ in range(K):
-        ctx.union([(seg, 0), (seg, 1)], out=out)
-    dt = (time.time() - t) / K
-    print(f"union.dense={dense} match={ok}: {dt*1e6:.0f} us  {(a.size+b.size)/dt/1e9:.1f} Gpostings/s  out {n}", flush=True)
+lists = [synth.zipf_list(r, D) for r in (2, 3)]
+seg = ctx.encode_lists(lists)
+ls = [(seg, 0), (seg, 1)]
+out = ctx.empty(sum(l.size for l in lists) + 16)
+want = np.union1d(lists[0], lists[1]).astype(np.uint32)
+for stream in (1, 0):
+    ctx.set_option("union.stream", stream)
+    _, n = ctx.union(ls, out=out)
+    assert n == want.size and np.array_equal(out.download(n), want), stream
+    ctx.sync(); t = time.time()
+    for _ in range(20): ctx.union(ls, out=out)
+    ctx.sync(); dt = (time.time() - t) / 20
+    print(f"union.stream={stream}: {dt*1e6:.1f} us  {sum(l.size for l in lists)/dt/1e12:.3f} T postings/s  ids out {n}", flush=True)
+seg.free(); ctx.close()

@@ -100,3 +100,61 @@ def test_dense_zipf_pairs_match_the_oracle(ctx):
     _check(ctx, [lists[0], lists[0][::3].copy(), lists[1]])
     lo, hi = lists[0][lists[0] < D // 2], lists[1][lists[1] >= D // 2]
     _check(ctx, [lo, hi])
+
+
+# ---- the same kernel with OR semantics: unions paced by a long dense list (PrefixSearch, inverted_index.go:274-292) ----
+def _check_union(ctx, lists, removed=None, split=False):
+    want = lists[0]
+    for x in lists[1:]:
+        want = np.union1d(want, x)
+    if removed is not None:
+        want = np.setdiff1d(want, removed, assume_unique=True)
+    want = want.astype(np.uint32)
+    tomb = ctx.tombstones(removed) if removed is not None else None
+    if split:
+        segs = [ctx.encode_lists([l]) for l in lists]
+        ls = [(s, 0) for s in segs]
+    else:
+        seg = ctx.encode_lists(lists)
+        ls = [(seg, i) for i in range(len(lists))]
+    out = ctx.empty(sum(l.size for l in lists) + 16)
+    for stream in (1, 0):                          # the streaming kernel, then the fixed-range OR tiles as a second opinion
+        ctx.set_option("union.stream", stream)
+        _, n = ctx.union(ls, tomb=tomb, out=out)
+        assert n == want.size, (stream, n, want.size)
+        assert np.array_equal(out.download(n), want), stream
+    ctx.set_option("union.stream", 1)
+    return want
+
+
+@pytest.mark.parametrize("ps", [(0.5, 0.33), (0.9, 0.05), (0.3, 0.3, 0.002), (0.6, 0.5, 0.4, 0.01)])
+def test_stream_union_bernoulli_lists(ctx, ps):
+    rng = np.random.default_rng(int(sum(ps) * 977))
+    U = 1_600_000
+    lists = [bernoulli(rng, p, 0, U) for p in ps]
+    _check_union(ctx, lists)
+    _check_union(ctx, lists, removed=bernoulli(rng, 0.05, 0, U))
+    _check_union(ctx, lists[::-1], split=True)
+
+
+def test_stream_union_lists_reaching_past_the_pacer(ctx):
+    # the longest list covers [300k, 1.5M); the others start before it and end after it (the first and the last round
+    # of the pacer stretch over them), one has holes and multi-byte gaps, one ends next to 2^32 - far outside: that
+    # case must fall back to the fixed-range tiles and still be exact
+    rng = np.random.default_rng(5)
+    pacer = bernoulli(rng, 0.6, 300_000, 1_500_000)
+    early = bernoulli(rng, 0.2, 250_000, 900_000)
+    late = bernoulli(rng, 0.3, 700_000, 1_560_000)
+    late = late[~((late >= 1_000_000) & (late < 1_090_000))]
+    _check_union(ctx, [pacer, early, late])
+    _check_union(ctx, [early, pacer])
+    _check_union(ctx, [late, pacer], removed=bernoulli(rng, 0.03, 0, 1_600_000))
+    far = np.concatenate([bernoulli(rng, 0.1, 0, 50_000), np.array([4_000_000_000, 0xFFFFFFFE], np.uint32)]).astype(np.uint32)
+    _check_union(ctx, [pacer, far])
+
+
+def test_stream_union_duplicates_and_identical_lists(ctx):
+    rng = np.random.default_rng(6)
+    a = bernoulli(rng, 0.5, 0, 1_000_000)
+    _check_union(ctx, [a, a])
+    _check_union(ctx, [a, a[::2], a[1::3]])
