@@ -11,7 +11,7 @@ One run times BOTH halves of the metric ("intersect + segment-merge") and prints
 * `merge` (N = 1): configs[2] — 16-way segment merge of 1M terms x mean 1000 postings (~1.06e9 postings in), 1 %
   tombstones; checked against the oracle before timing; that oracle run is also the `cpu_baseline` sample.
 * `merge_strong` (every N): configs[3] — ONE fixed problem, 64 segments x 1M terms, the terms cut into N contiguous
-  ranges balanced by posting count (shard.go:362-378 ranges are contiguous too); every rank merges its range, then the
+  ranges balanced by estimated merge cost (shard.go:362-378 ranges are contiguous too); every rank merges its range, then the
   merged postings are concatenated in rank order with ii2_allgatherv (RCCL).  This is the STRONG-scaling figure the
   1 -> 8 GPU target is about.  (The headline is WEAK scaling: every rank intersects its own doc-range shard.)
 
@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--merge-mean", type=float, default=1000.0)
     ap.add_argument("--merge-steps", type=int, default=0, help="timed merges (0: min(steps, 10))")
     ap.add_argument("--cold-pairs", type=int, default=4)
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank uses cuda:0, the process group is gloo and the exchange takes the "
+                         "torch fallback (RCCL refuses two ranks on one device) - checks the multi-rank control flow, the numbers mean nothing")
     return ap.parse_args()
 
 
@@ -110,12 +113,18 @@ class Job:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-        torch.cuda.set_device(self.local_rank)
+        self.rehearse = bool(args.rehearse) and self.world > 1
+        device = 0 if self.rehearse else self.local_rank
+        self.dev = "cpu" if self.rehearse else "cuda"      # where the control-plane tensors of the collectives live
+        torch.cuda.set_device(device)
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         from inverted_index_2_amd import Context
-        self.ctx = Context(self.local_rank)
+        self.ctx = Context(device)
         self.ctx.selftest()
         self.comm = None           # "ii2" | "torch" once decided (identically on every rank)
         self.rc = 0
@@ -129,7 +138,7 @@ class Job:
     def max_over_ranks(self, x):
         if self.world == 1:
             return x
-        t = self.torch.tensor([x], dtype=self.torch.float64, device="cuda")
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -141,13 +150,15 @@ class Job:
         from inverted_index_2_amd import comm_unique_id
         ok = 1
         try:
+            if self.rehearse:
+                raise RuntimeError("rehearsal on one GPU: the library communicator is not attempted")
             uid = [comm_unique_id() if self.rank == 0 else None]
             self.dist.broadcast_object_list(uid, src=0)
             self.ctx.comm_init(self.world, self.rank, uid[0])
         except Exception as e:  # noqa: BLE001
             print("rank %d: ii2_comm_init failed: %r" % (self.rank, e), file=sys.stderr, flush=True)
             ok = 0
-        t = self.torch.tensor([ok], dtype=self.torch.int32, device="cuda")
+        t = self.torch.tensor([ok], dtype=self.torch.int32, device=self.dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         self.comm = "ii2" if int(t.item()) == 1 else "torch"
 
@@ -161,11 +172,11 @@ class Job:
             counts = self.ctx.allgatherv(local, n_local, out, self.world)
             return out, counts, "ii2_allgatherv (ncclAllGather of counts + grouped ncclSend/ncclRecv over xGMI)"
         # every rank agreed that the library communicator is unusable: padded all_gather through torch's RCCL communicator
-        cnt = torch.tensor([n_local], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([n_local], dtype=torch.int64, device=self.dev)
         cnts = [torch.zeros_like(cnt) for _ in range(self.world)]
         dist.all_gather(cnts, cnt)
         host = local.download(n_local)
-        mine = torch.from_numpy(np.concatenate([host, np.zeros(cap_per_rank - n_local, np.uint32)]).view(np.int32)).cuda()
+        mine = torch.from_numpy(np.concatenate([host, np.zeros(cap_per_rank - n_local, np.uint32)]).view(np.int32)).to(self.dev)
         parts = [torch.empty_like(mine) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         counts = [int(c.item()) for c in cnts]
@@ -477,8 +488,8 @@ def bench_merge(job):
 
 
 def bench_merge_strong(job):
-    """configs[3]: ONE 64-segment x 1M-term merge, the terms cut into `world` contiguous ranges balanced by posting
-    count; every rank merges its range; the merged postings are concatenated in rank order over RCCL."""
+    """configs[3]: ONE 64-segment x 1M-term merge, the terms cut into `world` contiguous ranges balanced by estimated
+    merge cost; every rank merges its range; the merged postings are concatenated in rank order over RCCL."""
     args, ctx, world, rank = job.args, job.ctx, job.world, job.rank
     from inverted_index_2_amd import sharding, synth
     T, k = args.merge_terms, args.strong_segments
@@ -507,14 +518,14 @@ def bench_merge_strong(job):
     del offs, vals
     steps = args.merge_steps or min(args.steps, 10)
     dt, dev_ms, dev_n = time_merges(job, segs, tomb, out_off, out_vals, steps)
-    tot = job.torch.tensor([float(n_in_local), float(st.n_out)], dtype=job.torch.float64, device="cuda")
+    tot = job.torch.tensor([float(n_in_local), float(st.n_out)], dtype=job.torch.float64, device=job.dev)
     if world > 1:
         job.dist.all_reduce(tot)
     n_in_total, n_out_total = int(tot[0].item()), int(tot[1].item())
     res = {
         "value": n_in_total * steps / dt, "unit": "postings/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "scaling": "strong",
         "config": {"workload": "ONE %d-way segment merge of %d terms x mean %.0f postings (BASELINE configs[3]), terms cut into "
-                               "%d contiguous ranges balanced by posting count" % (k, T, args.merge_mean, world),
+                               "%d contiguous ranges balanced by estimated merge cost (sharding.merge_cost_weights)" % (k, T, args.merge_mean, world),
                    "postings_in_total": n_in_total, "postings_out_total": n_out_total,
                    "rank0_terms": [int(t0), int(t1)] if rank == 0 else None, "rank0_postings_in": n_in_local if rank == 0 else None,
                    "parallelism": "terms%d" % world},
@@ -523,7 +534,7 @@ def bench_merge_strong(job):
     if world > 1:
         def exchange():
             job.torch.cuda.synchronize()
-            cap = job.torch.tensor([int(st.n_out)], dtype=job.torch.int64, device="cuda")
+            cap = job.torch.tensor([int(st.n_out)], dtype=job.torch.int64, device=job.dev)
             job.dist.all_reduce(cap, op=job.dist.ReduceOp.MAX)
             g0 = time.perf_counter()
             gout, counts, impl = job.gather(out_vals, int(st.n_out), int(cap.item()))
@@ -571,8 +582,10 @@ def main():
     for name in ("merge", "merge_strong"):
         if name in parts and parts[name] is not head:
             result[name] = parts[name]
+    if job.rehearse:
+        result["rehearsal"] = "all %d ranks shared cuda:0 (gloo control plane, torch exchange fallback): control-flow check only" % world
     if world > 1:
-        rc = job.torch.tensor([job.rc], dtype=job.torch.int32, device="cuda")
+        rc = job.torch.tensor([job.rc], dtype=job.torch.int32, device=job.dev)
         job.dist.all_reduce(rc, op=job.dist.ReduceOp.MAX)
         job.rc = int(rc.item())
     if rank == 0:

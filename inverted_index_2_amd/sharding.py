@@ -54,14 +54,32 @@ def concat_in_rank_order(parts: Sequence[np.ndarray]) -> np.ndarray:
     return np.concatenate(list(parts)) if len(parts) else np.empty(0, np.uint32)
 
 
-def balanced_term_ranges(n_terms: int, mean_len: float, universe: int, world: int) -> List[Tuple[int, int]]:
-    """Contiguous term ranges of the big synthetic merge workload, one per rank, balanced by POSTING count (Zipf skew:
-    equal term counts would give rank 0 most of the work — SURVEY §8 e), cut at the generator's chunk boundaries so
-    that every rank can generate exactly its own share."""
+# Merge cost per posting by term size, relative to a giant term (measured range by range on one MI355X, round 2,
+# scripts/strong_ranges.py, 64 segments): terms above the tile size run through single-term tiles at the same rate
+# whatever their size; batches of small terms pay per list (block decode, slice tables, scans over T x k counts).
+_COST_LOG10_SIZE = np.array([2.2, 3.0, 3.8, 4.6])
+_COST_PER_POSTING = np.array([2.7, 2.0, 1.18, 1.0])
+
+
+def merge_cost_weights(sizes: np.ndarray) -> np.ndarray:
+    """Estimated merge cost of every term (arbitrary unit: postings of a giant term)."""
+    sizes = np.asarray(sizes, dtype=np.float64)
+    return sizes * np.interp(np.log10(np.maximum(sizes, 1.0)), _COST_LOG10_SIZE, _COST_PER_POSTING)
+
+
+def balanced_term_ranges(n_terms: int, mean_len: float, universe: int, world: int, by: str = "cost") -> List[Tuple[int, int]]:
+    """Contiguous term ranges of the big synthetic merge workload, one per rank, balanced by estimated merge COST
+    (by="cost": posting count weighted by merge_cost_weights — a posting of a 160-posting term costs 2.7x one of a giant
+    term, so ranges balanced by posting count alone leave the tail rank 2.5x the head rank's time) or by POSTING count
+    (by="postings"; Zipf skew: equal term counts would give rank 0 most of the work — SURVEY §8 e), cut at the
+    generator's chunk boundaries so that every rank can generate exactly its own share."""
     from . import synth
     sizes, fine = synth.merge_chunk_bounds(n_terms, mean_len, universe)
-    cum = np.concatenate([[0], np.cumsum(sizes)])
-    total = int(cum[-1])
+    if by not in ("cost", "postings"):
+        raise ValueError("by must be 'cost' or 'postings'")
+    w = merge_cost_weights(sizes) if by == "cost" else sizes.astype(np.float64)
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = float(cum[-1])
     fine = np.asarray(fine)
     cuts = [0]
     for r in range(1, world):

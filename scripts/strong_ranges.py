@@ -1,0 +1,34 @@
+"""GPU probe: the strong-scaling split of BASELINE configs[3] (64 segments x 1M terms) measured range by range on ONE
+GPU — every rank's share is generated, merged and timed in turn, so the slowest range (what an N-GPU run waits for) is
+known without an N-GPU node.  Usage: strong_ranges.py [world ...]   (default 8)"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from inverted_index_2_amd import Context, synth, sharding
+T, k, mean, D = 1_000_000, 64, 1000.0, 100_000_000
+worlds = [int(a) for a in sys.argv[1:] if "=" not in a] or [8]
+only = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("only=")]      # only=<rank>: just that range (for rocprofv3)
+ctx = Context(0)
+ctx.set_option("profile.events", 1)
+for world in worlds:
+    ranges = sharding.balanced_term_ranges(T, mean, D, world)
+    times, posts = [], []
+    for r, (t0, t1) in enumerate(ranges):
+        if only and r not in only: continue
+        offs, vals, removed = synth.merge_workload_big(T, k, mean, D, threads=16, term_range=(t0, t1))
+        n_in = int(sum(int(o[-1]) for o in offs))
+        segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+        tomb = ctx.tombstones(removed)
+        out_off = ctx.empty(t1 - t0 + 1, np.uint64); out_vals = ctx.empty(max(n_in, 1))
+        del offs, vals
+        ctx.merge(segs, tomb, out_off, out_vals); ctx.sync()
+        t = time.perf_counter()
+        for _ in range(3): ctx.merge(segs, tomb, out_off, out_vals)
+        ctx.sync(); dt = (time.perf_counter() - t) / 3
+        times.append(dt * 1e3); posts.append(n_in)
+        print(f"world {world} range [{t0}, {t1}) terms {t1 - t0} postings {n_in} merge {dt*1e3:.2f} ms", flush=True)
+        for s in segs: s.free()
+        tomb.free(); out_off.free(); out_vals.free()
+    print(f"world {world}: slowest range {max(times):.2f} ms, sum {sum(times):.2f} ms, postings {sum(posts)} -> "
+          f"{sum(posts)/max(times)/1e6:.1f} G postings/s if the ranges ran side by side", flush=True)
+ctx.close()

@@ -113,8 +113,16 @@ def test_key_ranges_partition_the_keyspace():
 def test_balanced_term_ranges_balance_postings():
     sizes, fine = synth.merge_chunk_bounds(1_000_000, 1000.0, 100_000_000)
     for world in (2, 4, 8):
-        rs = sharding.balanced_term_ranges(1_000_000, 1000.0, 100_000_000, world)
+        rs = sharding.balanced_term_ranges(1_000_000, 1000.0, 100_000_000, world, by="postings")
         assert rs[0][0] == 0 and rs[-1][1] == 1_000_000 and all(a[1] == b[0] for a, b in zip(rs[:-1], rs[1:]))
         assert all(a in fine and b in fine for a, b in rs)
         share = [sizes[a:b].sum() / sizes.sum() for a, b in rs]
         assert max(share) < 1.1 / world and min(share) > 0.9 / world
+        # the default balances estimated merge cost: small terms weigh more per posting, so the tail ranks hold fewer postings
+        rc = sharding.balanced_term_ranges(1_000_000, 1000.0, 100_000_000, world)
+        assert rc[0][0] == 0 and rc[-1][1] == 1_000_000 and all(a[1] == b[0] for a, b in zip(rc[:-1], rc[1:]))
+        assert all(a in fine and b in fine for a, b in rc)
+        w = sharding.merge_cost_weights(sizes)
+        cshare = [w[a:b].sum() / w.sum() for a, b in rc]
+        assert max(cshare) < 1.1 / world and min(cshare) > 0.9 / world
+        assert sizes[rc[-1][0]:].sum() < sizes[rs[-1][0]:].sum()
