@@ -98,9 +98,12 @@ int ii2_copy_d2h(ii2_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
  * list ascending and duplicate-free — what the index itself always produces. */
 int ii2_seg_encode(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *post_off, const uint32_t *values,
                    int where, ii2_seg **out);
-/* Adopt an already DV1-encoded segment (blk_off[n_lists+1], skip[n_blocks+1], payload[n_bytes]). */
-int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const uint32_t *blk_off,
-                   const ii2_skip *skip, const uint8_t *payload, int where, ii2_seg **out);
+/* Adopt an already DV1-encoded segment (blk_off[n_lists+1], skip[n_blocks+1], payload[n_bytes]).
+ * The caller states the lengths of its arrays; blk_off[n_lists] must equal n_blocks and
+ * skip[n_blocks].byte_off must equal n_bytes, else II2_EINVAL — the library never reads past the
+ * stated lengths, whatever the arrays contain. */
+int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes,
+                   const uint32_t *blk_off, const ii2_skip *skip, const uint8_t *payload, int where, ii2_seg **out);
 /* Decode step.  Replaces Reader.Next -> intcomp.UncompressUint32 (file/reader.go:79-100):
  * post_off[n_lists+1] and values[n_postings] are written to caller buffers. */
 int ii2_seg_decode(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *post_off, uint32_t *values, int where);

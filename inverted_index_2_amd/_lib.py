@@ -45,7 +45,7 @@ PROTOTYPES = {
     "ii2_copy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ii2_copy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "ii2_seg_encode": (C.c_int, [vp, C.c_uint64, vp, vp, C.c_int, vpp]),
-    "ii2_seg_import": (C.c_int, [vp, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_int, vpp]),
+    "ii2_seg_import": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_int, vpp]),
     "ii2_seg_decode": (C.c_int, [vp, vp, vp, vp, C.c_int]),
     "ii2_seg_export": (C.c_int, [vp, vp, vp, vp, vp]),
     "ii2_seg_select": (C.c_int, [vp, vp, C.c_uint64, vp, vpp]),

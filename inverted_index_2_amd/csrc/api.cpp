@@ -342,9 +342,10 @@ int ii2_seg_encode(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *post_off, con
     return ii2_seg_encode_dev_unlocked(ctx, n_lists, dpo, dv, n, out);
 }
 
-int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const uint32_t *blk_off, const ii2_skip *skip,
-                   const uint8_t *payload, int where, ii2_seg **out) {
+int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, const uint32_t *blk_off,
+                   const ii2_skip *skip, const uint8_t *payload, int where, ii2_seg **out) {
     if (!ctx || !blk_off || !skip || !out) return fail(ctx, II2_EINVAL, "ii2_seg_import: bad argument");
+    if (n_blocks > 0xFFFFFFFEull || n_bytes > 0xFFFFFFFFull) return fail(ctx, II2_EINVAL, "ii2_seg_import: a segment holds < 2^32 blocks and payload bytes");
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     *out = nullptr;
@@ -354,19 +355,20 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, const ui
     seg->device = ctx->device;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
+    // the closing entries must agree with the stated array lengths: nothing below reads past those lengths
     uint32_t nb = 0;
-    if (where == II2_HOST) nb = blk_off[n_lists];
-    else {
-        HIP_TRY(ctx, hipMemcpyAsync(&nb, blk_off + n_lists, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    seg->n_blocks = nb;
     ii2_skip last;
-    if (where == II2_HOST) last = skip[nb];
-    else {
-        HIP_TRY(ctx, hipMemcpyAsync(&last, skip + nb, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
+    if (where == II2_HOST) {
+        nb = blk_off[n_lists];
+        last = skip[n_blocks];
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(&nb, blk_off + n_lists, sizeof nb, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&last, skip + n_blocks, sizeof last, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    if (nb != n_blocks) return fail(ctx, II2_EINVAL, "ii2_seg_import: malformed DV1 segment (blk_off[n_lists] differs from n_blocks)");
+    if (last.byte_off != n_bytes) return fail(ctx, II2_EINVAL, "ii2_seg_import: malformed DV1 segment (skip[n_blocks].byte_off differs from n_bytes)");
+    seg->n_blocks = nb;
     seg->n_bytes = last.byte_off;
     if (seg->n_bytes && !payload) return fail(ctx, II2_EINVAL, "ii2_seg_import: payload is NULL");
     if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||

@@ -161,8 +161,10 @@ class Context:
         skip = _np(skip, SKIP_DTYPE)
         payload = _np(payload, np.uint8)
         s = C.c_void_p()
-        self._ck(self.lib.ii2_seg_import(self.h, blk_off.size - 1, n_postings, _ptr(blk_off), _ptr(skip), _ptr(payload),
-                                         II2_HOST, C.byref(s)))
+        if blk_off.size < 1 or skip.size < 1:
+            raise ValueError("import_dv1: blk_off and skip hold at least their closing entry")
+        self._ck(self.lib.ii2_seg_import(self.h, blk_off.size - 1, n_postings, skip.size - 1, payload.size, _ptr(blk_off), _ptr(skip),
+                                         _ptr(payload) if payload.size else None, II2_HOST, C.byref(s)))
         return Segment(self, s)
 
     def tombstones(self, removed, where: int = II2_HOST) -> "Tombstones":

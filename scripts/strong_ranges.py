@@ -1,12 +1,14 @@
 """GPU probe: the strong-scaling split of BASELINE configs[3] (64 segments x 1M terms) measured range by range on ONE
 GPU — every rank's share is generated, merged and timed in turn, so the slowest range (what an N-GPU run waits for) is
-known without an N-GPU node.  Usage: strong_ranges.py [world ...]   (default 8)"""
+known without an N-GPU node.  Usage: strong_ranges.py [world ...] [k=<segments>] [only=<rank>]   (default: 8 ranges, 64 segments)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from inverted_index_2_amd import Context, synth, sharding
 T, k, mean, D = 1_000_000, 64, 1000.0, 100_000_000
 worlds = [int(a) for a in sys.argv[1:] if "=" not in a] or [8]
+kk = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("k=")]          # k=<segments> (default 64)
+if kk: k = kk[0]
 only = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("only=")]      # only=<rank>: just that range (for rocprofv3)
 ctx = Context(0)
 ctx.set_option("profile.events", 1)

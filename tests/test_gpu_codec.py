@@ -100,6 +100,14 @@ def test_import_rejects_malformed_segment(ctx):
     bad2[1] = 999
     with pytest.raises(II2Error):
         ctx.import_dv1(a.size, bad2, skip, payload)
+    # the arrays' lengths are part of the call: closing entries that disagree with them are refused before anything is
+    # read past the arrays (blk_off[n_lists] = 999 above used to index the 5-entry skip table with 999)
+    with pytest.raises(II2Error) as e:
+        ctx.import_dv1(a.size, blk, skip, payload[:-7])          # payload shorter than skip[n_blocks].byte_off
+    assert e.value.code == -1
+    with pytest.raises(II2Error) as e:
+        ctx.import_dv1(a.size, blk, skip[:-1], payload)          # skip table one entry short
+    assert e.value.code == -1
     ctx.import_dv1(a.size, blk, skip, payload)      # the intact one is accepted
     # n_postings sizes the decode buffers: a count that differs from what the blocks hold is refused either way
     for wrong in (a.size - 1, a.size + 1, 0):
