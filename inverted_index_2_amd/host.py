@@ -40,6 +40,11 @@ def _lib_typed():
     if not _typed:
         lib.ii2h_create.restype = vp
         lib.ii2h_create.argtypes = [vp, C.c_int]
+        lib.ii2h_open.restype = vp
+        lib.ii2h_open.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64]
+        lib.ii2h_file_write.argtypes = [vp, vp, C.c_char_p, C.c_int, vp, vp, C.c_uint64, vp, vp, C.c_char_p]
+        lib.ii2h_file_read.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int, u64p]
+        lib.ii2h_remove_segment.argtypes = [vp, C.c_char_p, C.c_char_p]
         lib.ii2h_destroy.argtypes = [vp]
         lib.ii2h_last_error.restype = C.c_char_p
         lib.ii2h_last_error.argtypes = [vp]
@@ -71,10 +76,17 @@ def _pack(terms: List[bytes]):
 
 
 class _Target:
-    def __init__(self, ctx: Context, is_index: bool):
+    def __init__(self, ctx: Context, is_index: bool, basedir: Optional[str] = None):
         self.lib = _lib_typed()
         self.ctx = ctx
-        self.h = self.lib.ii2h_create(ctx.h, 1 if is_index else 0)
+        self.basedir = basedir
+        if basedir is None:
+            self.h = self.lib.ii2h_create(ctx.h, 1 if is_index else 0)
+        else:               # NewShard(basedir) / NewInvertedIndex(basedir): what the directory holds is loaded
+            err = C.create_string_buffer(512)
+            self.h = self.lib.ii2h_open(ctx.h, 1 if is_index else 0, os.fsencode(basedir), err, len(err))
+            if not self.h:
+                raise HostError(err.value.decode())
 
     def _ck(self, rc: int) -> None:
         if rc:
@@ -131,10 +143,11 @@ class _Target:
 
 
 class Shard(_Target):
-    """shard.go: Put / Read / Remove / Merge."""
+    """shard.go: Put / Read / Remove / Merge.  With `basedir` the shard lives in that directory (segment files and
+    removed.list, host/segment_file.h) and a new Shard on the same directory picks the state up (shard.go:300-358)."""
 
-    def __init__(self, ctx: Context):
-        super().__init__(ctx, False)
+    def __init__(self, ctx: Context, basedir: Optional[str] = None):
+        super().__init__(ctx, False, basedir)
 
     def merge(self, req_count: int, m_count: int) -> int:
         return self._merge(req_count, m_count, 1)
@@ -150,8 +163,8 @@ class Shard(_Target):
 class InvertedIndex(_Target):
     """inverted_index.go: Put / Read / Merge / PutRemoved / PrefixSearch (+ Intersect)."""
 
-    def __init__(self, ctx: Context):
-        super().__init__(ctx, True)
+    def __init__(self, ctx: Context, basedir: Optional[str] = None):
+        super().__init__(ctx, True, basedir)
 
     def merge(self, req_count: int, m_count: int, concurrency: int = 1) -> int:
         return self._merge(req_count, m_count, concurrency)
@@ -176,3 +189,53 @@ class InvertedIndex(_Target):
     @property
     def n_shards(self) -> int:
         return self.lib.ii2h_shard_count(self.h)
+
+
+class SegmentFiles(_Target):
+    """file.Writer / file.Reader / file.RemoveSegment (file/writer.go, file/reader.go) over host/segment_file.h: the
+    encode and decode steps run on the device."""
+
+    def __init__(self, ctx: Context):
+        super().__init__(ctx, False)
+
+    def write(self, directory: str, term_values: List[Tuple[bytes, List[int]]], direct: bool = False) -> str:
+        """NewWriter / NewDirectWriter + Append for every (term, values) + Close; returns GetKey()."""
+        blob, off = _pack([t for t, _ in term_values])
+        po = np.zeros(len(term_values) + 1, np.uint64)
+        if term_values:
+            po[1:] = np.cumsum([len(v) for _, v in term_values])
+        flat = np.ascontiguousarray([x for _, v in term_values for x in v] + [0], dtype=np.uint32)
+        key = C.create_string_buffer(32)
+        self._ck(self.lib.ii2h_file_write(self.h, self.ctx.h, os.fsencode(directory), 1 if direct else 0, blob.ctypes.data, off.ctypes.data,
+                                          len(term_values), po.ctypes.data, flat.ctypes.data, key))
+        return key.value.decode()
+
+    def write_arrays(self, directory: str, term_blob: np.ndarray, term_off: np.ndarray, post_off: np.ndarray, values: np.ndarray) -> str:
+        """write() for callers that already hold flat arrays (terms: bytes + u64 offsets; lists: u64 offsets + u32 ids)."""
+        key = C.create_string_buffer(32)
+        term_blob = np.ascontiguousarray(term_blob, np.uint8)
+        term_off = np.ascontiguousarray(term_off, np.uint64)
+        post_off = np.ascontiguousarray(post_off, np.uint64)
+        values = np.ascontiguousarray(values, np.uint32)
+        self._ck(self.lib.ii2h_file_write(self.h, self.ctx.h, os.fsencode(directory), 0, term_blob.ctypes.data, term_off.ctypes.data,
+                                          term_off.size - 1, post_off.ctypes.data, values.ctypes.data, key))
+        return key.value.decode()
+
+    def read_count(self, directory: str, key: str) -> Tuple[int, int]:
+        """Reads and decodes a whole segment; returns (terms, postings) without copying the lists into Python."""
+        n = C.c_uint64()
+        self._ck(self.lib.ii2h_file_read(self.h, self.ctx.h, os.fsencode(directory), key.encode(), b"", 0, 0, b"", 0, 0, C.byref(n)))
+        return n.value, sum(self.lib.ii2h_result_values_len(self.h, i) for i in range(0, n.value, max(n.value // 1000, 1)))
+
+    def read(self, directory: str, key: str, lo: Optional[bytes] = None, hi: Optional[bytes] = None):
+        """NewReader(dir, key, min, max) drained with Next(); None when the segment has nothing in range."""
+        n = C.c_uint64()
+        rc = self.lib.ii2h_file_read(self.h, self.ctx.h, os.fsencode(directory), key.encode(), lo or b"", len(lo or b""), lo is not None,
+                                     hi or b"", len(hi or b""), hi is not None, C.byref(n))
+        if rc == 1:
+            return None
+        self._ck(rc)
+        return self._results(n.value)
+
+    def remove(self, directory: str, key: str) -> None:
+        self._ck(self.lib.ii2h_remove_segment(self.h, os.fsencode(directory), key.encode()))

@@ -3,9 +3,13 @@
 // layer is C++ with the reference's names, argument meaning and error behaviour, and the posting
 // work of every operation goes to the GPU through the same entry points a cgo binding would
 // use.  Segments live in HBM (DV1); term dictionaries are plain sorted byte strings here (the
-// reference's vellum FST, files, locks and pools are out of scope — SURVEY.md §8).
+// reference's vellum FST, locks and pools are out of scope — SURVEY.md §8).  A shard opened on a
+// directory keeps its segments and its removed list on disk as well (segment_file.h: the `file`
+// package's Writer / Reader / RemoveSegment and the removed.list persistence).
 //
 //   Shard.Put / Read / Remove / Merge / MinMax      shard.go:33-298
+//   NewShard (load existing files, removed.list)     shard.go:300-358
+//   file.Writer / Reader / RemoveSegment             file/writer.go, file/reader.go
 //   Segments.add ordering                            segments.go:56-64
 //   RemovedLists.Put / Values / Sync                 removed_list.go:36-71
 //   InvertedIndex.Put / Read / Merge / PutRemoved / PrefixSearch   inverted_index.go:41-340
@@ -28,6 +32,7 @@
 #include <vector>
 
 #include "../../include/ii2.h"
+#include "segment_file.h"
 
 namespace ii2h {
 
@@ -88,9 +93,154 @@ static int64_t now_ns() {      // strictly increasing across threads (segment ke
     return t;
 }
 
+// ---- file.Writer / file.Reader over segment_file.h (file/writer.go, file/reader.go) -----------------------------
+// The encode and decode steps run on the device through the C ABI (ii2_seg_encode / ii2_seg_import + ii2_seg_decode):
+// there is no host codec in the product.
+class Writer {
+   public:
+    // file/writer.go:122-136 (NewWriter) and :95-120 (NewDirectWriter)
+    Writer(ii2_ctx *ctx, std::string dir, bool direct) : ctx_(ctx), dir_(std::move(dir)), direct_(direct), key_(std::to_string(now_ns())) {}
+    // terms must ascend (file/writer.go:30); direct mode keeps Values[0] only (:34-40)
+    void Append(const TermValues &tv) {
+        if (closed_) throw Error("writer: append after close");
+        if (direct_ && tv.values.empty()) throw Error("writer: fst insert: direct mode needs one value per term");
+        terms_.push_back(tv.term);
+        if (direct_) vals_.push_back(tv.values[0]);
+        else vals_.insert(vals_.end(), tv.values.begin(), tv.values.end());
+        off_.push_back(vals_.size());
+    }
+    // file/writer.go:61-90: both files appear under their final names only here
+    void Close() {
+        if (closed_) return;
+        closed_ = true;
+        file::TermFile tf;
+        tf.terms = std::move(terms_);
+        tf.direct = direct_;
+        if (direct_) tf.direct_vals = vals_;
+        file::write_terms(dir_, key_, tf);
+        const uint64_t n_terms = tf.terms.size();
+        if (!direct_) {
+            ii2_seg *s = nullptr;
+            ck(ctx_, ii2_seg_encode(ctx_, n_terms, off_.data(), vals_.data(), II2_HOST, &s), "writer: encode");
+            SegHandle seg(s);
+            file::write_dv1(dir_, key_, export_dv1(ctx_, s));
+            file::commit(file::dv1_path(dir_, key_));
+        }
+        file::commit(file::tdx_path(dir_, key_));
+    }
+    const std::string &GetKey() const { return key_; }
+
+    static file::Dv1File export_dv1(ii2_ctx *ctx, const ii2_seg *s) {
+        ii2_seg_info info;
+        ii2_seg_get_info(s, &info);
+        file::Dv1File d;
+        d.n_lists = info.n_lists;
+        d.n_postings = info.n_postings;
+        d.blk_off.resize(info.n_lists + 1);
+        d.skip.resize(info.n_blocks + 1);
+        d.payload.resize(info.n_bytes);
+        ck(ctx, ii2_seg_export(ctx, s, d.blk_off.data(), d.skip.data(), d.payload.empty() ? nullptr : d.payload.data()), "writer: export");
+        return d;
+    }
+
+   private:
+    ii2_ctx *ctx_;
+    std::string dir_;
+    bool direct_;
+    std::string key_;
+    bool closed_ = false;
+    std::vector<Term> terms_;
+    std::vector<uint32_t> vals_;
+    std::vector<uint64_t> off_{0};
+};
+
+// a segment file pair brought to the device: the term dictionary on the host, the lists as an ii2_seg
+struct LoadedSegment {
+    std::vector<Term> terms;
+    ii2_seg *seg = nullptr;        // caller owns
+};
+static LoadedSegment load_segment(ii2_ctx *ctx, const std::string &dir, const std::string &key) {
+    LoadedSegment out;
+    file::TermFile tf = file::read_terms(dir, key);
+    const uint64_t n = tf.terms.size();
+    if (tf.direct) {
+        std::vector<uint64_t> off(n + 1);
+        for (uint64_t i = 0; i <= n; i++) off[i] = i;
+        ck(ctx, ii2_seg_encode(ctx, n, off.data(), tf.direct_vals.data(), II2_HOST, &out.seg), "reader: encode");
+    } else {
+        file::Dv1File d = file::read_dv1(dir, key);
+        if (d.n_lists != n) throw Error("reader: " + key + ": term file and value file disagree on the term count");
+        ck(ctx, ii2_seg_import(ctx, d.n_lists, d.n_postings, d.skip.size() - 1, d.payload.size(), d.blk_off.data(), d.skip.data(),
+                               d.payload.empty() ? nullptr : d.payload.data(), II2_HOST, &out.seg), "reader: values file");
+    }
+    out.terms = std::move(tf.terms);
+    return out;
+}
+
+class Reader {
+   public:
+    struct NothingInRange {};      // vellum.ErrIteratorDone from NewReader: the shard skips the segment (shard.go:257-261)
+    // file/reader.go:136-199: min / max inclusive, nullptr = open
+    Reader(ii2_ctx *ctx, const std::string &dir, const std::string &key, const Term *min, const Term *max) {
+        LoadedSegment ls = load_segment(ctx, dir, key);
+        SegHandle seg(ls.seg);
+        terms_ = std::move(ls.terms);
+        at_ = min ? std::lower_bound(terms_.begin(), terms_.end(), *min, term_less) - terms_.begin() : 0;
+        end_ = max ? std::upper_bound(terms_.begin(), terms_.end(), *max, term_less) - terms_.begin() : terms_.size();
+        if (at_ >= end_) throw NothingInRange{};
+        ii2_seg_info info;
+        ii2_seg_get_info(seg.h, &info);
+        off_.resize(terms_.size() + 1);
+        vals_.resize(info.n_postings);
+        ck(ctx, ii2_seg_decode(ctx, seg.h, off_.data(), vals_.empty() ? nullptr : vals_.data(), II2_HOST), "reader: values file: decompress");
+    }
+    // false = go_iterators.EmptyIterator
+    bool Next(TermValues *tv) {
+        if (closed_ || at_ >= end_) return false;
+        tv->term = terms_[at_];
+        tv->values.assign(vals_.begin() + off_[at_], vals_.begin() + off_[at_ + 1]);
+        at_++;
+        return true;
+    }
+    void Close() { closed_ = true; }
+
+   private:
+    std::vector<Term> terms_;
+    std::vector<uint64_t> off_;
+    std::vector<uint32_t> vals_;
+    size_t at_ = 0, end_ = 0;
+    bool closed_ = false;
+};
+
 class Shard {
    public:
-    explicit Shard(ii2_ctx *ctx) : ctx_(ctx) {}
+    // basedir empty: segments live in HBM only (the replayed reference scripts); else shard.go:300-358 — load every
+    // segment file pair and removed.list found there, and keep the directory in step with every later operation
+    explicit Shard(ii2_ctx *ctx, std::string basedir = "") : ctx_(ctx), basedir_(std::move(basedir)) {
+        if (basedir_.empty()) return;
+        std::error_code ec;
+        if (!file::fs::is_directory(basedir_, ec)) throw Error("load inverted index shard: " + basedir_ + " is not a directory");
+        std::vector<std::string> keys;
+        for (auto &e : file::fs::directory_iterator(basedir_)) {
+            if (e.is_directory()) continue;
+            const std::string name = e.path().filename().string();
+            if (name.size() <= 4 || name.compare(name.size() - 4, 4, "_tdx") != 0) continue;      // (*_tmp files are not segments)
+            keys.push_back(name.substr(0, name.size() - 4));
+        }
+        std::sort(keys.begin(), keys.end());
+        for (auto &key : keys) {
+            char *endp = nullptr;
+            errno = 0;
+            const long long k = std::strtoll(key.c_str(), &endp, 10);
+            if (errno || !endp || *endp || key.empty()) throw Error("load inverted index: key to int conversion: " + key);
+            LoadedSegment ls = load_segment(ctx_, basedir_, key);
+            add(Segment{(int64_t)k, std::move(ls.terms), std::make_shared<SegHandle>(ls.seg)});
+        }
+        try { file::read_removed(basedir_, &removed_); }
+        catch (const std::exception &e) { throw Error(std::string("rem list: ") + e.what()); }
+    }
+    const std::string &basedir() const { return basedir_; }
+    void Close() {}                // shard.go:247-249
 
     // shard.go:33-67 — one direct segment, every term -> [val]
     void Put(std::vector<Term> terms, uint32_t val) {
@@ -101,7 +251,17 @@ class Shard {
         std::vector<uint32_t> vals(terms.size(), val);
         ii2_seg *s = nullptr;
         ck(ctx_, ii2_seg_encode(ctx_, terms.size(), off.data(), vals.data(), II2_HOST, &s), "s: put");
-        add(Segment{now_ns(), std::move(terms), std::make_shared<SegHandle>(s)});
+        Segment seg{now_ns(), std::move(terms), std::make_shared<SegHandle>(s)};
+        if (!basedir_.empty()) {   // file.NewDirectWriter: term file only, the value rides in it (file/writer.go:95-120)
+            file::TermFile tf;
+            tf.terms = seg.terms;
+            tf.direct = true;
+            tf.direct_vals = vals;
+            const std::string key = std::to_string(seg.key);
+            try { file::write_terms(basedir_, key, tf); file::commit(file::tdx_path(basedir_, key)); }
+            catch (const std::exception &e) { throw Error(std::string("index put: ") + e.what()); }
+        }
+        add(std::move(seg));       // make the new segment visible (shard.go:64)
     }
 
     // shard.go:72-75 + makeIterator :253-278 — merged view of all segments, [min,max] inclusive, no tombstones
@@ -118,6 +278,14 @@ class Shard {
         for (auto &s : segments_) ts.push_back(s->key);
         removed_sync(ts);
         removed_[now_ns()] = values;
+        WriteRemovedList();
+    }
+
+    // shard.go:107-120
+    void WriteRemovedList() const {
+        if (basedir_.empty()) return;
+        try { file::write_removed(basedir_, removed_); }
+        catch (const std::exception &e) { throw Error(std::string("write rem list: ") + e.what()); }
     }
 
     // removed_list.go:44-54
@@ -144,12 +312,33 @@ class Shard {
         const std::vector<uint32_t> removed = RemovedValues();
         Segment out;
         const bool any = merged_segment(ctx, segs, removed, &out);
-        if (any) add(std::move(out));              // lazy writer: nothing survives -> no segment (shard.go:219-225)
+        if (any) {                                 // lazy writer: nothing survives -> no segment (shard.go:219-225)
+            if (!basedir_.empty()) {               // file.NewWriter + Close: both files, renamed when complete
+                const std::string key = std::to_string(out.key);
+                try {
+                    file::TermFile tf;
+                    tf.terms = out.terms;
+                    file::write_terms(basedir_, key, tf);
+                    file::write_dv1(basedir_, key, Writer::export_dv1(ctx, out.seg->h));
+                    file::commit(file::dv1_path(basedir_, key));
+                    file::commit(file::tdx_path(basedir_, key));
+                } catch (const std::exception &e) { throw Error(std::string("s: merge: writer close: ") + e.what()); }
+            }
+            add(std::move(out));
+        }
         segments_.erase(std::remove_if(segments_.begin(), segments_.end(),
                                        [&](const std::shared_ptr<Segment> &s) {
                                            return std::find(picked.begin(), picked.end(), s) != picked.end();
                                        }),
                         segments_.end());
+        if (!basedir_.empty()) {                   // file.RemoveSegment for every merged segment; the last error is reported (shard.go:232-242)
+            std::string err;
+            for (auto &sg : picked) {
+                try { file::remove_segment(basedir_, std::to_string(sg->key)); }
+                catch (const std::exception &e) { err = e.what(); }
+            }
+            if (!err.empty()) throw Error(err);
+        }
         return (int)picked.size();
     }
 
@@ -330,6 +519,7 @@ class Shard {
     }
 
     ii2_ctx *ctx_;
+    std::string basedir_;                                  // empty: no files
     std::vector<std::shared_ptr<Segment>> segments_;       // sorted by term count
     std::map<int64_t, std::vector<uint32_t>> removed_;     // RemovedLists.lists
 };
@@ -343,7 +533,21 @@ static uint32_t shard_key(const Term &t) {
 
 class InvertedIndex {
    public:
-    explicit InvertedIndex(ii2_ctx *ctx) : ctx_(ctx) {}
+    // inverted_index.go:342-403: every sub-directory of basedir is a shard named by its key ("%04d")
+    explicit InvertedIndex(ii2_ctx *ctx, std::string basedir = "") : ctx_(ctx), basedir_(std::move(basedir)) {
+        if (basedir_.empty()) return;
+        std::error_code ec;
+        if (!file::fs::is_directory(basedir_, ec)) throw Error("shards read: " + basedir_ + " is not a directory");
+        for (auto &e : file::fs::directory_iterator(basedir_)) {
+            if (!e.is_directory()) continue;
+            const std::string name = e.path().filename().string();
+            char *endp = nullptr;
+            const unsigned long k = std::strtoul(name.c_str(), &endp, 10);
+            if (name.empty() || !endp || *endp || k >= 1024) continue;          // not a shard directory
+            try { shards_.emplace((uint32_t)k, std::make_unique<Shard>(ctx_, e.path().string())); }
+            catch (const std::exception &ex) { throw Error(std::string("shard init: ") + ex.what()); }
+        }
+    }
 
     void Put(const std::vector<Term> &terms, uint32_t val) {                  // inverted_index.go:113-145
         std::map<uint32_t, std::vector<Term>> groups;
@@ -444,7 +648,17 @@ class InvertedIndex {
    private:
     Shard &shard(uint32_t key) {
         auto it = shards_.find(key);
-        if (it == shards_.end()) it = shards_.emplace(key, std::make_unique<Shard>(ctx_)).first;
+        if (it == shards_.end()) {                 // inverted_index.go:163-190 newShard: mkdir <basedir>/<key>
+            std::string dir;
+            if (!basedir_.empty()) {
+                char name[8];
+                std::snprintf(name, sizeof name, "%04u", key);
+                dir = (file::fs::path(basedir_) / name).string();
+                std::error_code ec;
+                if (!file::fs::create_directory(dir, ec) && ec) throw Error("new shard: " + dir + ": " + ec.message());
+            }
+            it = shards_.emplace(key, std::make_unique<Shard>(ctx_, dir)).first;
+        }
         return *it->second;
     }
     std::vector<uint32_t> lists_op(bool is_union, const std::vector<std::vector<uint32_t>> &lists) const {
@@ -464,6 +678,7 @@ class InvertedIndex {
         return out;
     }
     ii2_ctx *ctx_;
+    std::string basedir_;
     std::vector<ii2_ctx *> workers_;                       // contexts of Merge's workers 1..n-1 (created on demand)
     std::map<uint32_t, std::unique_ptr<Shard>> shards_;    // sorted by key, like ii.shards
 };
@@ -498,6 +713,55 @@ ii2h_target *ii2h_create(ii2_ctx *ctx, int is_index) {
     if (is_index) t->index = std::make_unique<InvertedIndex>(ctx);
     else t->shard = std::make_unique<Shard>(ctx);
     return t;
+}
+// NewShard(basedir) / NewInvertedIndex(basedir): loads what the directory holds.  NULL + message in err[] on failure.
+ii2h_target *ii2h_open(ii2_ctx *ctx, int is_index, const char *basedir, char *err, uint64_t err_cap) {
+    auto t = std::make_unique<ii2h_target>();
+    try {
+        if (is_index) t->index = std::make_unique<InvertedIndex>(ctx, basedir);
+        else t->shard = std::make_unique<Shard>(ctx, basedir);
+    } catch (const std::exception &e) {
+        if (err && err_cap) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; }
+        return nullptr;
+    }
+    return t.release();
+}
+// file.NewWriter / NewDirectWriter + Append* + Close in one call; key_out receives GetKey() (NUL-terminated, <= 31 chars)
+int ii2h_file_write(ii2h_target *t, ii2_ctx *ctx, const char *dir, int direct, const uint8_t *term_bytes, const uint64_t *term_off, uint64_t n_terms,
+                    const uint64_t *post_off, const uint32_t *values, char *key_out) {
+    H_TRY(t, {
+        Writer w(ctx, dir, direct != 0);
+        auto terms = unpack_terms(term_bytes, term_off, n_terms);
+        for (uint64_t i = 0; i < n_terms; i++)
+            w.Append(TermValues{terms[i], std::vector<uint32_t>(values + post_off[i], values + post_off[i + 1])});
+        w.Close();
+        std::strncpy(key_out, w.GetKey().c_str(), 31);
+        key_out[31] = 0;
+    })
+}
+// file.NewReader(dir, key, min, max) drained with Next() into the target's result; *n_terms = 0 and rc 1 when the
+// segment has nothing in range (vellum.ErrIteratorDone)
+int ii2h_file_read(ii2h_target *t, ii2_ctx *ctx, const char *dir, const char *key, const uint8_t *mn, uint64_t mnl, int has_min,
+                   const uint8_t *mx, uint64_t mxl, int has_max, uint64_t *n_terms) {
+    try {
+        Term a((const char *)mn, has_min ? mnl : 0), b((const char *)mx, has_max ? mxl : 0);
+        t->result.clear();
+        *n_terms = 0;
+        Reader r(ctx, dir, key, has_min ? &a : nullptr, has_max ? &b : nullptr);
+        TermValues tv;
+        while (r.Next(&tv)) t->result.push_back(tv);
+        r.Close();
+        *n_terms = t->result.size();
+        return 0;
+    } catch (const Reader::NothingInRange &) {
+        return 1;
+    } catch (const std::exception &e) {
+        t->err = e.what();
+        return -1;
+    }
+}
+int ii2h_remove_segment(ii2h_target *t, const char *dir, const char *key) {
+    H_TRY(t, { file::remove_segment(dir, key); })
 }
 void ii2h_destroy(ii2h_target *t) { delete t; }
 const char *ii2h_last_error(const ii2h_target *t) { return t->err.c_str(); }
