@@ -45,6 +45,9 @@ def _lib_typed():
         lib.ii2h_file_write.argtypes = [vp, vp, C.c_char_p, C.c_int, vp, vp, C.c_uint64, vp, vp, C.c_char_p]
         lib.ii2h_file_read.argtypes = [vp, vp, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64, C.c_int, u64p]
         lib.ii2h_remove_segment.argtypes = [vp, C.c_char_p, C.c_char_p]
+        lib.ii2h_terms_read.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), u64p]
+        lib.ii2h_removed_write.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, vp]
+        lib.ii2h_removed_read.argtypes = [vp, C.c_char_p, u64p, u64p]
         lib.ii2h_destroy.argtypes = [vp]
         lib.ii2h_last_error.restype = C.c_char_p
         lib.ii2h_last_error.argtypes = [vp]
@@ -81,7 +84,7 @@ class _Target:
         self.ctx = ctx
         self.basedir = basedir
         if basedir is None:
-            self.h = self.lib.ii2h_create(ctx.h, 1 if is_index else 0)
+            self.h = self.lib.ii2h_create(ctx.h if ctx is not None else None, 1 if is_index else 0)
         else:               # NewShard(basedir) / NewInvertedIndex(basedir): what the directory holds is loaded
             err = C.create_string_buffer(512)
             self.h = self.lib.ii2h_open(ctx.h, 1 if is_index else 0, os.fsencode(basedir), err, len(err))
@@ -99,7 +102,7 @@ class _Target:
 
     def __del__(self):
         try:
-            if self.ctx.h:
+            if self.ctx is None or self.ctx.h:
                 self.close()
         except Exception:
             pass
@@ -206,8 +209,10 @@ class SegmentFiles(_Target):
             po[1:] = np.cumsum([len(v) for _, v in term_values])
         flat = np.ascontiguousarray([x for _, v in term_values for x in v] + [0], dtype=np.uint32)
         key = C.create_string_buffer(32)
-        self._ck(self.lib.ii2h_file_write(self.h, self.ctx.h, os.fsencode(directory), 1 if direct else 0, blob.ctypes.data, off.ctypes.data,
-                                          len(term_values), po.ctypes.data, flat.ctypes.data, key))
+        if self.ctx is None and not direct:
+            raise HostError("writer: the encode step needs a device context")
+        self._ck(self.lib.ii2h_file_write(self.h, self.ctx.h if self.ctx is not None else None, os.fsencode(directory), 1 if direct else 0,
+                                          blob.ctypes.data, off.ctypes.data, len(term_values), po.ctypes.data, flat.ctypes.data, key))
         return key.value.decode()
 
     def write_arrays(self, directory: str, term_blob: np.ndarray, term_off: np.ndarray, post_off: np.ndarray, values: np.ndarray) -> str:
@@ -239,3 +244,25 @@ class SegmentFiles(_Target):
 
     def remove(self, directory: str, key: str) -> None:
         self._ck(self.lib.ii2h_remove_segment(self.h, os.fsencode(directory), key.encode()))
+
+    # ---- the parts of the file layer that involve no device (usable with ctx = None) ----
+    def read_terms(self, directory: str, key: str):
+        """The term dictionary file alone: (direct, [(term, [value] if direct else [])])."""
+        n, direct = C.c_uint64(), C.c_int()
+        self._ck(self.lib.ii2h_terms_read(self.h, os.fsencode(directory), key.encode(), C.byref(direct), C.byref(n)))
+        return bool(direct.value), self._results(n.value)
+
+    def write_removed(self, directory: str, batches: Dict[int, List[int]]) -> None:
+        ts = np.ascontiguousarray(sorted(batches), dtype=np.int64)
+        off = np.zeros(ts.size + 1, np.uint64)
+        off[1:] = np.cumsum([len(batches[int(t)]) for t in ts])
+        vals = np.ascontiguousarray([v for t in ts for v in batches[int(t)]] + [0], dtype=np.uint32)
+        self._ck(self.lib.ii2h_removed_write(self.h, os.fsencode(directory), ts.size, ts.ctypes.data, off.ctypes.data, vals.ctypes.data))
+
+    def read_removed(self, directory: str) -> Tuple[int, List[int]]:
+        """(batches, RemovedLists.Values()) of the directory's removed.list; (0, []) when there is none."""
+        nb, n = C.c_uint64(), C.c_uint64()
+        self._ck(self.lib.ii2h_removed_read(self.h, os.fsencode(directory), C.byref(nb), C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self.lib.ii2h_ids_copy(self.h, out.ctypes.data)
+        return nb.value, out[: n.value].tolist()

@@ -763,6 +763,39 @@ int ii2h_file_read(ii2h_target *t, ii2_ctx *ctx, const char *dir, const char *ke
 int ii2h_remove_segment(ii2h_target *t, const char *dir, const char *key) {
     H_TRY(t, { file::remove_segment(dir, key); })
 }
+// the term dictionary file alone (no device involved): terms into the target's result, a direct segment's value as each
+// term's one-element list; *direct = the file's mode
+int ii2h_terms_read(ii2h_target *t, const char *dir, const char *key, int *direct, uint64_t *n_terms) {
+    H_TRY(t, {
+        file::TermFile tf = file::read_terms(dir, key);
+        t->result.clear();
+        for (size_t i = 0; i < tf.terms.size(); i++)
+            t->result.push_back(TermValues{tf.terms[i], tf.direct ? std::vector<uint32_t>{tf.direct_vals[i]} : std::vector<uint32_t>{}});
+        *direct = tf.direct ? 1 : 0;
+        *n_terms = t->result.size();
+    })
+}
+// removed.list alone: write batches (timestamp i, values vals[off[i] .. off[i+1])); read them back as RemovedLists.Values()
+int ii2h_removed_write(ii2h_target *t, const char *dir, uint64_t n, const int64_t *ts, const uint64_t *off, const uint32_t *vals) {
+    H_TRY(t, {
+        file::RemovedBatches b;
+        for (uint64_t i = 0; i < n; i++) b[ts[i]] = std::vector<uint32_t>(vals + off[i], vals + off[i + 1]);
+        file::write_removed(dir, b);
+    })
+}
+int ii2h_removed_read(ii2h_target *t, const char *dir, uint64_t *n_batches, uint64_t *n_ids) {
+    H_TRY(t, {
+        file::RemovedBatches b;
+        t->ids.clear();
+        *n_batches = 0;
+        if (file::read_removed(dir, &b)) {
+            *n_batches = b.size();
+            for (auto &kv : b) t->ids.insert(t->ids.end(), kv.second.begin(), kv.second.end());
+            std::sort(t->ids.begin(), t->ids.end());
+        }
+        *n_ids = t->ids.size();
+    })
+}
 void ii2h_destroy(ii2h_target *t) { delete t; }
 const char *ii2h_last_error(const ii2h_target *t) { return t->err.c_str(); }
 
