@@ -40,6 +40,8 @@ def _lib_typed():
     if not _typed:
         lib.ii2h_create.restype = vp
         lib.ii2h_create.argtypes = [vp, C.c_int]
+        lib.ii2h_attach.restype = vp
+        lib.ii2h_attach.argtypes = [vp]
         lib.ii2h_open.restype = vp
         lib.ii2h_open.argtypes = [vp, C.c_int, C.c_char_p, C.c_char_p, C.c_uint64]
         lib.ii2h_file_write.argtypes = [vp, vp, C.c_char_p, C.c_int, vp, vp, C.c_uint64, vp, vp, C.c_char_p]
@@ -94,6 +96,14 @@ class _Target:
     def _ck(self, rc: int) -> None:
         if rc:
             raise HostError((self.lib.ii2h_last_error(self.h) or b"").decode())
+
+    def session(self):
+        """Another handle on the same shard / index for use from another thread: the operations are thread-safe (like the
+        reference's goroutine-safe methods), a handle's result buffers are per handle."""
+        other = object.__new__(type(self))
+        other.lib, other.ctx, other.basedir = self.lib, self.ctx, self.basedir
+        other.h = self.lib.ii2h_attach(self.h)
+        return other
 
     def close(self) -> None:
         if self.h:

@@ -261,19 +261,24 @@ class Shard {
             try { file::write_terms(basedir_, key, tf); file::commit(file::tdx_path(basedir_, key)); }
             catch (const std::exception &e) { throw Error(std::string("index put: ") + e.what()); }
         }
+        std::lock_guard<std::mutex> g(mu_);
         add(std::move(seg));       // make the new segment visible (shard.go:64)
     }
 
     // shard.go:72-75 + makeIterator :253-278 — merged view of all segments, [min,max] inclusive, no tombstones
+    // The snapshot of shared pointers plays the part of the reference's per-segment read locks (segments.go:32-46):
+    // a merge may detach and unlink these segments meanwhile, their device arrays live until the last reader lets go.
     std::vector<TermValues> Read(const Term *min, const Term *max) const {
+        const std::vector<std::shared_ptr<Segment>> snap = snapshot();
         std::vector<const Segment *> segs;
-        for (auto &s : segments_) segs.push_back(s.get());
+        for (auto &s : snap) segs.push_back(s.get());
         return merged(segs, min, max, nullptr);
     }
 
     // shard.go:78-105
     void Remove(const std::vector<uint32_t> &values) {
         if (values.empty()) return;
+        std::lock_guard<std::mutex> g(mu_);
         std::vector<int64_t> ts{now_ns()};
         for (auto &s : segments_) ts.push_back(s->key);
         removed_sync(ts);
@@ -281,7 +286,7 @@ class Shard {
         WriteRemovedList();
     }
 
-    // shard.go:107-120
+    // shard.go:107-120 (called with mu_ held)
     void WriteRemovedList() const {
         if (basedir_.empty()) return;
         try { file::write_removed(basedir_, removed_); }
@@ -290,6 +295,7 @@ class Shard {
 
     // removed_list.go:44-54
     std::vector<uint32_t> RemovedValues() const {
+        std::lock_guard<std::mutex> g(mu_);
         std::vector<uint32_t> r;
         for (auto &kv : removed_) r.insert(r.end(), kv.second.begin(), kv.second.end());
         std::sort(r.begin(), r.end());
@@ -300,11 +306,14 @@ class Shard {
     // between contexts of one device, so InvertedIndex.Merge's workers each bring their own (inverted_index.go:83-103)
     int Merge(int reqCount, int mCount, ii2_ctx *worker = nullptr) {
         ii2_ctx *ctx = worker ? worker : ctx_;
-        if ((int)segments_.size() < reqCount) return 0;
         std::vector<std::shared_ptr<Segment>> picked;
-        for (auto &s : segments_) {
-            if ((int)picked.size() == mCount) break;
-            if (!s->merging) { s->merging = true; picked.push_back(s); }
+        {   // pick under the list lock; the `merging` flag keeps concurrent merges off the same segments (shard.go:134-146)
+            std::lock_guard<std::mutex> g(mu_);
+            if ((int)segments_.size() < reqCount) return 0;
+            for (auto &s : segments_) {
+                if ((int)picked.size() == mCount) break;
+                if (!s->merging) { s->merging = true; picked.push_back(s); }
+            }
         }
         if (picked.size() < 2) return 0;           // NB: a lone picked flag stays set (shard.go:149-151)
         std::vector<const Segment *> segs;
@@ -312,25 +321,26 @@ class Shard {
         const std::vector<uint32_t> removed = RemovedValues();
         Segment out;
         const bool any = merged_segment(ctx, segs, removed, &out);
-        if (any) {                                 // lazy writer: nothing survives -> no segment (shard.go:219-225)
-            if (!basedir_.empty()) {               // file.NewWriter + Close: both files, renamed when complete
-                const std::string key = std::to_string(out.key);
-                try {
-                    file::TermFile tf;
-                    tf.terms = out.terms;
-                    file::write_terms(basedir_, key, tf);
-                    file::write_dv1(basedir_, key, Writer::export_dv1(ctx, out.seg->h));
-                    file::commit(file::dv1_path(basedir_, key));
-                    file::commit(file::tdx_path(basedir_, key));
-                } catch (const std::exception &e) { throw Error(std::string("s: merge: writer close: ") + e.what()); }
-            }
-            add(std::move(out));
+        if (any && !basedir_.empty()) {            // file.NewWriter + Close: both files, renamed when complete
+            const std::string key = std::to_string(out.key);
+            try {
+                file::TermFile tf;
+                tf.terms = out.terms;
+                file::write_terms(basedir_, key, tf);
+                file::write_dv1(basedir_, key, Writer::export_dv1(ctx, out.seg->h));
+                file::commit(file::dv1_path(basedir_, key));
+                file::commit(file::tdx_path(basedir_, key));
+            } catch (const std::exception &e) { throw Error(std::string("s: merge: writer close: ") + e.what()); }
         }
-        segments_.erase(std::remove_if(segments_.begin(), segments_.end(),
-                                       [&](const std::shared_ptr<Segment> &s) {
-                                           return std::find(picked.begin(), picked.end(), s) != picked.end();
-                                       }),
-                        segments_.end());
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (any) add(std::move(out));          // lazy writer: nothing survives -> no segment (shard.go:219-225)
+            segments_.erase(std::remove_if(segments_.begin(), segments_.end(),
+                                           [&](const std::shared_ptr<Segment> &s) {
+                                               return std::find(picked.begin(), picked.end(), s) != picked.end();
+                                           }),
+                            segments_.end());      // Segments.detach: invisible for new reads (shard.go:228-230)
+        }
         if (!basedir_.empty()) {                   // file.RemoveSegment for every merged segment; the last error is reported (shard.go:232-242)
             std::string err;
             for (auto &sg : picked) {
@@ -344,6 +354,7 @@ class Shard {
 
     // shard.go:280-298
     bool MinMax(Term *mn, Term *mx) const {
+        std::lock_guard<std::mutex> g(mu_);
         bool any = false;
         for (auto &s : segments_) {
             if (s->terms.empty()) continue;
@@ -354,10 +365,12 @@ class Shard {
         return any;
     }
 
-    size_t SegmentCount() const { return segments_.size(); }
+    size_t SegmentCount() const { std::lock_guard<std::mutex> g(mu_); return segments_.size(); }
 
    private:
-    // segments.go:56-64 — insert before the first segment with terms >= new.terms
+    std::vector<std::shared_ptr<Segment>> snapshot() const { std::lock_guard<std::mutex> g(mu_); return segments_; }
+
+    // segments.go:56-64 — insert before the first segment with terms >= new.terms (mu_ held, or the constructor)
     void add(Segment s) {
         auto sp = std::make_shared<Segment>(std::move(s));
         size_t pos = 0;
@@ -520,6 +533,7 @@ class Shard {
 
     ii2_ctx *ctx_;
     std::string basedir_;                                  // empty: no files
+    mutable std::mutex mu_;                                // Segments.m and RemovedLists.m in one: guards the two members below
     std::vector<std::shared_ptr<Segment>> segments_;       // sorted by term count
     std::map<int64_t, std::vector<uint32_t>> removed_;     // RemovedLists.lists
 };
@@ -555,7 +569,7 @@ class InvertedIndex {
         for (auto &g : groups) shard(g.first).Put(g.second, val);
     }
     void PutRemoved(const std::vector<uint32_t> &values) {                    // inverted_index.go:41-55
-        for (auto &s : shards_) s.second->Remove(values);
+        for (auto &s : shard_list()) s.second->Remove(values);
     }
     // inverted_index.go:62-109: `concurrency` workers pull shards off one queue; every worker owns a context (a HIP
     // stream with its scratch) on the index's device, the segments are shared.  A worker that fails records the
@@ -563,13 +577,18 @@ class InvertedIndex {
     // starts no worker and merges nothing.
     int64_t Merge(int reqCount, int mCount, int concurrency) {
         std::vector<Shard *> shards;
-        for (auto &s : shards_) shards.push_back(s.second.get());
+        for (auto &s : shard_list()) shards.push_back(s.second);
         if (concurrency <= 0 || shards.empty()) return 0;
         const size_t nw = std::min<size_t>((size_t)concurrency, shards.size());
-        while (workers_.size() + 1 < nw) {                       // worker 0 uses the index's own context
-            ii2_ctx *c = nullptr;
-            if (ii2_ctx_create(ii2_ctx_device(ctx_), 0, &c)) throw Error(std::string("merge: worker context: ") + ii2_last_error(nullptr));
-            workers_.push_back(c);
+        std::vector<ii2_ctx *> workers;                          // worker 0 uses the index's own context
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            while (workers_.size() + 1 < nw) {
+                ii2_ctx *c = nullptr;
+                if (ii2_ctx_create(ii2_ctx_device(ctx_), 0, &c)) throw Error(std::string("merge: worker context: ") + ii2_last_error(nullptr));
+                workers_.push_back(c);
+            }
+            workers.assign(workers_.begin(), workers_.begin() + (nw - 1));
         }
         std::atomic<size_t> next{0};
         std::atomic<int64_t> merged{0};
@@ -584,7 +603,7 @@ class InvertedIndex {
             }
         };
         std::vector<std::thread> pool;
-        for (size_t w = 1; w < nw; w++) pool.emplace_back(work, workers_[w - 1]);
+        for (size_t w = 1; w < nw; w++) pool.emplace_back(work, workers[w - 1]);
         work(ctx_);
         for (auto &t : pool) t.join();
         if (!err.empty()) throw Error(err);
@@ -593,7 +612,7 @@ class InvertedIndex {
     ~InvertedIndex() { for (ii2_ctx *c : workers_) ii2_ctx_destroy(c); }
     std::vector<TermValues> Read(const Term *min, const Term *max) const {    // inverted_index.go:300-340
         std::vector<TermValues> out;
-        for (auto &s : shards_) {                                             // ascending shard key
+        for (auto &s : shard_list()) {                                        // ascending shard key
             Term mn, mx;
             if (!s.second->MinMax(&mn, &mx)) continue;
             if (min && term_less(mx, *min)) continue;
@@ -606,7 +625,7 @@ class InvertedIndex {
     std::map<Term, std::vector<uint32_t>> PrefixSearch(std::vector<Term> prefixes) const {   // inverted_index.go:192-295
         std::sort(prefixes.begin(), prefixes.end(), term_less);
         std::map<Term, std::vector<std::vector<uint32_t>>> found;
-        for (auto &s : shards_) {
+        for (auto &s : shard_list()) {
             Term mn, mx;
             if (!s.second->MinMax(&mn, &mx)) continue;
             std::vector<Term> mine;
@@ -635,18 +654,30 @@ class InvertedIndex {
         std::vector<std::vector<uint32_t>> lists;
         for (auto &t : terms) {
             std::vector<uint32_t> v;
-            auto it = shards_.find(shard_key(t));
-            if (it != shards_.end())
-                for (auto &tv : it->second->Read(&t, &t)) v = tv.values;
+            if (Shard *sh = find_shard(shard_key(t)))
+                for (auto &tv : sh->Read(&t, &t)) v = tv.values;
             lists.push_back(std::move(v));
         }
         return lists_op(false, lists);
     }
-    size_t ShardCount() const { return shards_.size(); }
-    Shard *OnlyShard() { return shards_.empty() ? nullptr : shards_.begin()->second.get(); }
+    size_t ShardCount() const { std::lock_guard<std::mutex> g(mu_); return shards_.size(); }
+    Shard *OnlyShard() { std::lock_guard<std::mutex> g(mu_); return shards_.empty() ? nullptr : shards_.begin()->second.get(); }
 
    private:
+    // shards are never removed: a snapshot of (key, pointer) pairs in key order is all a reader needs (ii.shardsM)
+    std::vector<std::pair<uint32_t, Shard *>> shard_list() const {
+        std::lock_guard<std::mutex> g(mu_);
+        std::vector<std::pair<uint32_t, Shard *>> v;
+        for (auto &s : shards_) v.emplace_back(s.first, s.second.get());
+        return v;
+    }
+    Shard *find_shard(uint32_t key) const {
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = shards_.find(key);
+        return it == shards_.end() ? nullptr : it->second.get();
+    }
     Shard &shard(uint32_t key) {
+        std::lock_guard<std::mutex> g(mu_);
         auto it = shards_.find(key);
         if (it == shards_.end()) {                 // inverted_index.go:163-190 newShard: mkdir <basedir>/<key>
             std::string dir;
@@ -679,6 +710,7 @@ class InvertedIndex {
     }
     ii2_ctx *ctx_;
     std::string basedir_;
+    mutable std::mutex mu_;                                // guards shards_ (the map, not the shards) and workers_
     std::vector<ii2_ctx *> workers_;                       // contexts of Merge's workers 1..n-1 (created on demand)
     std::map<uint32_t, std::unique_ptr<Shard>> shards_;    // sorted by key, like ii.shards
 };
@@ -689,8 +721,8 @@ class InvertedIndex {
 using namespace ii2h;
 
 struct ii2h_target {
-    std::unique_ptr<Shard> shard;
-    std::unique_ptr<InvertedIndex> index;
+    std::shared_ptr<Shard> shard;          // shared by every session attached to the same shard / index:
+    std::shared_ptr<InvertedIndex> index;  // the error text and the last results below are per session
     std::string err;
     std::vector<TermValues> result;     // last Read / PrefixSearch result
     std::vector<uint32_t> ids;          // last Intersect / RemovedValues result
@@ -710,16 +742,24 @@ extern "C" {
 
 ii2h_target *ii2h_create(ii2_ctx *ctx, int is_index) {
     auto *t = new ii2h_target();
-    if (is_index) t->index = std::make_unique<InvertedIndex>(ctx);
-    else t->shard = std::make_unique<Shard>(ctx);
+    if (is_index) t->index = std::make_shared<InvertedIndex>(ctx);
+    else t->shard = std::make_shared<Shard>(ctx);
+    return t;
+}
+// another handle on the same Shard / InvertedIndex with its own result and error slots: one per calling thread
+// (the operations themselves are thread-safe like the reference's; a handle's result buffers are not shared state)
+ii2h_target *ii2h_attach(const ii2h_target *owner) {
+    auto *t = new ii2h_target();
+    t->shard = owner->shard;
+    t->index = owner->index;
     return t;
 }
 // NewShard(basedir) / NewInvertedIndex(basedir): loads what the directory holds.  NULL + message in err[] on failure.
 ii2h_target *ii2h_open(ii2_ctx *ctx, int is_index, const char *basedir, char *err, uint64_t err_cap) {
     auto t = std::make_unique<ii2h_target>();
     try {
-        if (is_index) t->index = std::make_unique<InvertedIndex>(ctx, basedir);
-        else t->shard = std::make_unique<Shard>(ctx, basedir);
+        if (is_index) t->index = std::make_shared<InvertedIndex>(ctx, basedir);
+        else t->shard = std::make_shared<Shard>(ctx, basedir);
     } catch (const std::exception &e) {
         if (err && err_cap) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; }
         return nullptr;

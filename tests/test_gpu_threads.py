@@ -88,3 +88,96 @@ def test_host_mirror_merge_fans_out_over_workers(ctx):
         assert ii.merge(2, 8, 0) == 0                     # no workers: nothing merged (the reference starts none)
         ii.close()
     assert results[0] == results[1]
+
+
+# ---- the host mirror's own thread safety (segments.go:26-54 locks, shard.go:134-146 merging flags) ----------------
+def test_concurrent_access_on_one_shard(ctx, tmp_path):
+    # shard_test.go:216-248 TestConcurrentAccess: many threads run the same ingest / merge / compare sequence on ONE shard
+    import threading
+    from inverted_index_2_amd.host import Shard
+    shard = Shard(ctx, str(tmp_path))
+    want = [(b"term1", [1, 2]), (b"term2", [2]), (b"term3", [3])]
+    errors = []
+    begin = threading.Event()
+
+    def run(sess):
+        try:
+            begin.wait()
+            sess.put([b"term1"], 1)
+            sess.put([b"term1", b"term2"], 2)
+            sess.put([b"term3"], 3)
+            for _ in range(3):
+                sess.merge(2, 2)
+            got = sess.read()
+            assert got == want, got
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            sess.close()
+
+    threads = [threading.Thread(target=run, args=(shard.session(),)) for _ in range(16)]
+    for t in threads:
+        t.start()
+    begin.set()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    while shard.merge(2, 100):
+        pass
+    assert shard.read() == want
+    shard.close()
+    # what the directory holds after the storm is the same index
+    again = Shard(ctx, str(tmp_path))
+    assert again.read() == want
+    assert not [f for f in __import__("os").listdir(tmp_path) if f.endswith("_tmp")]
+    again.close()
+
+
+def test_concurrent_put_read_merge_on_an_index(ctx):
+    # inverted_index_test.go:84-138 TestConcurrent: writers and readers at once, merges until nothing is left to merge
+    import threading
+    from inverted_index_2_amd.host import InvertedIndex
+    ii = InvertedIndex(ctx)
+    rng = np.random.default_rng(9)
+    letters = list(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ")
+    plan = [[(sorted(bytes(rng.choice(letters, int(rng.integers(10, 20))).tolist()) for _ in range(3)), i) for _ in range(int(rng.integers(1, 12)))]
+            for i in range(12)]
+    errors = []
+
+    def writer(sess, puts):
+        try:
+            for terms, val in puts:
+                sess.put(list(terms), val)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            sess.close()
+
+    def reader(sess):
+        try:
+            for _ in range(3):
+                got = sess.read()
+                terms = [t for t, _ in got]                   # whatever moment the read caught: ascending terms, ascending unique ids
+                assert terms == sorted(set(terms)) and all(v == sorted(set(v)) and v for _, v in got)
+                sess.merge(2, 4, 2)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+        finally:
+            sess.close()
+
+    threads = [threading.Thread(target=writer, args=(ii.session(), p)) for p in plan] + [threading.Thread(target=reader, args=(ii.session(),)) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    while ii.merge(2, 100, 2):
+        pass
+    expect = {}
+    for puts in plan:
+        for terms, val in puts:
+            for t in terms:
+                expect.setdefault(t, set()).add(val)
+    got = dict(ii.read())
+    assert got == {t: sorted(v) for t, v in expect.items()}
+    ii.close()
