@@ -499,7 +499,31 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
             };
             // ---- D. gather the runs into vals[0] (coalesced inside every run) ----
             // MCAP = 8 * MT: eight postings per thread, all global loads issued before the first LDS write
-            {
+            if (bucketed) {
+                // single-term tile: every wave copies whole runs (run s to wave s mod MW), lane i of the wave the run's
+                // elements i, i + 64, ... — no search for the run an element belongs to, loads four deep
+                const uint32_t *RB = sm.runbase[0];
+                for (uint32_t s2 = (uint32_t)wv; s2 < k; s2 += MW) {
+                    const uint32_t base = RB[s2], len = RB[s2 + 1u] - base;
+                    const uint32_t *src = p.raw + sm.rs[s2];
+                    for (uint32_t i0 = 0; i0 < len; i0 += 256u) {
+                        uint32_t v4[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
+                            v4[j] = i < len ? src[i] : 0u;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
+                            if (i < len) {
+                                sm.vals[0][base + i] = v4[j];
+                                sm.tids[0][base + i] = (uint16_t)atomicAdd(&bkt[bucket_of(v4[j])], 1u);
+                            }
+                        }
+                    }
+                }
+            } else {
                 const uint32_t *RB = sm.runbase[0];
                 uint32_t gv[8], gsa[8], gi[8];
 #pragma unroll
@@ -520,7 +544,6 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                     if (e < n_in) {
                         const uint32_t v = gv[j];
                         sm.vals[0][e] = v;
-                        if (bucketed) sm.tids[0][e] = (uint16_t)atomicAdd(&bkt[bucket_of(v)], 1u);
                         if (nt > 1u) {
                             const uint32_t *O = sm.offs[0] + gsa[j] * stride;
                             const uint32_t i = gi[j];
