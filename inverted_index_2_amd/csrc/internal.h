@@ -31,6 +31,7 @@ struct ii2_ctx {
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
+    int64_t opt_merge_bitmap = 1;       // single-term tiles whose doc range fits the LDS bitmap are merged by marking bits
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
     size_t aux_cap = 0;
     uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
@@ -258,6 +259,7 @@ struct MergeParams {
     uint32_t *out_values;
     uint64_t out_cap;
     uint64_t *d_total;            // total survivors
+    uint32_t bitmap_tiles;        // 1: dense single-term tiles take the bitmap path
     unsigned long long *debug;    // optional diagnostics words
 };
 hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s);

@@ -480,11 +480,88 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
         };
 
         // ---- steps D-F on a loaded range: copy the runs into LDS, fold them, dedupe + tombstones + compact.
-        // Survivors land in sm.vals[*outbuf][0..return); per-term counts go to out_counts when asked.
+        // Survivors land in sm.vals[*outbuf][0..return) (*outbuf = 2: in the tag arrays); per-term counts go to out_counts when asked.
         auto merge_range = [&](uint32_t *outbuf, bool emit_counts, bool atomic_counts) -> uint32_t {
             const uint32_t n_in = sm.n_in;
             *outbuf = 0;
             if (n_in == 0) return 0u;
+            // Single-term tiles whose doc range fits a bitmap in the two value arrays (2 * MCAP words = 262144 docs: terms
+            // with >= 1 posting per 64 docs, a third of a Zipf workload's postings): mark, clear the tombstoned bits word
+            // by word (coalesced loads of exactly the tile's range — no per-posting probe), count, extract.  The union,
+            // the dedupe and the order come for free; ~5x fewer instructions per posting than the bucket fold below.
+            if (p.bitmap_tiles && nt == 1u && k > 1u && sm.vmax - (sm.vmin & ~31u) < 2u * MCAP * 32u) {
+                const uint32_t lo32 = sm.vmin & ~31u;
+                const uint32_t nw = ((sm.vmax - lo32) >> 5) + 1u;                 // <= 2 * MCAP
+                uint32_t *bm = &sm.vals[0][0];                                    // vals[0] and vals[1] are contiguous
+                for (uint32_t i = 4u * (uint32_t)tid; i < nw; i += 4u * MT) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+                {   // every wave marks whole runs (run s to wave s mod MW), loads four deep
+                    const uint32_t *RB = sm.runbase[0];
+                    for (uint32_t s2 = (uint32_t)wv; s2 < k; s2 += MW) {
+                        const uint32_t len = RB[s2 + 1u] - RB[s2];
+                        const uint32_t *src = p.raw + sm.rs[s2];
+                        for (uint32_t i0 = 0; i0 < len; i0 += 256u) {
+                            uint32_t v4[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
+                                v4[j] = i < len ? src[i] : 0u;
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
+                                if (i < len) atomicOr(&bm[(v4[j] - lo32) >> 5], 1u << (v4[j] & 31u));
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (p.tomb) {     // the tombstone words of exactly this range, coalesced and four in flight per thread
+                    const uint32_t twb = lo32 >> 5;
+                    for (uint32_t i0 = (uint32_t)tid; i0 < nw; i0 += 4u * MT) {
+                        uint32_t t4[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++) {
+                            const uint32_t i = i0 + j * MT;
+                            t4[j] = (i < nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++)
+                            if (t4[j]) bm[i0 + j * MT] &= ~t4[j];
+                    }
+                    __syncthreads();
+                }
+                II2_STAMP(3)      // D: gather (here: mark, tombstones)
+                // consecutive words per thread, as few as cover the range (a dense tile spans few words: one each).  Two
+                // passes over the thread's own words in LDS instead of sixteen registers: this kernel has none to spare.  The ids go to the tag arrays (4096 words, unused by this path): the
+                // bitmap occupies both value arrays.
+                const uint32_t wpt = (nw + MT - 1u) / MT;                         // 1 .. 16
+                const uint32_t w0 = wpt * (uint32_t)tid;
+                const uint32_t w1 = w0 + wpt < nw ? w0 + wpt : nw;
+                uint32_t cnt = 0;
+#pragma unroll 1
+                for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(bm[w]);
+                uint32_t tot;
+                uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
+                uint32_t *V2 = reinterpret_cast<uint32_t *>(&sm.tids[0][0]);
+#pragma unroll 1
+                for (uint32_t w = w0; w < w1; w++) {
+                    uint32_t x = bm[w];
+                    const uint32_t base = lo32 + 32u * w;
+                    while (x) {
+                        V2[pos++] = base + (uint32_t)__ffs((int)x) - 1u;
+                        x &= x - 1u;
+                    }
+                }
+                *outbuf = 2u;     // (the tag arrays)
+                if (emit_counts && tid == 0 && tot) {
+                    if (atomic_counts) atomicAdd(&p.out_counts[t0], tot);
+                    else p.out_counts[t0] = tot;
+                }
+                __syncthreads();
+                II2_STAMP(1)      // E1: single-term fold (here: tombstones, count, extract)
+                return tot;
+            }
             // Single-term tiles (the tiles of large terms — most of the postings) are folded by a bucket sort:
             // a monotone map of the doc id onto NBK buckets, slot inside the bucket from an LDS counter,
             // then every posting ranks itself among the few that share its bucket.  Docs clustered so that a
@@ -953,7 +1030,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                 // range tiles of a large term leave its count to k_merge_large_counts: an atomicAdd per tile would put
                 // thousands of same-address device atomics in flight (the top terms own most tiles)
                 total = merge_range(&outbuf, root_full, false);
-                const uint32_t *V = sm.vals[outbuf];
+                const uint32_t *V = outbuf == 2u ? reinterpret_cast<const uint32_t *>(&sm.tids[0][0]) : sm.vals[outbuf];
                 for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
             } else {
                 // the range holds more than LDS (a term whose lists are clustered differently): bisect the
@@ -978,7 +1055,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                     }
                     uint32_t ob2 = 0;
                     const uint32_t c = merge_range(&ob2, nt > 1u, true);       // single-term leaves: counted from the tile totals
-                    const uint32_t *V = sm.vals[ob2];
+                    const uint32_t *V = ob2 == 2u ? reinterpret_cast<const uint32_t *>(&sm.tids[0][0]) : sm.vals[ob2];
                     for (uint32_t q = (uint32_t)tid; q < c; q += MT) p.tmp[slot + total + q] = V[q];
                     total += c;
                 }

@@ -75,6 +75,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.batch_q = cap - p.small_max;
     p.wmin = (cap + nt_max - 1u) / nt_max;  // <= cap / wmin <= nt_max terms per batch
     if (p.wmin > p.small_max) p.wmin = p.small_max;
+    p.bitmap_tiles = ctx->opt_merge_bitmap ? 1u : 0u;
     p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : (cap / 4u) * 3u;   // exact counts: leave slack for uneven lists
     // upper bound of the tile count (the exact one is computed on the device and stays there): a large term has more than
     // small_max postings and takes ceil(u / large_tile) tiles; a batch ends when its weight passes batch_q or a large term

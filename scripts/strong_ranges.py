@@ -12,6 +12,9 @@ if kk: k = kk[0]
 only = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("only=")]      # only=<rank>: just that range (for rocprofv3)
 ctx = Context(0)
 ctx.set_option("profile.events", 1)
+for a in sys.argv[1:]:                                  # any other name=value is a library option
+    if "=" in a and not a.startswith(("k=", "only=")):
+        ctx.set_option(a.split("=")[0], int(a.split("=")[1]))
 for world in worlds:
     ranges = sharding.balanced_term_ranges(T, mean, D, world)
     times, posts = [], []

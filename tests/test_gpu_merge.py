@@ -216,3 +216,38 @@ def test_union_dense_high_ids_and_sparse_fallback(ctx):
     sparse = [sorted_unique(rng, 40_000, 1 << 31) for _ in range(3)]                       # far too sparse: merge path
     _check_union(ctx, sparse)
     _check_union(ctx, [a, sparse[0]])                                                       # dense run + ids spread over 2^31
+
+
+@pytest.mark.parametrize("k", [2, 16, 40])
+def test_dense_single_term_tiles_take_the_bitmap_path(ctx, k):
+    # terms dense enough for a tile's doc range to fit the LDS bitmap (>= 1 posting per ~64 docs), next to terms that
+    # are not; docs clustered so that ranges of one term differ in density; duplicates across segments; tombstones
+    # inside and outside the tiles' ranges; ids next to 2^32.  Both paths (option merge.bitmap_tiles) against the oracle.
+    rng = np.random.default_rng(100 + k)
+    U = 3_000_000
+    def docs(p, lo, hi):
+        return (np.flatnonzero(rng.random(hi - lo) < p) + lo).astype(np.uint32)
+    terms = [
+        docs(0.7, 0, 400_000),                                                          # very dense: few words per tile
+        np.concatenate([docs(0.05, 0, 1_000_000), docs(0.0005, 1_000_000, U)]),        # dense head, sparse tail (bucket fold)
+        docs(1 / 70, 0, U),                                                             # just inside the bitmap's reach
+        docs(1 / 400, 0, U),                                                            # outside it
+        docs(0.3, (1 << 32) - 200_000, (1 << 32) - 1).astype(np.uint32),               # dense, at the top of the id space
+        docs(0.2, 5_000, 5_500),                                                        # small term between the large ones
+    ]
+    T = len(terms)
+    where = [rng.integers(0, k, t.size) for t in terms]
+    dup = [rng.random(t.size) < 0.1 for t in terms]
+    where2 = [(w + 1 + rng.integers(0, k - 1, w.size)) % k for w in where]
+    offs, vals = [], []
+    for s in range(k):
+        lists = [np.unique(np.concatenate([t[w == s], t[d & (w2 == s)]])) for t, w, d, w2 in zip(terms, where, dup, where2)]
+        offs.append(np.concatenate([[0], np.cumsum([x.size for x in lists])]).astype(np.uint64))
+        vals.append(np.concatenate(lists).astype(np.uint32))
+    removed = np.concatenate([docs(0.02, 0, U), docs(0.05, (1 << 32) - 200_000, (1 << 32) - 1), np.array([0xFFFFFFFE], np.uint32)])
+    for on in (1, 0):
+        ctx.set_option("merge.bitmap_tiles", on)
+        _check_merge(ctx, offs, vals)
+        st = _check_merge(ctx, offs, vals, removed=removed)
+        assert st.n_tiles > T
+    ctx.set_option("merge.bitmap_tiles", 1)
