@@ -56,9 +56,10 @@ def concat_in_rank_order(parts: Sequence[np.ndarray]) -> np.ndarray:
 
 # Merge cost per posting by term size, relative to a giant term (measured range by range on one MI355X, round 2,
 # scripts/strong_ranges.py, 64 segments): terms above the tile size run through single-term tiles at the same rate
-# whatever their size; batches of small terms pay per list (block decode, slice tables, scans over T x k counts).
-_COST_LOG10_SIZE = np.array([2.2, 3.0, 3.8, 4.6])
-_COST_PER_POSTING = np.array([2.7, 2.0, 1.18, 1.0])
+# whatever their size, except the densest (a tile's doc range fits the LDS bitmap: ~0.75x); batches of small terms pay
+# per list (block decode, slice tables, scans over T x k counts).  Sizes are for the 100M-doc universe of the configs.
+_COST_LOG10_SIZE = np.array([2.2, 3.0, 3.8, 4.6, 6.0, 6.6])
+_COST_PER_POSTING = np.array([2.7, 2.0, 1.18, 1.0, 1.0, 0.75])
 
 
 def merge_cost_weights(sizes: np.ndarray) -> np.ndarray:
