@@ -31,6 +31,7 @@ constexpr uint32_t MT = MERGE_THREADS;            // threads per workgroup of th
 constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
 constexpr uint32_t NBK = 4096;                    // buckets of the single-term fold (8 per thread)
 constexpr uint32_t BKT_LIMIT = 24;                // fullest bucket the bucket fold accepts
+constexpr uint32_t BKT_LIMIT_MT = 14;             // ... for batches (the slot shares 16 bits with the 12-bit bucket)
 static_assert(NBK == 8u * MT && NBK + 4u <= 2u * OFFMAX, "bucket counters alias the list-offset table");
 
 // ---- pass 1: decode everything once --------------------------------------------------------
@@ -601,34 +602,60 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                     }
                 }
             } else {
+                // batches (and the odd single-run tile): the same wave-by-wave copy of whole runs; the (run, term) tag of
+                // every element comes from markers instead of a search per element — the first element of every
+                // non-empty list gets its tag, and since the tags ascend along the run-major order an inclusive
+                // max-scan over the positions fills in the rest
                 const uint32_t *RB = sm.runbase[0];
-                uint32_t gv[8], gsa[8], gi[8];
+                uint32_t *tg32 = reinterpret_cast<uint32_t *>(&sm.tids[0][0]);
+                for (uint32_t i = (uint32_t)tid; i < (n_in + 1u) / 2u; i += MT) tg32[i] = 0u;
+                __syncthreads();
+                for (uint32_t s2 = (uint32_t)wv; s2 < k; s2 += MW) {
+                    const uint32_t base = RB[s2], len = RB[s2 + 1u] - base;
+                    if (len == 0u) continue;                                   // (wave-uniform)
+                    if (nt > 1u) {
+                        const uint32_t *O = sm.offs[0] + s2 * stride;
+                        for (uint32_t t = (uint32_t)l; t < nt; t += 64u) {
+                            const uint32_t o0 = O[t], o1 = O[t + 1u];
+                            if (o1 > o0) sm.tids[0][base + o0] = (uint16_t)((s2 << 10) | t);
+                        }
+                    } else if (l == 0) sm.tids[0][base] = (uint16_t)(s2 << 10);
+                    const uint32_t *src = p.raw + sm.rs[s2];
+                    for (uint32_t i0 = 0; i0 < len; i0 += 256u) {
+                        uint32_t v4[4];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
-                    gv[j] = 0; gsa[j] = 0; gi[j] = 0;
-                    if (e < n_in) {
-                        uint32_t sa = 0, sb = k;              // last run with RB[s] <= e (it is not empty)
-                        while (sb - sa > 1u) { const uint32_t sm_ = (sa + sb) >> 1; if (RB[sm_] <= e) sa = sm_; else sb = sm_; }
-                        gsa[j] = sa;
-                        gi[j] = e - RB[sa];
-                        gv[j] = p.raw[sm.rs[sa] + gi[j]];
-                    }
-                }
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
+                            v4[j] = i < len ? src[i] : 0u;
+                        }
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
-                    if (e < n_in) {
-                        const uint32_t v = gv[j];
-                        sm.vals[0][e] = v;
-                        if (nt > 1u) {
-                            const uint32_t *O = sm.offs[0] + gsa[j] * stride;
-                            const uint32_t i = gi[j];
-                            uint32_t ta = 0, tb = nt;         // last term with O[t] <= i
-                            while (tb - ta > 1u) { const uint32_t tm = (ta + tb) >> 1; if (O[tm] <= i) ta = tm; else tb = tm; }
-                            sm.tids[0][e] = (uint16_t)((gsa[j] << 10) | ta);
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
+                            if (i < len) sm.vals[0][base + i] = v4[j];
                         }
                     }
+                }
+                __syncthreads();
+                {   // inclusive max-scan of the tags: eight consecutive positions per thread, then across the workgroup
+                    uint4 *tg4 = reinterpret_cast<uint4 *>(&sm.tids[0][0]);
+                    const uint4 q = tg4[tid];
+                    uint32_t g[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
+#pragma unroll
+                    for (int j = 1; j < 8; j++) g[j] = g[j] > g[j - 1] ? g[j] : g[j - 1];
+                    uint32_t m = g[7];                                         // inclusive max over the wave's threads up to mine
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = (uint32_t)__shfl_up((int)m, d, 64);
+                        if (l >= d) m = o > m ? o : m;
+                    }
+                    if (l == 63) sm.wmax[wv] = m;
+                    uint32_t before = (uint32_t)__shfl_up((int)m, 1, 64);      // exclusive: the threads before mine in the wave
+                    if (l == 0) before = 0u;
+                    __syncthreads();
+                    for (int w2 = 0; w2 < wv; w2++) before = sm.wmax[w2] > before ? sm.wmax[w2] : before;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) g[j] = g[j] > before ? g[j] : before;
+                    tg4[tid] = make_uint4(g[0] | (g[1] << 16), g[2] | (g[3] << 16), g[4] | (g[5] << 16), g[6] | (g[7] << 16));
                 }
             }
             __syncthreads();
@@ -739,8 +766,10 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t b = bucket_mt(t, sm.vals[0][e]);
                         const uint32_t sh = 16u * (b & 1u);
                         uint32_t slot = (atomicAdd(&c32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                        slot = slot < 63u ? slot : 63u;           // a fuller bucket sends the tile to the pairwise fold anyway
-                        sm.tids[0][e] = (uint16_t)((slot << 10) | t);
+                        slot = slot < 15u ? slot : 15u;           // a fuller bucket sends the tile to the pairwise fold anyway
+                        // from here on an element is known by its bucket (12 bits; the bucket implies the term): the
+                        // flagged fold below and step F need no term tag, so the bucket is computed once
+                        sm.tids[0][e] = (uint16_t)((slot << 12) | b);
                     }
                 }
                 __syncthreads();
@@ -759,7 +788,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                 uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
                 mxc = 0;
                 for (int w = 0; w < (int)MW; w++) mxc = sm.wmax[w] > mxc ? sm.wmax[w] : mxc;
-                if (mxc <= BKT_LIMIT) {
+                if (mxc <= BKT_LIMIT_MT) {
                     uint32_t ex[8];
 #pragma unroll
                     for (int j = 0; j < 8; j++) { ex[j] = run; run += c[j]; }
@@ -771,17 +800,16 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         if (e < n_in) {
                             const uint32_t v = sm.vals[0][e];
                             const uint32_t tag = sm.tids[0][e];
-                            const uint32_t dst = base_of(bucket_mt(tag & 1023u, v)) + (tag >> 10);
+                            const uint32_t dst = base_of(tag & 4095u) + (tag >> 12);
                             sm.vals[1][dst] = v;
-                            sm.tids[1][dst] = (uint16_t)(tag & 1023u);
+                            sm.tids[1][dst] = (uint16_t)(tag & 4095u);
                         }
                     }
                     __syncthreads();
 #pragma unroll 4
                     for (uint32_t q = (uint32_t)tid; q < n_in; q += MT) {
                         const uint32_t v = sm.vals[1][q];
-                        const uint32_t t = sm.tids[1][q];
-                        const uint32_t b = bucket_mt(t, v);
+                        const uint32_t b = sm.tids[1][q];
                         const uint32_t lo = base_of(b), hi = b + 1u < MCAP ? base_of(b + 1u) : n_in;
                         const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
                         uint32_t r = 0, dup = 0;
@@ -794,7 +822,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         sm.vals[0][lo + r] = v;
                         uint32_t dead = dup;
                         if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
-                        sm.tids[0][lo + r] = (uint16_t)(t | (dead << 15));   // bit 15: duplicate or tombstoned
+                        sm.tids[0][lo + r] = (uint16_t)(dead << 15);         // bit 15: duplicate or tombstoned
                     }
                     __syncthreads();
                     nruns = 1u;

@@ -13,7 +13,7 @@ only = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("only=")]    
 ctx = Context(0)
 ctx.set_option("profile.events", 1)
 for a in sys.argv[1:]:                                  # any other name=value is a library option
-    if "=" in a and not a.startswith(("k=", "only=")):
+    if "=" in a and not a.startswith(("k=", "only=", "stamps=")):
         ctx.set_option(a.split("=")[0], int(a.split("=")[1]))
 for world in worlds:
     ranges = sharding.balanced_term_ranges(T, mean, D, world)
@@ -32,6 +32,17 @@ for world in worlds:
         ctx.sync(); dt = (time.perf_counter() - t) / 3
         times.append(dt * 1e3); posts.append(n_in)
         print(f"world {world} range [{t0}, {t1}) terms {t1 - t0} postings {n_in} merge {dt*1e3:.2f} ms", flush=True)
+        if "stamps=1" in sys.argv:                          # cycle shares of the tile kernel's steps (see merge_probe.py)
+            import ctypes as C
+            ctx.set_option("debug.stamps", 1)
+            _, _, st = ctx.merge(segs, tomb, out_off, out_vals)
+            buf = (C.c_uint64 * (512 * 8))()
+            ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, 512 * 8))
+            arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
+            tot = arr.sum(axis=1).mean()
+            names = ["A ranges/table", "E1 single-term fold", "E2 batch fold", "D gather/mark", "E3 pairwise fold", "F filter/compact", "G park", "-"]
+            print("   tiles", st.n_tiles, " ".join(f"{nm}: {100 * arr[:, i].mean() / tot:.0f}%" for i, nm in enumerate(names[:7])), flush=True)
+            ctx.set_option("debug.stamps", 0)
         for s in segs: s.free()
         tomb.free(); out_off.free(); out_vals.free()
     print(f"world {world}: slowest range {max(times):.2f} ms, sum {sum(times):.2f} ms, postings {sum(posts)} -> "
