@@ -705,7 +705,21 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t lo = bkt[b], hi = bkt[b + 1u];
                         const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
                         uint32_t r = 0, dup = 0;
-                        for (uint32_t m = lo; m < hi; m++) {
+                        {   // the first four of the bucket without a loop (buckets hold one posting on average: lanes that
+                            // loop make the whole wave wait for the fullest bucket among its 64); reading past the bucket
+                            // is harmless (masked), past vals[1] lands in the tag arrays
+                            const uint32_t *B4 = &sm.vals[1][lo];
+                            const uint32_t u0 = B4[0], u1 = B4[1], u2 = B4[2], u3 = B4[3];
+                            const uint32_t nb = hi - lo;
+                            const uint32_t e0 = (u0 == v && lo < q) ? 1u : 0u;
+                            const uint32_t e1 = (nb > 1u && u1 == v && lo + 1u < q) ? 1u : 0u;
+                            const uint32_t e2 = (nb > 2u && u2 == v && lo + 2u < q) ? 1u : 0u;
+                            const uint32_t e3 = (nb > 3u && u3 == v && lo + 3u < q) ? 1u : 0u;
+                            r = (u0 < v ? 1u : 0u) + ((nb > 1u && u1 < v) ? 1u : 0u) + ((nb > 2u && u2 < v) ? 1u : 0u) + ((nb > 3u && u3 < v) ? 1u : 0u) +
+                                e0 + e1 + e2 + e3;
+                            dup = e0 | e1 | e2 | e3;
+                        }
+                        for (uint32_t m = lo + 4u; m < hi; m++) {
                             const uint32_t u = sm.vals[1][m];
                             const uint32_t eq = (u == v && m < q) ? 1u : 0u;
                             r += (u < v ? 1u : 0u) + eq;
@@ -813,7 +827,21 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
                         const uint32_t lo = base_of(b), hi = b + 1u < MCAP ? base_of(b + 1u) : n_in;
                         const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
                         uint32_t r = 0, dup = 0;
-                        for (uint32_t m = lo; m < hi; m++) {
+                        {   // the first four of the bucket without a loop (buckets hold one posting on average: lanes that
+                            // loop make the whole wave wait for the fullest bucket among its 64); reading past the bucket
+                            // is harmless (masked), past vals[1] lands in the tag arrays
+                            const uint32_t *B4 = &sm.vals[1][lo];
+                            const uint32_t u0 = B4[0], u1 = B4[1], u2 = B4[2], u3 = B4[3];
+                            const uint32_t nb = hi - lo;
+                            const uint32_t e0 = (u0 == v && lo < q) ? 1u : 0u;
+                            const uint32_t e1 = (nb > 1u && u1 == v && lo + 1u < q) ? 1u : 0u;
+                            const uint32_t e2 = (nb > 2u && u2 == v && lo + 2u < q) ? 1u : 0u;
+                            const uint32_t e3 = (nb > 3u && u3 == v && lo + 3u < q) ? 1u : 0u;
+                            r = (u0 < v ? 1u : 0u) + ((nb > 1u && u1 < v) ? 1u : 0u) + ((nb > 2u && u2 < v) ? 1u : 0u) + ((nb > 3u && u3 < v) ? 1u : 0u) +
+                                e0 + e1 + e2 + e3;
+                            dup = e0 | e1 | e2 | e3;
+                        }
+                        for (uint32_t m = lo + 4u; m < hi; m++) {
                             const uint32_t u = sm.vals[1][m];
                             const uint32_t eq = (u == v && m < q) ? 1u : 0u;
                             r += (u < v ? 1u : 0u) + eq;
