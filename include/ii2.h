@@ -222,13 +222,19 @@ int ii2_gatherv_offsets(const uint64_t *counts, int world, uint64_t cap, uint64_
 /* ---- diagnostics ------------------------------------------------------------------------ */
 /* Runs the device self-checks (wave scan, block decode against a scalar decode). 0 = pass. */
 int ii2_selftest(ii2_ctx *ctx);
-/* Tuning knobs, by name ("intersect.lookback", "merge.cap", …); unknown names are II2_EINVAL. */
+/* Tuning and diagnostic knobs, by name; unknown names are II2_EINVAL.  Path selection (1 = default on):
+ *   intersect.dense, intersect.dense_bpw   the wave-streaming kernel for dense queries / its driver blocks per wave
+ *   intersect.bitmap, intersect.g, intersect.wgs, intersect.map_docs   the general tile kernel's modes and sizes
+ *   union.stream, union.dense               unions through the streaming kernel / through the OR tiles
+ *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms / postings per tile of a large term
+ *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below
+ * Every combination returns the same results; the tests run the kernels with the alternatives switched on and off. */
 int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);
 /* With option "debug.stamps"=1 the intersect kernel sums, per workgroup, the shader cycles spent
  * in each part of its tile loop; this copies those counters (8 words per workgroup) out. */
 int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words);
-/* With option "profile.events"=N (N > 0) every Nth call brackets its pass (intersect: partition + tiles +
- * expand; merge: the tile kernel) with HIP events on the ctx stream — a timed event pair idles the stream
+/* With option "profile.events"=N (N > 0) every Nth call brackets its pass (intersect: every kernel of the
+ * query; merge: every kernel of the call) with HIP events on the ctx stream — a timed event pair idles the stream
  * for ~10 us, so sample (N = 8) when the calls themselves are being timed; this waits for the stream and
  * returns the summed device time and the number of bracketed launches since the previous read. */
 int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches);
