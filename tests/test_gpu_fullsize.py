@@ -47,6 +47,28 @@ def test_config5_scaled_eight_term_and(ctx):
     assert np.all(np.isin(core, out.download(n)))                       # the forced core survives
 
 
+def test_config5_full_size_on_one_gpu(ctx):
+    # configs[4] at its stated size on ONE GPU (the 8-GPU run shards the doc range; one card holds all of it): 1B docs,
+    # 833M postings in eight lists of 500M ... 71k, the longest lists' own intersection through the dense kernel
+    D = 1_000_000_000
+    rng = np.random.default_rng(55)
+    core = np.unique(rng.integers(0, D, 10_000)).astype(np.uint32)
+    lists = [np.union1d(synth.zipf_list(r, D), core).astype(np.uint32) for r in (2, 4, 16, 64, 256, 1024, 4096, 16384)]
+    assert lists[0].size > 499_000_000
+    seg = ctx.encode_lists(lists)
+    out = ctx.empty(lists[1].size + 512)
+    _, n = ctx.intersect([(seg, i) for i in range(8)], out=out)
+    want = orc.intersect(lists[::-1])                                   # shortest first: the oracle gallops too
+    assert n == want.size and np.array_equal(out.download(n), want)
+    assert np.all(np.isin(core, want))
+    _, n2 = ctx.intersect([(seg, 0), (seg, 1)], out=out)                # 500M AND 250M: 125M ids
+    got = out.download(n2)
+    assert np.all(np.diff(got.astype(np.int64)) > 0)
+    # every id of the result is in both lists, and the count is the lists' inclusion-exclusion count
+    assert n2 == np.intersect1d(lists[0], lists[1], assume_unique=True).size
+    assert int(got.astype(np.uint64).sum()) == int(np.intersect1d(lists[0], lists[1], assume_unique=True).astype(np.uint64).sum())
+
+
 def test_config3_scaled_merge_properties(ctx):
     # configs[2] family: 16-way merge, Zipf term sizes (mean 1000), 10 % duplicated postings, 1 % tombstones
     T, k = 40_000, 16
