@@ -9,7 +9,7 @@ import "unsafe"
 
 // This file is what the reference's `file` package needs to keep merged segments in the DV1
 // layout instead of intcomp runs: the values file <key>_val holds the three DV1 arrays of a
-// device segment (Export), and a reader hands them back to the device (ImportSegment) instead of
+// device segment (ExportSegment), and a reader hands them back to the device (ImportSegment) instead of
 // calling intcomp.UncompressUint32 per term (file/reader.go:79-100).  The FST side of the
 // package (term -> list index instead of term -> byte offset) stays Go.  The C++ host mirror
 // (inverted_index_2_amd/host/segment_file.h) shows the same lifecycle end to end on its own
@@ -31,8 +31,8 @@ type DV1 struct {
 	Payload   []byte
 }
 
-// Export copies a device segment's DV1 arrays out (what Writer.Close would put into <key>_val).
-func (c *Ctx) Export(s *Segment) (*DV1, error) {
+// ExportSegment copies a device segment's DV1 arrays out (what Writer.Close would put into <key>_val).
+func (c *Ctx) ExportSegment(s *Segment) (*DV1, error) {
 	var info C.ii2_seg_info
 	C.ii2_seg_get_info(s.h, &info)
 	d := &DV1{
