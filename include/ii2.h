@@ -226,6 +226,7 @@ int ii2_selftest(ii2_ctx *ctx);
  *   intersect.dense, intersect.dense_bpw   the wave-streaming kernel for dense queries / its driver blocks per wave
  *   intersect.bitmap, intersect.g, intersect.wgs, intersect.map_docs   the general tile kernel's modes and sizes
  *   union.stream, union.dense               unions through the streaming kernel / through the OR tiles
+ *   setop.small                             ANDs / ORs of <= 32 blocks in all as one single-workgroup kernel
  *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms / postings per tile of a large term
  *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below
  * Every combination returns the same results; the tests run the kernels with the alternatives switched on and off. */

@@ -164,6 +164,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (ctx->aux2) (void)hipFree(ctx->aux2);
     for (uint8_t *q : ctx->pool) if (q) (void)hipFree(q);
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     for (hipEvent_t e : ctx->region_ev) if (e) (void)hipEventDestroy(e);
@@ -511,6 +512,18 @@ int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg) {
     return II2_OK;
 }
 
+int ii2_seg_host_cnt(ii2_ctx *ctx, const ii2_seg *seg) {
+    std::lock_guard<std::mutex> sg(seg->span_mu);
+    if (seg->h_cnt.size() == seg->n_lists) return II2_OK;
+    std::vector<uint32_t> h(seg->n_lists);
+    if (seg->n_lists) {
+        HIP_TRY(ctx, hipMemcpyAsync(h.data(), seg->d_cnt, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    const_cast<ii2_seg *>(seg)->h_cnt.swap(h);
+    return II2_OK;
+}
+
 // a view over src's store whose four per-slot arrays were built on the device (align.hip); takes ownership of them
 int ii2_seg_adopt_view(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, uint32_t *d_blk_off, uint32_t *d_cnt, uint32_t *d_last_doc,
                        uint32_t *d_blk_list, ii2_seg **out) {
@@ -614,6 +627,61 @@ static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListVi
     return II2_OK;
 }
 
+// AND / OR of lists that hold <= SMALL_SET_BLOCKS blocks together: one single-workgroup kernel (setop_small.hip).
+// *taken = false when the query is too large (or the path is switched off).
+int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, const ListView *views, const ii2_seg *const *segs,
+                             const uint64_t *list_idx, const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count, bool *taken) {
+    *taken = false;
+    if (!ctx->opt_small_setop || n == 0 || n > MAX_LISTS) return II2_OK;
+    SmallSetParams sp;
+    std::memset(&sp, 0, sizeof sp);
+    uint32_t m = 0, nb = 0;
+    for (uint32_t i = 0; i < n; i++) {             // by blocks first: no size is fetched for a query that is too large anyway
+        if (views[i].nblk == 0 && !is_union) return II2_OK;      // (an AND with an empty list is answered by the caller)
+        if (views[i].nblk > SMALL_SET_BLOCKS - nb) return II2_OK;
+        nb += views[i].nblk;
+    }
+    nb = 0;
+    uint32_t np = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (views[i].nblk == 0) continue;
+        if (int rc = ii2_seg_host_cnt(ctx, segs[i])) return rc;
+        const uint32_t c = segs[i]->h_cnt[list_idx ? list_idx[i] : 0];
+        // an AND pays off below ~2k postings (the general path is four launches, ~14-20 us whatever the size); an OR up
+        // to the kernel's capacity (the merge passes are ~40 launches)
+        if (c > (is_union ? SMALL_SET_POSTINGS : SMALL_SET_POSTINGS / 4u) - np) return II2_OK;
+        sp.lists[m] = views[i];
+        sp.blk_base[m] = nb;
+        sp.lpre[m] = np;
+        nb += views[i].nblk;
+        np += c;
+        m++;
+    }
+    if (m == 0) return II2_OK;
+    sp.blk_base[m] = nb;
+    sp.lpre[m] = np;
+    sp.n_lists = m;
+    sp.n_blocks = nb;
+    sp.is_union = is_union ? 1u : 0u;
+    sp.tomb = tomb ? tomb->d_words : nullptr;
+    sp.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+    sp.out = d_out;
+    sp.out_cap = cap;
+    sp.d_count = d_count;
+    if (!ctx->d_small) {
+        const size_t bytes = ((size_t)SMALL_SET_POSTINGS + 16) * sizeof(uint32_t);
+        if (hipMalloc((void **)&ctx->d_small, bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "small set-operation scratch allocation failed");
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_small, 0, bytes, ctx->stream));
+    }
+    sp.sorted = ctx->d_small;
+    sp.ticket = ctx->d_small + (size_t)SMALL_SET_POSTINGS;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ii2_profile_pair(ctx, &e0, &e1);
+    HIP_TRY(ctx, launch_setop_small(sp, ctx->stream, e0, e1));
+    *taken = true;
+    return II2_OK;
+}
+
 // first doc, first doc of the last block and last doc of a non-empty list: fetched once per (segment, list), then cached
 static int list_span(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, const ListView &v, ii2_seg::ListSpan *out) {
     {
@@ -652,6 +720,11 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         return II2_OK;
     }
     if (!d_out) return fail(ctx, II2_EINVAL, "ii2_intersect: output buffer is NULL");
+    if (ctx->opt_intersect_g <= 0) {
+        bool taken = false;
+        if (int rc = ii2_setop_small_unlocked(ctx, false, n, views.data(), segs, list_idx, tomb, d_out, cap, d_count, &taken)) return rc;
+        if (taken) return II2_OK;
+    }
     std::vector<uint32_t> order(n);
     for (uint32_t i = 0; i < n; i++) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return views[a].nblk < views[b].nblk; });
@@ -805,7 +878,12 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
         p.lists[m++] = v;
         total_blocks += v.nblk;
     }
-    if (m == 0 || total_blocks < 64) return II2_OK;
+    if (m == 0) return II2_OK;
+    if (total_blocks <= SMALL_SET_BLOCKS) {
+        if (int rc = ii2_setop_small_unlocked(ctx, true, m, p.lists, nz_seg, nz_idx, tomb, d_out, cap, d_count, taken)) return rc;
+        if (*taken) return II2_OK;
+    }
+    if (total_blocks < 64) return II2_OK;
     p.n_lists = m;
     // Few long lists, the longest one dense: the streaming kernel of the dense intersection with OR semantics — every
     // wave walks its own run of blocks of the longest list (the pacer), the other lists mark into the same bitmap
@@ -975,6 +1053,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
     else if (k == "union.dense") ctx->opt_union_dense = value;
     else if (k == "union.stream") ctx->opt_union_stream = value;
+    else if (k == "setop.small") ctx->opt_small_setop = value;
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;

@@ -41,6 +41,7 @@ struct ii2_ctx {
     size_t pool_cap[4] = {0, 0, 0, 0};
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
+    int64_t opt_small_setop = 1;        // queries of <= 32 blocks in all run as one single-workgroup kernel
     int64_t opt_union_stream = 1;       // ... and, for 2-4 lists paced by a long dense one, through the streaming kernel
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
@@ -52,6 +53,7 @@ struct ii2_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;     // reusable pairs
     hipEvent_t region_ev[2] = {nullptr, nullptr};                 // ii2_profile_region: one pair around a whole run of calls
     unsigned long long *d_debug = nullptr;
+    uint32_t *d_small = nullptr;        // small set operations: ascending ids [8192] + the workgroup ticket (setop_small.hip)
     void *comm = nullptr;               // ncclComm_t
     int world = 1, rank = 0;
     int cu_count = 256;
@@ -80,6 +82,7 @@ struct ii2_seg {
     uint32_t *d_cnt = nullptr;       // [n_lists] postings of each list
     uint32_t *d_blk_list = nullptr;  // [n_blocks] list owning each block (0xFFFFFFFF: none of this view's lists)
     std::vector<uint32_t> h_blk_off; // host mirror of d_blk_off
+    std::vector<uint32_t> h_cnt;     // host mirror of d_cnt (fetched when a small query first needs it)
     // per list: first_doc of its first and of its last block and its last doc (tile-height heuristic), fetched once
     struct ListSpan { uint32_t first_doc, last_block_first_doc, last_doc; };
     mutable std::mutex span_mu;             // contexts on different threads share the cache
@@ -95,6 +98,7 @@ struct ii2_tomb {
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
 void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes);      // grow-only ctx buffer `slot`, at least `bytes` (nullptr: out of memory); ctx->mu held
+int ii2_seg_host_cnt(ii2_ctx *ctx, const ii2_seg *seg);       // fills seg->h_cnt on first use (thread-safe)
 int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg);   // fills seg->h_blk_off on first use (thread-safe)
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);   // false when profiling is off
 // union through the intersection tiles (OR); *taken = false when the lists are too sparse for it (caller merges instead)
@@ -154,6 +158,26 @@ struct IntersectParams {
     uint32_t op_union;           // 1: OR instead of AND — fixed doc-range tiles [u_base + t * u_span, ...], every list searched per tile
     uint32_t u_base, u_span, u_max;
 };
+
+// small AND / OR in one workgroup (setop_small.hip)
+constexpr uint32_t SMALL_SET_POSTINGS = 8192;  // postings the lists may hold together ...
+constexpr uint32_t SMALL_SET_BLOCKS = 128;     // ... in at most this many DV1 blocks
+struct SmallSetParams {
+    ListView lists[MAX_LISTS];   // non-empty lists, any order
+    uint32_t blk_base[MAX_LISTS + 1];   // first block of each list in the concatenated block list
+    uint32_t lpre[MAX_LISTS + 1];       // exclusive prefix of the lists' posting counts; lpre[n_lists] <= SMALL_SET_POSTINGS
+    uint32_t n_lists;
+    uint32_t n_blocks;           // <= SMALL_SET_BLOCKS
+    uint32_t is_union;
+    uint32_t tomb_nwords;
+    const uint32_t *tomb;        // may be null
+    uint32_t *out;
+    uint64_t out_cap;
+    uint64_t *d_count;
+    uint32_t *sorted;            // [SMALL_SET_POSTINGS] scratch: every id at its rank
+    uint32_t *ticket;            // zero between launches (the last workgroup resets it)
+};
+hipError_t launch_setop_small(const SmallSetParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // dense streaming intersection (intersect_dense.hip)
 constexpr uint32_t DENSE_MAXL = 4;             // lists it takes
