@@ -629,7 +629,7 @@ static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListVi
 
 // AND / OR of lists that hold <= SMALL_SET_BLOCKS blocks together: one single-workgroup kernel (setop_small.hip).
 // *taken = false when the query is too large (or the path is switched off).
-int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, const ListView *views, const ii2_seg *const *segs,
+static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, const ListView *views, const ii2_seg *const *segs,
                              const uint64_t *list_idx, const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count, bool *taken) {
     *taken = false;
     if (!ctx->opt_small_setop || n == 0 || n > MAX_LISTS) return II2_OK;
