@@ -627,6 +627,17 @@ static int make_list_view(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, ListVi
     return II2_OK;
 }
 
+// device-side address of a word of the pinned host mailbox (hipHostMalloc memory is mapped), or null if the runtime
+// does not give one
+uint64_t *ii2_mapped_mail(ii2_ctx *ctx, uint32_t word) {
+    if (!ctx->d_mail_mapped) {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, ctx->h_mail, 0) != hipSuccess || !dp) { (void)hipGetLastError(); return nullptr; }
+        ctx->d_mail_mapped = (uint64_t *)dp;
+    }
+    return ctx->d_mail_mapped + word;
+}
+
 // AND / OR of lists that hold <= SMALL_SET_BLOCKS blocks together: one single-workgroup kernel (setop_small.hip).
 // *taken = false when the query is too large (or the path is switched off).
 static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, const ListView *views, const ii2_seg *const *segs,
@@ -1000,11 +1011,14 @@ int ii2_intersect(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const ui
     if (!ctx || !count) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = intersect_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, ctx->d_mail);
+    // the count lands in the pinned host mailbox directly (the kernels write it once, at their end): one stream
+    // synchronisation, no copy behind it
+    uint64_t *d_cnt = ii2_mapped_mail(ctx, II2_MAIL_COUNT);
+    int rc = intersect_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, d_cnt ? d_cnt : ctx->d_mail);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (!d_cnt) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + II2_MAIL_COUNT, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    *count = ctx->h_mail[0];
+    *count = ctx->h_mail[II2_MAIL_COUNT];
     if (*count > cap) return fail(ctx, II2_ECAPACITY, "ii2_intersect: result does not fit the output buffer (content unspecified)");
     return II2_OK;
 }

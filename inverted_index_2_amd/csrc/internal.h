@@ -13,6 +13,7 @@
 
 // mailbox layout (u64 words; h_mail and d_mail both hold II2_MAIL_WORDS)
 constexpr size_t II2_MAIL_WORDS = 512;
+constexpr size_t II2_MAIL_COUNT = 200;     // word of h_mail that receives the result count of ii2_intersect / ii2_union
 constexpr size_t II2_MAIL_COMM = 256;      // all-gatherv: {count, cap} of this rank, then of every rank (2 + 2 * II2_MAX_RANKS words)
 
 struct ii2_ctx {
@@ -53,6 +54,7 @@ struct ii2_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;     // reusable pairs
     hipEvent_t region_ev[2] = {nullptr, nullptr};                 // ii2_profile_region: one pair around a whole run of calls
     unsigned long long *d_debug = nullptr;
+    uint64_t *d_mail_mapped = nullptr;  // h_mail as the device sees it (result counts of the synchronous calls go there directly)
     uint32_t *d_small = nullptr;        // small set operations: ascending ids [8192] + the workgroup ticket (setop_small.hip)
     void *comm = nullptr;               // ncclComm_t
     int world = 1, rank = 0;
@@ -98,6 +100,7 @@ struct ii2_tomb {
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
 void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes);      // grow-only ctx buffer `slot`, at least `bytes` (nullptr: out of memory); ctx->mu held
+uint64_t *ii2_mapped_mail(ii2_ctx *ctx, uint32_t word);
 int ii2_seg_host_cnt(ii2_ctx *ctx, const ii2_seg *seg);       // fills seg->h_cnt on first use (thread-safe)
 int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg);   // fills seg->h_blk_off on first use (thread-safe)
 bool ii2_profile_pair(ii2_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);   // false when profiling is off

@@ -294,12 +294,13 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
     if (!d_out) return fail(ctx, II2_EINVAL, "ii2_union: output buffer is NULL");
     {   // lists dense together: OR over byte-map tiles instead of the merge passes
         bool taken = false;
-        int rc = ii2_union_dense_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, ctx->d_mail, &taken);
+        uint64_t *d_cnt = ii2_mapped_mail(ctx, II2_MAIL_COUNT);      // the count goes straight into the pinned host mailbox
+        int rc = ii2_union_dense_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, d_cnt ? d_cnt : ctx->d_mail, &taken);
         if (rc) return rc;
         if (taken) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+            if (!d_cnt) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + II2_MAIL_COUNT, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            *count = ctx->h_mail[0];
+            *count = ctx->h_mail[II2_MAIL_COUNT];
             if (*count > cap) return fail(ctx, II2_ECAPACITY, "ii2_union: result does not fit the output buffer (content unspecified)");
             return II2_OK;
         }
