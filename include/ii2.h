@@ -225,7 +225,8 @@ int ii2_selftest(ii2_ctx *ctx);
 /* Tuning and diagnostic knobs, by name; unknown names are II2_EINVAL.  Path selection (1 = default on):
  *   intersect.dense, intersect.dense_bpw   the wave-streaming kernel for dense queries / its driver blocks per wave
  *   intersect.bitmap, intersect.g, intersect.wgs, intersect.map_docs   the general tile kernel's modes and sizes
- *   union.stream, union.dense               unions through the streaming kernel / through the OR tiles
+ *   union.stream, union.dense, union.sparsity   unions through the streaming kernel / through the OR tiles (the latter up
+ *                                           to `sparsity` docs of the lists' common range per posting, default 2048)
  *   setop.small                             ANDs / ORs of <= 32 blocks in all as one single-workgroup kernel
  *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms / postings per tile of a large term
  *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below

@@ -960,7 +960,7 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
     constexpr uint32_t S = ISECT_SMAX - 64u;               // tile span: a multiple of 32 below the byte-map size
     const uint32_t base = mm[0] & ~31u;
     const uint64_t span = (uint64_t)mm[1] - base + 1;
-    if (total_blocks * II2_DV1_BLOCK * 16u < span) return II2_OK;       // too sparse: the merge passes do better
+    if (total_blocks * II2_DV1_BLOCK * (uint64_t)ctx->opt_union_sparsity < span) return II2_OK;       // too sparse (the tile count grows with the span): the merge passes do better
     const uint64_t n_tiles = (span + S - 1) / S;
     if (n_tiles >= (1ull << 24)) return II2_OK;
     p.op_union = 1u;
@@ -1068,6 +1068,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "union.dense") ctx->opt_union_dense = value;
     else if (k == "union.stream") ctx->opt_union_stream = value;
     else if (k == "setop.small") ctx->opt_small_setop = value;
+    else if (k == "union.sparsity") ctx->opt_union_sparsity = value > 0 ? value : 2048;
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;

@@ -42,6 +42,7 @@ struct ii2_ctx {
     size_t pool_cap[4] = {0, 0, 0, 0};
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
+    int64_t opt_union_sparsity = 2048;   // OR tiles are used up to this many docs of the common range per posting
     int64_t opt_small_setop = 1;        // queries of <= 32 blocks in all run as one single-workgroup kernel
     int64_t opt_union_stream = 1;       // ... and, for 2-4 lists paced by a long dense one, through the streaming kernel
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
