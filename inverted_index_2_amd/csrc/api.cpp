@@ -951,11 +951,14 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
             }
         }
     }
-    uint32_t *d_mm = (uint32_t *)(ctx->d_mail + 80);
-    uint32_t mm[2] = {0, 0};
-    HIP_TRY(ctx, launch_union_range(p, d_mm, st));
-    HIP_TRY(ctx, hipMemcpyAsync(mm, d_mm, sizeof mm, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // the lists' common doc range from their cached ends (one round trip per list the first time it is used, none after)
+    uint32_t mm[2] = {0xFFFFFFFFu, 0u};
+    for (uint32_t i = 0; i < m; i++) {
+        ii2_seg::ListSpan sp;
+        if (int rc = list_span(ctx, nz_seg[i], nz_idx[i], p.lists[i], &sp)) return rc;
+        mm[0] = std::min(mm[0], sp.first_doc);
+        mm[1] = std::max(mm[1], sp.last_doc);
+    }
     if (mm[1] < mm[0]) return II2_OK;
     constexpr uint32_t S = ISECT_SMAX - 64u;               // tile span: a multiple of 32 below the byte-map size
     const uint32_t base = mm[0] & ~31u;

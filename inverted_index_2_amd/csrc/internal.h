@@ -242,7 +242,6 @@ hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStrea
 // intersect
 constexpr uint32_t ISECT_GMAX = 16;         // driver blocks per tile (max)
 constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
-hipError_t launch_union_range(const IntersectParams &p, uint32_t *d_minmax, hipStream_t s);
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // merge / union

@@ -800,23 +800,6 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
 #undef II2_STAMP
 }
 
-// smallest first doc / largest last doc of the lists of a union (one thread per list)
-__global__ void k_union_range(IntersectParams p, uint32_t *__restrict__ minmax) {
-    const uint32_t j = threadIdx.x;
-    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    if (j < p.n_lists) { mn = p.lists[j].skip[0].first_doc; mx = *p.lists[j].last_doc; }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t on = (uint32_t)__shfl_xor((int)mn, d, 64), ox = (uint32_t)__shfl_xor((int)mx, d, 64);
-        mn = on < mn ? on : mn;
-        mx = ox > mx ? ox : mx;
-    }
-    if (j == 0) { minmax[0] = mn; minmax[1] = mx; }
-}
-hipError_t launch_union_range(const IntersectParams &p, uint32_t *d_minmax, hipStream_t s) {
-    hipLaunchKernelGGL(k_union_range, dim3(1), dim3(64), 0, s, p, d_minmax);
-    return hipGetLastError();
-}
-
 // ---- per-64-tile sums of the tile counts (expand reads them to place its tiles) ------------
 // A kernel of its own: an atomicAdd per tile from the tile kernel put 64 same-address device atomics in flight
 // per sum at once, and every workgroup then waited for its own at its next s_waitcnt — ~20 us per pass.
