@@ -227,7 +227,7 @@ int ii2_selftest(ii2_ctx *ctx);
  *   intersect.bitmap, intersect.g, intersect.wgs, intersect.map_docs   the general tile kernel's modes and sizes
  *   union.stream, union.dense, union.sparsity   unions through the streaming kernel / through the OR tiles (the latter up
  *                                           to `sparsity` docs of the lists' common range per posting, default 2048)
- *   setop.small                             ANDs / ORs of <= 32 blocks in all as one single-workgroup kernel
+ *   setop.small, union.rank                 short-list ANDs / ORs in one launch; ORs of a few medium lists by ranking
  *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms / postings per tile of a large term
  *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below
  * Every combination returns the same results; the tests run the kernels with the alternatives switched on and off. */

@@ -894,6 +894,43 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
         if (int rc = ii2_setop_small_unlocked(ctx, true, m, p.lists, nz_seg, nz_idx, tomb, d_out, cap, d_count, taken)) return rc;
         if (*taken) return II2_OK;
     }
+    // a few lists of medium size: decode, rank every id by bisection in the other lists, filter, write (union_rank.hip)
+    if (ctx->opt_union_rank && m <= UNION_RANK_MAXL && total_blocks <= UNION_RANK_MAX_POSTINGS / II2_DV1_BLOCK + m) {
+        UnionRankParams up;
+        std::memset(&up, 0, sizeof up);
+        uint64_t np = 0;
+        uint32_t nb = 0;
+        for (uint32_t i = 0; i < m; i++) {
+            if (int rc = ii2_seg_host_cnt(ctx, nz_seg[i])) return rc;
+            up.lists[i] = p.lists[i];
+            up.blk_base[i] = nb;
+            up.lpre[i] = (uint32_t)np;
+            nb += p.lists[i].nblk;
+            np += nz_seg[i]->h_cnt[nz_idx[i]];
+        }
+        if (np <= UNION_RANK_MAX_POSTINGS) {
+            up.blk_base[m] = nb;
+            up.lpre[m] = (uint32_t)np;
+            up.n_lists = m;
+            up.n_blocks = nb;
+            const uint32_t nwg = (uint32_t)((np + 2047) / 2048);
+            const size_t need = 2 * align_up(np * sizeof(uint32_t)) + align_up(((size_t)nwg + 1) * sizeof(uint32_t)) + 4096;
+            if (int rc = ii2_ws_reserve(ctx, need)) return rc;
+            up.raw = ws_take<uint32_t>(ctx, np);
+            up.sorted = ws_take<uint32_t>(ctx, np);
+            up.wg_cnt = ws_take<uint32_t>(ctx, (size_t)nwg + 1);
+            up.tomb = tomb ? tomb->d_words : nullptr;
+            up.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
+            up.out = d_out;
+            up.out_cap = cap;
+            up.d_count = d_count;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            ii2_profile_pair(ctx, &e0, &e1);
+            HIP_TRY(ctx, launch_union_rank(up, st, e0, e1));
+            *taken = true;
+            return II2_OK;
+        }
+    }
     if (total_blocks < 64) return II2_OK;
     p.n_lists = m;
     // Few long lists, the longest one dense: the streaming kernel of the dense intersection with OR semantics — every
@@ -1071,6 +1108,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "union.dense") ctx->opt_union_dense = value;
     else if (k == "union.stream") ctx->opt_union_stream = value;
     else if (k == "setop.small") ctx->opt_small_setop = value;
+    else if (k == "union.rank") ctx->opt_union_rank = value;
     else if (k == "union.sparsity") ctx->opt_union_sparsity = value > 0 ? value : 2048;
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;

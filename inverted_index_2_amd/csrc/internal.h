@@ -42,6 +42,7 @@ struct ii2_ctx {
     size_t pool_cap[4] = {0, 0, 0, 0};
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
+    int64_t opt_union_rank = 1;         // unions of <= 8 lists / 2^20 postings by ranking (union_rank.hip)
     int64_t opt_union_sparsity = 2048;   // OR tiles are used up to this many docs of the common range per posting
     int64_t opt_small_setop = 1;        // queries of <= 32 blocks in all run as one single-workgroup kernel
     int64_t opt_union_stream = 1;       // ... and, for 2-4 lists paced by a long dense one, through the streaming kernel
@@ -182,6 +183,26 @@ struct SmallSetParams {
     uint32_t *ticket;            // zero between launches (the last workgroup resets it)
 };
 hipError_t launch_setop_small(const SmallSetParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
+// OR of a few medium-size lists by ranking (union_rank.hip)
+constexpr uint32_t UNION_RANK_MAXL = 8;
+constexpr uint32_t UNION_RANK_MAX_POSTINGS = 1u << 20;
+struct UnionRankParams {
+    ListView lists[UNION_RANK_MAXL];
+    uint32_t blk_base[UNION_RANK_MAXL + 1];   // first block of each list in the concatenated block list
+    uint32_t lpre[UNION_RANK_MAXL + 1];       // exclusive prefix of the lists' posting counts
+    uint32_t n_lists;
+    uint32_t n_blocks;
+    uint32_t tomb_nwords;
+    const uint32_t *tomb;        // may be null
+    uint32_t *raw;               // [n_total] the lists decoded back to back
+    uint32_t *sorted;            // [n_total] every id at its rank
+    uint32_t *wg_cnt;            // survivors per 2048 ids
+    uint32_t *out;
+    uint64_t out_cap;
+    uint64_t *d_count;
+};
+hipError_t launch_union_rank(const UnionRankParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // dense streaming intersection (intersect_dense.hip)
 constexpr uint32_t DENSE_MAXL = 4;             // lists it takes

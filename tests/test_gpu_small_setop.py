@@ -86,3 +86,51 @@ def test_block_boundaries_and_capacity(ctx):
     small = ctx.empty(10)
     with pytest.raises(II2Error):                                                # union larger than the output buffer
         ctx.union([(seg, 0), (seg, 1)], out=small)
+
+
+# ---- unions of a few medium-size lists by ranking (csrc/union_rank.hip) ----
+@pytest.mark.parametrize("seed", range(5))
+def test_union_by_ranking(ctx, seed):
+    rng = np.random.default_rng(900 + seed)
+    for _ in range(4):
+        k = int(rng.integers(1, 9))
+        universe = int(rng.choice([20_000, 3_000_000, (1 << 32) - 1]))
+        lists = []
+        for _ in range(k):
+            n = int(rng.choice([1, 300, 9_000, 60_000, 250_000]))
+            l = np.unique(rng.integers(0, universe, min(n, universe), dtype=np.uint64)).astype(np.uint32)
+            if rng.random() < 0.3 and lists:                                   # heavy overlap with an earlier list
+                l = np.union1d(l, lists[0][::3]).astype(np.uint32)
+            lists.append(l)
+        if rng.random() < 0.3:
+            lists.append(lists[0].copy())                                      # the same ids twice
+        lists = lists[:8]
+        removed = np.unique(rng.integers(0, universe, 3000, dtype=np.uint64)).astype(np.uint32) if rng.random() < 0.5 else None
+        want = np.unique(np.concatenate(lists))
+        if removed is not None:
+            want = np.setdiff1d(want, removed, assume_unique=True)
+        tomb = ctx.tombstones(removed) if removed is not None else None
+        seg = ctx.encode_lists(lists)
+        ls = [(seg, i) for i in range(len(lists))]
+        out = ctx.empty(sum(l.size for l in lists) + 8)
+        for rank in (1, 0):
+            ctx.set_option("union.rank", rank)
+            _, n = ctx.union(ls, tomb=tomb, out=out)
+            assert n == want.size and np.array_equal(out.download(n), want.astype(np.uint32)), rank
+        ctx.set_option("union.rank", 1)
+        seg.free()
+        out.free()
+
+
+def test_union_by_ranking_limits(ctx):
+    from inverted_index_2_amd import II2Error
+    a = np.arange(0, 600_000, dtype=np.uint32) * 3
+    b = np.arange(0, 448_576, dtype=np.uint32) * 5                               # 1,048,576 postings in all: the limit
+    c = np.array([7], np.uint32)
+    for lists in ([a, b], [a, b, c]):                                            # ... and one more: the other paths
+        seg = ctx.encode_lists(lists)
+        out, n = ctx.union([(seg, i) for i in range(len(lists))])
+        assert np.array_equal(out.download(n), np.unique(np.concatenate(lists)))
+    seg = ctx.encode_lists([a[:50_000], b[:50_000]])
+    with pytest.raises(II2Error):
+        ctx.union([(seg, 0), (seg, 1)], out=ctx.empty(1000))
