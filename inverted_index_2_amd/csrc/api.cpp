@@ -161,7 +161,8 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     ii2_comm_destroy_internal(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->aux) (void)hipFree(ctx->aux);
-    if (ctx->aux2) (void)hipFree(ctx->aux2);
+    if (ctx->h_segs) (void)hipHostFree(ctx->h_segs);
+    if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     for (uint8_t *q : ctx->pool) if (q) (void)hipFree(q);
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
     if (ctx->d_small) (void)hipFree(ctx->d_small);

@@ -35,8 +35,8 @@ struct ii2_ctx {
     int64_t opt_merge_bitmap = 1;       // single-term tiles whose doc range fits the LDS bitmap are merged by marking bits
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
     size_t aux_cap = 0;
-    uint8_t *aux2 = nullptr;            // grow-only: merge pass-1 output (raw decoded lists)
-    size_t aux2_cap = 0;
+    void *h_segs = nullptr;             // pinned staging block of a merge call's segment views ...
+    void *d_segs = nullptr;             // ... and its device copy (MergeSegs)
     // grow-only staging buffers of the encode / decode / merge-to-segment paths (no hipMalloc per call)
     uint8_t *pool[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t pool_cap[4] = {0, 0, 0, 0};
@@ -131,6 +131,7 @@ struct SegView {
     const uint8_t *payload;
     const uint32_t *cnt;        // [n_terms] postings of each list (same indexing as blk_off)
     const uint32_t *blk_list;   // [n_blocks of the store] list that owns each block, in the segment's own numbering
+    const uint32_t *last_doc;   // [n_terms] last doc id of each list (same indexing as blk_off)
     uint32_t list_base;         // blk_off / cnt point at this list of the segment (blk_list[b] - list_base = term slot)
     uint32_t pad;
 };
@@ -233,10 +234,12 @@ hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
 hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s);
 
-// scans (hipcub) — temp storage comes from the caller
+// scans (scan.hip) — temp storage comes from the caller
 size_t scan_temp_bytes(size_t n);
 hipError_t scan_excl_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
 hipError_t scan_excl_u32_to_u64(void *tmp, size_t tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t s);
+hipError_t scan_excl_u32_to_u64_guarded(void *tmp, size_t tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, const uint64_t *guard,
+                                        uint64_t guard_max, hipStream_t s);
 hipError_t scan_excl_u64(void *tmp, size_t tmp_bytes, const uint64_t *in, uint64_t *out, size_t n, hipStream_t s);
 
 // codec
@@ -265,23 +268,20 @@ constexpr uint32_t ISECT_GMAX = 16;         // driver blocks per tile (max)
 constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map can cover
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
-// merge / union
-constexpr uint32_t MERGE_CAP = 4096;        // postings per tile (LDS)
-constexpr uint32_t MERGE_OFFMAX = 2176;     // (terms per batch + 1) * k  must fit
+// merge / union (merge.hip)
 constexpr uint32_t MERGE_THREADS = 512;     // threads per workgroup of the tile kernel
-// pass 1 (decode) sees the segments; the plan and the tile kernels only see what pass 1 decoded
+constexpr uint32_t MERGE_CAP = 7168;        // postings a tile sorts in LDS (14 per thread)
+constexpr uint32_t MERGE_NT_MAX = 512;      // terms per batch tile (one thread per term)
+constexpr uint32_t MERGE_BM_WORDS = 2 * MERGE_CAP;          // LDS bitmap of a bitmap tile: the sort arrays' 56 KB
+constexpr uint32_t MERGE_BM_DOCS = MERGE_BM_WORDS * 32u;    // docs a bitmap tile covers (458752)
+// the k term-aligned inputs, by value in the kernel arguments
 struct MergeSegs {
     SegView segs[MAX_LISTS];
     uint32_t k;
     uint32_t pad0;
     uint64_t n_terms;
-    // device table written by k_mseg_blocks (no host round trip): [0, k) first block of every segment's term range,
-    // [k, 2k] prefix of the segments' block counts (global block numbering; [2k] = total)
-    const uint32_t *segtab;
-    uint32_t total_ub;                // host-side upper bound of the total (sizes grids and scratch)
-    uint32_t pad1;
 };
-static_assert(sizeof(MergeSegs) <= 4000, "MergeSegs is passed by value as a kernel argument");
+static_assert(sizeof(MergeSegs) <= 4096, "MergeSegs travels through one pinned 4 KB block");
 
 struct MergeParams {
     uint32_t k;
@@ -290,40 +290,46 @@ struct MergeParams {
     const uint32_t *tomb;
     const uint32_t *tomb_summary;  // 1 bit per 16 docs: most bit tests stop at this small, L2-resident array
     uint32_t tomb_nwords;
-    uint32_t small_max;           // terms with a larger upper bound get their own doc-range tiles
-    uint32_t large_tile;          // target upper bound per large-term tile
+    uint32_t small_max;           // terms with more input postings get their own tiles (doc ranges)
+    uint32_t range_target;        // input postings a range tile of a large term aims at
     uint32_t wmin;                // minimum packing weight of a term (bounds terms per batch)
     uint32_t batch_q;             // batch id = weight prefix / batch_q
+    uint32_t bitmap_tiles;        // 1: dense terms are cut into bitmap tiles
+    uint32_t bitmap_sparsity;     // ... when they hold at least one posting per this many docs
     uint32_t pad0;
-    const uint32_t *raw;              // pass 1 output: every input list decoded, back to back
-    const unsigned long long *poff;   // [k * (n_terms+1)] position in raw of list (s, t)
-    const uint4 *rng;                 // [2 * n_tiles * k] the slice of list (s, t0) inside the tile's doc range (k_merge_tile_ranges)
-    const unsigned long long *ub_prefix;   // [n_terms+1] exclusive prefix of the terms' input counts: scratch slot of each term
-    const uint32_t *n_tiles_dev;  // the tile count, computed on the device by the plan kernels
-    uint32_t *tmp;                // scratch: parked survivors
-    uint32_t *tile_count;         // [n_tiles_ub+1] survivors per tile (zeroed by the host: entries past the real tile count stay 0)
+    // per term (plan)
+    uint32_t *tn;                 // [T+1] input postings
+    uint32_t *tmin, *tmax;        // [T+1] smallest / largest doc id over the k lists
+    uint32_t *tinfo;              // [T+1] longest list (bits 0-7), bit 8: bitmap tiles, bit 9: splitters uniform in doc space
+    uint32_t *weight;             // [T+1] packing weight of a small term (0 for large terms)
+    uint32_t *ntl;                // [T+1] tiles of a large term (0 for small terms)
+    const uint64_t *npre;         // [T+1] exclusive prefix of tn: where a term's parking region starts
+    const uint32_t *term_tile;    // [T+1] first tile of each term; [T] = number of tiles
+    const uint32_t *n_tiles_dev;  // = term_tile + T
+    // per tile
+    uint4 *desc;                  // {t0, t1 | flags, dlo, dhi}
+    uint2 *runs;                  // [n_tiles * k] block range of list (s, t0) that overlaps the tile's doc range
+    uint32_t *term_alloc;         // [T] bump allocator inside a large term's parking region (zeroed by the host)
+    uint32_t *tmp;                // parked survivors
+    uint32_t *tile_count;         // [n_tiles_ub+1] survivors per tile (zeroed by the host)
     unsigned long long *tile_slot;   // [n_tiles_ub] where in tmp the tile parked them
-    uint32_t *out_counts;         // [n_terms] survivors per term (zeroed by the host)
+    uint32_t *out_counts;         // [T] survivors per term (zeroed by the host)
     uint32_t *out_values;
     uint64_t out_cap;
     uint64_t *d_total;            // total survivors
-    uint32_t bitmap_tiles;        // 1: dense single-term tiles take the bitmap path
     unsigned long long *debug;    // optional diagnostics words
 };
-hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s);
-hipError_t launch_merge_heads(const MergeParams &p, const uint32_t *ntl, const uint64_t *wpre, uint32_t *head, hipStream_t s);
-hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, const uint32_t *head, const uint32_t *hpre,
-                                  const uint32_t *lpre, uint32_t *term_tile, hipStream_t s);
-hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s);
-hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0 = nullptr,
-                              hipEvent_t ev1 = nullptr);
-hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *segtab, hipStream_t s);
-hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s);
-hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s);
-hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
-                             uint32_t grid_rows, hipStream_t s);
-hipError_t launch_merge_tile_ranges(const MergeParams &p, const MergeSegs &ms, const void *desc, uint32_t *ends, void *rng, hipStream_t s);
-hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s);
+constexpr uint32_t MERGE_DESC_LARGE = 1u << 30;   // desc.y: the tile belongs to a large term (its count goes through tile_count)
+constexpr uint32_t MERGE_DESC_BITMAP = 1u << 31;  // desc.y: bitmap tile
+
+hipError_t launch_merge_plan_terms(const MergeSegs *ms, const MergeParams &p, hipStream_t s);
+hipError_t launch_merge_heads(const MergeParams &p, const uint64_t *wpre, uint32_t *head, hipStream_t s);
+hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *head, const uint32_t *hpre, const uint32_t *lpre,
+                                  uint32_t *term_tile, hipStream_t s);
+hipError_t launch_merge_tile_desc(const MergeSegs *ms, const MergeParams &p, hipStream_t s);
+hipError_t launch_merge_tile_runs(const MergeSegs *ms, const MergeParams &p, hipStream_t s);
+hipError_t launch_merge_tiles(const MergeSegs *ms, const MergeParams &p, uint32_t grid, hipStream_t s);
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 

@@ -7,273 +7,153 @@
 //     empty terms reported with count 0 (shard.go:192-194);
 //   * the multi-term union of PrefixSearch (inverted_index.go:274-292) — one "term", k lists.
 //
-// Pass 1 decodes every input list once, streaming, into a raw u32 scratch array (one wave per
-// DV1 block, all segments in one launch) and derives exact per-(segment, term) offsets.  Pass 2
-// cuts the work into TILES that fit LDS (<= CAP postings):
-//   small terms are packed, in term order, into batches of consecutive terms;
-//   a large term is cut into doc-id ranges at exact quantiles of its longest list; where each
-//   segment's list enters and leaves a range is found by binary search in the planning pass.
-// A 512-thread workgroup handles a tile: it copies the tile's slices of the k raw lists into
-// LDS as k runs sorted by (term, doc), folds the runs pairwise (log2 k levels; single-term tiles
-// by merge-path + sequential two-way merges, batches by one binary search per element), then
-// drops duplicates and tombstoned ids and compacts.  Tiles are independent: each parks its
-// survivors in a scratch array at the input rank of its first posting; a scan of the tile counts
-// and a packing pass then produce the CSR the reference's writer would have been fed: terms
-// ascending, ids ascending.
+// Round 3: every posting crosses HBM once on its way in.  There is no decode pass and no raw scratch array: the plan
+// is made from what the segments already hold (per-list posting counts, first / last docs, skip tables) and the tile
+// kernel decodes the DV1 blocks of its tile straight into LDS.  Three kinds of tile:
+//   batch    consecutive small terms, whole lists (<= MERGE_CAP postings in all);
+//   range    a doc-id range of a large term (ranges are cut at block boundaries of the term's longest list, so they
+//            need no decoded data; every list's blocks that overlap a range are found in its skip table);
+//   bitmap   a fixed doc-id range (MERGE_BM_DOCS docs) of a term dense enough for a bitmap over the range.
+// Batch and range tiles sort by buckets: a monotone map of the doc id (per term) onto ~1 bucket per posting, slot
+// inside the bucket from an LDS counter, exclusive scan of the counters, then every posting ranks itself among the few
+// that share its bucket; duplicates and tombstoned ids set a bit in a "dead" mask over the sorted positions and every
+// survivor goes straight from its register to its final rank in the output (no compaction pass, no sorted copy).
+// Bitmap tiles mark, clear the tombstoned words and extract.  A bucket that overflows (clustered ids) or a range that
+// holds more than LDS sends the range to a bisection whose leaves are small enough for the bitmap — exact for any input.
+// Tiles are independent: each parks its survivors in a scratch array (batches at the input rank of their first term,
+// tiles of a large term through a bump allocator inside the term's region); a scan of the tile counts and a packing
+// pass then produce the CSR the reference's writer would have been fed: terms ascending, ids ascending.
+#include <type_traits>
+
 #include "dv1_device.h"
 #include "internal.h"
 
 namespace ii2 {
 
-constexpr uint32_t MCAP = MERGE_CAP;              // postings per tile
-constexpr uint32_t OFFMAX = MERGE_OFFMAX;         // (nt+1) * k table entries
-constexpr uint32_t MT = MERGE_THREADS;            // threads per workgroup of the tile kernel
+constexpr uint32_t MCAP = MERGE_CAP;
+constexpr uint32_t MT = MERGE_THREADS;
 constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
-constexpr uint32_t NBK = 4096;                    // buckets of the single-term fold (8 per thread)
-constexpr uint32_t BKT_LIMIT = 24;                // fullest bucket the bucket fold accepts
-constexpr uint32_t BKT_LIMIT_MT = 14;             // ... for batches (the slot shares 16 bits with the 12-bit bucket)
-static_assert(NBK == 8u * MT && NBK + 4u <= 2u * OFFMAX, "bucket counters alias the list-offset table");
+constexpr uint32_t EPT = MCAP / MT;               // elements per thread in the sort passes (14)
+constexpr uint32_t PCAP = 1024;                   // 16-byte payload pieces decoded per chunk of blocks
+constexpr uint32_t BKT_LIMIT = 15;                // fullest bucket the bucket sort accepts (slot numbers are 4 bits)
+constexpr uint32_t BMW = MERGE_BM_WORDS;
+static_assert(MCAP % MT == 0 && EPT * 4u <= 64u && (MCAP / 2u) % MT == 0, "sort passes: EPT elements and EPT / 2 counter words per thread");
 
-// ---- pass 1: decode everything once --------------------------------------------------------
-// global block g of the merge input -> (segment, block of that segment)
-__device__ __forceinline__ uint32_t seg_of_gblock(const MergeSegs &p, uint32_t g) {
-    const uint32_t *cum = p.segtab + p.k;
-    uint32_t lo = 0, hi = p.k;          // cum[lo] <= g < cum[hi]
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (cum[mid] <= g) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-// lc[s * (T+1) + t] = postings of list (s, t) (0 for t == T); its exclusive scan is poff
-__global__ void k_mlist_counts(MergeSegs p, uint32_t *__restrict__ lc) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n1 = p.n_terms + 1;
-    if (i >= (uint64_t)p.k * n1) return;
-    const uint32_t s = (uint32_t)(i / n1);
-    const uint64_t t = i % n1;
-    lc[i] = t < p.n_terms ? p.segs[s].cnt[t] : 0u;
-}
-
-// segtab: [s] = first block of segment s's term range, [k + s] = blocks of the segments before s, [2k] = all blocks (one wave)
-__global__ void k_mseg_blocks(MergeSegs p, uint32_t *__restrict__ segtab) {
-    const uint32_t s = threadIdx.x;
-    uint32_t b0 = 0, cnt = 0;
-    if (s < p.k) { b0 = p.segs[s].blk_off[0]; cnt = p.segs[s].blk_off[p.n_terms] - b0; }
-    const uint32_t incl = wave_incl_scan(cnt);
-    if (s < p.k) { segtab[s] = b0; segtab[p.k + s] = incl - cnt; }
-    if (s == 63u) segtab[2u * p.k] = incl;
-}
-
-// Every block but a list's last holds II2_DV1_BLOCK postings, so block j of list (s, t) decodes to
-// raw[poff[s, t] + 256 j ...].  Most lists of a Zipf index are tiny (a handful of postings per segment
-// and term): blocks with up to TINY_BYTES of payload are decoded one per LANE from registers (all seven
-// possible dwords fetched at once); the others are appended to a list and decoded one per 16-lane ROW.
-constexpr uint32_t TINY_BYTES = 28;
-
-// which (segment, list, block) a global block is, where it decodes to, and whether it is left to the row kernel
-struct BlkRef { bool valid, big; uint32_t s, q0, q1, first; unsigned long long pos; };
-__device__ __forceinline__ BlkRef blk_ref(const MergeSegs &p, const unsigned long long *__restrict__ poff, uint64_t g, bool want_pos) {
-    BlkRef r;
-    r.valid = false; r.big = false; r.s = 0; r.q0 = 0; r.q1 = 0; r.first = 0; r.pos = 0;
-    if (g >= p.segtab[2u * p.k]) return r;
-    const uint32_t s = seg_of_gblock(p, (uint32_t)g);
-    const SegView sv = p.segs[s];
-    const uint32_t b = p.segtab[s] + ((uint32_t)g - p.segtab[p.k + s]);
-    const uint32_t t = sv.blk_list[b] - sv.list_base;
-    if (t >= p.n_terms) return r;
-    const ii2_skip e0 = sv.skip[b];
-    r.valid = true;
-    r.s = s;
-    r.q0 = e0.byte_off;
-    r.q1 = sv.skip[b + 1].byte_off;
-    r.first = e0.first_doc;
-    r.big = r.q1 - r.q0 > TINY_BYTES;
-    if (want_pos) r.pos = poff[(uint64_t)s * (p.n_terms + 1) + t] + (unsigned long long)(b - sv.blk_off[t]) * II2_DV1_BLOCK;
-    return r;
-}
-
-// non-tiny blocks per workgroup of k_mdec_lane (their scan gives every workgroup its slice of the work list:
-// one address sustains only ~90 atomics/us, far too few for an append per wave)
-__global__ __launch_bounds__(256) void k_mbig_count(MergeSegs p, uint32_t *__restrict__ wgcnt) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const BlkRef r = blk_ref(p, nullptr, g, false);
-    const int c = __syncthreads_count(r.big ? 1 : 0);
-    if (threadIdx.x == 0) wgcnt[blockIdx.x] = (uint32_t)c;
-}
-
-__global__ __launch_bounds__(256) void k_mdec_lane(MergeSegs p, const unsigned long long *__restrict__ poff, uint32_t *__restrict__ raw,
-                                                    const uint32_t *__restrict__ wgbase, uint4 *__restrict__ ent0, uint2 *__restrict__ ent1) {
-    __shared__ uint32_t wcnt[4];
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const BlkRef r = blk_ref(p, poff, g, true);
-    if (r.valid && !r.big) {
-        const uint32_t len = r.q1 - r.q0;
-        const uint8_t *pl = p.segs[r.s].payload + r.q0;
-        uint32_t w[7];
-#pragma unroll
-        for (int j = 0; j < 7; j++) w[j] = (uint32_t)(4 * j) < len ? load_u32_unaligned(pl + 4u * j) : 0u;
-        uint32_t *out = raw + r.pos;
-        uint32_t cur = r.first, acc = 0, sh = 0;
-        *out++ = cur;
-#pragma unroll
-        for (int j = 0; j < 28; j++) {
-            if ((uint32_t)j < len) {
-                const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                acc += (c & 0x7Fu) << sh;
-                if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
-                else { cur += acc; *out++ = cur; acc = 0; sh = 0; }
-            }
-        }
-    }
-    // work list entries of the blocks left to the row kernel, in block order
-    const unsigned long long m = __ballot(r.big);
-    const int wv = (int)threadIdx.x >> 6;
-    if (lane_id() == 0) wcnt[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (r.big) {
-        uint32_t at = wgbase[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        for (int w2 = 0; w2 < wv; w2++) at += wcnt[w2];
-        ent0[at] = make_uint4((uint32_t)r.pos, (uint32_t)(r.pos >> 32), r.q0, r.q1);
-        ent1[at] = make_uint2(r.first, r.s);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mdec_rows(MergeSegs p, uint32_t *__restrict__ raw, const uint4 *__restrict__ ent0,
-                                                    const uint2 *__restrict__ ent1, const uint32_t *__restrict__ nbig) {
-    // a row's postings are collected in LDS and leave as 16-byte stores: a block is contiguous in raw, but the lanes of its
-    // row hold 16 payload bytes each — a varying number of postings — so storing from the decoder would be one partly
-    // filled 4-byte store instruction per posting of the fullest lane
-    __shared__ __align__(16) uint32_t stage[4][4][II2_DV1_BLOCK];
-    const uint32_t n = *nbig;
-    const uint64_t stride = ((uint64_t)gridDim.x * blockDim.x) >> 4;
-    const uint32_t wv = threadIdx.x >> 6, row = ((uint32_t)threadIdx.x >> 4) & 3u, rl = (uint32_t)threadIdx.x & 15u;
-    uint32_t *st = stage[wv][row];
-    for (uint64_t z = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; __ballot(z < n) != 0ull; z += stride) {
-        const bool rv = z < n;
-        uint32_t q0 = 0, q1 = 0, first = 0;
-        uint32_t *out = raw;
-        const uint8_t *pl = nullptr;     // rows of one wave may read different segments
-        if (rv) {
-            const uint4 e0 = ent0[z];
-            const uint2 e1 = ent1[z];
-            q0 = e0.z;
-            q1 = e0.w;
-            first = e1.x;
-            out = raw + ((unsigned long long)e0.x | ((unsigned long long)e0.y << 32));
-            pl = p.segs[e1.y].payload;
-        }
-        const uint32_t cnt = decode_rows16_any(pl, q0, q1, first, rv, [&](uint32_t ix, uint32_t id) { st[ix & (II2_DV1_BLOCK - 1u)] = id; });
-        if (rv) {
-            const uint32_t c = cnt < II2_DV1_BLOCK ? cnt : II2_DV1_BLOCK;       // (imported segments are validated: a block holds <= 256)
-            for (uint32_t i = 4u * rl; i < c; i += 64u) {
-                if (i + 4u <= c) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(&st[i]);
-                    __builtin_memcpy(out + i, &v, 16);
-                } else {
-                    for (uint32_t j = i; j < c; j++) out[j] = st[j];
-                }
-            }
-        }
-    }
-}
-
-// ---- plan -------------------------------------------------------------------------------
-// exact input postings of every term, its packing weight, and the tiles of a large term
-__global__ void k_merge_term_ub(MergeParams p, uint32_t *__restrict__ ub, uint32_t *__restrict__ weight,
-                                uint32_t *__restrict__ ntiles_large) {
+// ---- plan ----------------------------------------------------------------------------------
+// per term: input postings, doc range, longest list, and how it will be merged
+__global__ __launch_bounds__(256) void k_mp_terms(const MergeSegs *__restrict__ ms, MergeParams p) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > p.n_terms) return;
-    if (t == p.n_terms) { ub[t] = 0; weight[t] = 0; ntiles_large[t] = 0; return; }
-    const uint64_t n1 = p.n_terms + 1;
-    uint64_t u = 0;
-    for (uint32_t s = 0; s < p.k; s++) u += p.poff[s * n1 + t + 1] - p.poff[s * n1 + t];
-    const uint32_t u32 = u > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)u;
-    ub[t] = u32;
-    if (u32 > p.small_max) {
-        weight[t] = 0;
-        ntiles_large[t] = (uint32_t)((u + p.large_tile - 1) / p.large_tile);
-    } else {
-        weight[t] = u32 > p.wmin ? u32 : p.wmin;
-        ntiles_large[t] = 0;
+    if (t == p.n_terms) { p.tn[t] = 0; p.tmin[t] = 0; p.tmax[t] = 0; p.tinfo[t] = 0; p.weight[t] = 0; p.ntl[t] = 0; return; }
+    uint64_t n = 0;
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u, best = 0, best_nb = 0;
+    for (uint32_t s = 0; s < p.k; s++) {
+        const SegView &sv = ms->segs[s];
+        const uint32_t b0 = sv.blk_off[t], b1 = sv.blk_off[t + 1];
+        if (b1 > b0) {
+            n += sv.cnt[t];
+            const uint32_t f = sv.skip[b0].first_doc, la = sv.last_doc[t];
+            mn = f < mn ? f : mn;
+            mx = la > mx ? la : mx;
+            if (b1 - b0 > best_nb) { best_nb = b1 - b0; best = s; }
+        }
     }
+    const uint32_t n32 = n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
+    if (n == 0) { mn = 0; mx = 0; }
+    if (mx < mn) mx = mn;                              // (lists that are not ascending: keep the range well-formed)
+    p.tn[t] = n32;
+    p.tmin[t] = mn;
+    p.tmax[t] = mx;
+    uint32_t info = best, w = 0, tiles = 0;
+    if (n32 > p.small_max) {
+        const uint64_t span = (uint64_t)mx - (mn & ~31u) + 1ull;
+        if (p.bitmap_tiles && span <= (uint64_t)n32 * p.bitmap_sparsity) {
+            info |= 1u << 8;
+            tiles = (uint32_t)((span + MERGE_BM_DOCS - 1) / MERGE_BM_DOCS);
+        } else {
+            tiles = (uint32_t)(((uint64_t)n32 + p.range_target - 1) / p.range_target);
+            if (best_nb < 2u * tiles) info |= 1u << 9;     // too few blocks to cut at: splitters uniform in doc space
+        }
+    } else {
+        w = n32 > p.wmin ? n32 : p.wmin;
+    }
+    p.tinfo[t] = info;
+    p.weight[t] = w;
+    p.ntl[t] = tiles;
 }
 
 // head[t] = 1 when small term t opens a new batch
-__global__ void k_merge_heads(MergeParams p, const uint32_t *__restrict__ ntl, const uint64_t *__restrict__ wpre,
-                              uint32_t *__restrict__ head) {
+__global__ void k_merge_heads(MergeParams p, const uint64_t *__restrict__ wpre, uint32_t *__restrict__ head) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > p.n_terms) return;
-    if (t == p.n_terms || ntl[t] > 0) { head[t] = 0; return; }
-    bool h = t == 0 || ntl[t - 1] > 0;
+    if (t == p.n_terms || p.ntl[t] > 0) { head[t] = 0; return; }
+    bool h = t == 0 || p.ntl[t - 1] > 0;
     if (!h) h = (wpre[t] / p.batch_q) != (wpre[t - 1] / p.batch_q);
     head[t] = h ? 1u : 0u;
 }
 
-// term_tile[t] = id of the (first) tile of term t; monotone in t
-__global__ void k_merge_term_tile(MergeParams p, const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ head,
-                                  const uint32_t *__restrict__ hpre, const uint32_t *__restrict__ lpre,
-                                  uint32_t *__restrict__ term_tile) {
+// term_tile[t] = id of the (first) tile of term t; monotone in t; term_tile[T] = number of tiles
+__global__ void k_merge_term_tile(MergeParams p, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hpre,
+                                  const uint32_t *__restrict__ lpre, uint32_t *__restrict__ term_tile) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t > p.n_terms) return;
-    if (t == p.n_terms) { term_tile[t] = hpre[t] + lpre[t]; return; }
-    if (ntl[t] > 0) term_tile[t] = hpre[t] + lpre[t];
+    if (t == p.n_terms || p.ntl[t] > 0) term_tile[t] = hpre[t] + lpre[t];
     else term_tile[t] = hpre[t] + head[t] - 1u + lpre[t];
 }
 
-// tile descriptors {t0, t1, lo, hi}
-__global__ void k_merge_tile_desc(MergeParams p, const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile,
-                                  uint4 *__restrict__ desc) {
+// tile descriptors {t0, t1 | flags, dlo, dhi}
+__global__ void k_merge_tile_desc(const MergeSegs *__restrict__ ms, MergeParams p) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile >= *p.n_tiles_dev) return;
-    // last term whose first tile <= tile
+    const uint32_t *term_tile = p.term_tile;
     uint64_t lo = 0, hi = p.n_terms;           // term_tile[lo] <= tile < term_tile[hi] (term_tile[n_terms] = n_tiles)
     while (hi - lo > 1) {
         const uint64_t mid = lo + ((hi - lo) >> 1);
         if (term_tile[mid] <= tile) lo = mid; else hi = mid;
     }
     const uint64_t tl = lo;
-    if (ntl[tl] > 0) {                          // tile j of large term tl
-        const uint32_t m = ntl[tl], j = tile - term_tile[tl];
-        // splitters: exact quantiles of the term's longest list (raw ids)
-        const uint64_t n1 = p.n_terms + 1;
-        uint32_t best_s = 0;
-        uint64_t best_n = 0;
-        for (uint32_t s = 0; s < p.k; s++) {
-            const uint64_t len = p.poff[s * n1 + tl + 1] - p.poff[s * n1 + tl];
-            if (len > best_n) { best_n = len; best_s = s; }
+    if (p.ntl[tl] > 0) {                        // tile j of large term tl
+        const uint32_t m = p.ntl[tl], j = tile - term_tile[tl], info = p.tinfo[tl];
+        const uint32_t mn = p.tmin[tl], mx = p.tmax[tl];
+        uint32_t flags = MERGE_DESC_LARGE;
+        uint64_t lo64, hi64;                    // the tile covers [lo64, hi64)
+        if (info & (1u << 8)) {                 // bitmap tiles: fixed windows from the term's first doc (rounded down to a word)
+            flags |= MERGE_DESC_BITMAP;
+            lo64 = (uint64_t)(mn & ~31u) + (uint64_t)j * MERGE_BM_DOCS;
+            hi64 = lo64 + MERGE_BM_DOCS;
+            if (hi64 > (1ull << 32)) hi64 = 1ull << 32;
+        } else if (m == 1u) {
+            lo64 = 0; hi64 = 1ull << 32;
+        } else {
+            auto splitter = [&](uint32_t jj) -> uint64_t {
+                if (jj == 0) return 0ull;
+                if (jj >= m) return 1ull << 32;
+                if (info & (1u << 9)) return (uint64_t)mn + ((uint64_t)jj * ((uint64_t)mx - mn + 1ull)) / m;
+                const SegView &sv = ms->segs[info & 0xFFu];
+                const uint32_t b0 = sv.blk_off[tl], nb = sv.blk_off[tl + 1] - b0;
+                return (uint64_t)sv.skip[b0 + (uint32_t)(((uint64_t)jj * nb) / m)].first_doc;      // first docs ascend: non-decreasing in jj
+            };
+            lo64 = splitter(j);
+            hi64 = splitter(j + 1u);
         }
-        const uint32_t *lst = p.raw + p.poff[best_s * n1 + tl];
-        auto splitter = [&](uint32_t jj) -> uint32_t { return lst[((uint64_t)jj * best_n) / m]; };
-        // tile j covers [S_j, S_{j+1}) with S_0 = 0 and S_m = 2^32; S is non-decreasing in j
-        const uint64_t lo64 = j > 0 ? (uint64_t)splitter(j) : 0ull;
-        const uint64_t hi64 = j + 1u < m ? (uint64_t)splitter(j + 1u) : (1ull << 32);
         uint32_t dlo, dhi;
-        if (hi64 <= lo64) {                                   // empty range (dlo > dhi); dhi + 1 still is the upper splitter
-            if (hi64 > 0) { dlo = (uint32_t)hi64; dhi = (uint32_t)(hi64 - 1ull); }
-            else { dlo = 1u; dhi = 0u; }
-        }
+        if (hi64 <= lo64) { dlo = 1u; dhi = 0u; }                                 // empty range
         else { dlo = (uint32_t)lo64; dhi = (uint32_t)(hi64 - 1ull); }
-        desc[tile] = make_uint4((uint32_t)tl, (uint32_t)tl + 1u, dlo, dhi);
+        p.desc[tile] = make_uint4((uint32_t)tl, ((uint32_t)tl + 1u) | flags, dlo, dhi);
     } else {
         // batch: terms [first with term_tile == tile, last with term_tile == tile]
         uint64_t a = 0, b = tl;                 // find first term with term_tile >= tile
         if (term_tile[0] >= tile) b = 0;
         else {
-            a = 0;                              // term_tile[a] < tile <= term_tile[b]
-            while (b - a > 1) {
+            while (b - a > 1) {                 // term_tile[a] < tile <= term_tile[b]
                 const uint64_t mid = a + ((b - a) >> 1);
                 if (term_tile[mid] < tile) a = mid; else b = mid;
             }
         }
-        desc[tile] = make_uint4((uint32_t)b, (uint32_t)tl + 1u, 0u, 0xFFFFFFFFu);
+        p.desc[tile] = make_uint4((uint32_t)b, (uint32_t)tl + 1u, 0u, 0xFFFFFFFFu);
     }
 }
 
-// ends[tile * k + s] = postings of list (s, t0) with doc <= the tile's upper bound (large-term tiles only).
-// Two levels: the block is found in the segment's skip table (8 bytes per 256 postings, cache-resident), only the last
-// eight steps touch the decoded list itself — the searches over the raw arrays used to fetch 0.8 GB per merge.
 // first index i in [lo, hi) with get(i) > x, for an ascending sequence that is close to uniform between vlo (a lower bound of
 // get(lo)) and vhi (an upper bound of get(hi - 1)): a linear guess, a doubling walk away from it until x is bracketed, then
 // bisection inside the bracket — a handful of dependent loads instead of log2(hi - lo).  Exact for any ascending input.
@@ -304,75 +184,65 @@ __device__ __forceinline__ uint32_t upper_bound_guess(Get get, uint32_t lo, uint
     return lo;
 }
 
-__global__ void k_merge_tile_ends(MergeParams p, MergeSegs ms, const uint4 *__restrict__ desc, uint32_t *__restrict__ ends) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)*p.n_tiles_dev * p.k) return;
-    const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
-    const uint4 td = desc[tile];
-    if (td.z == 0u && td.w == 0xFFFFFFFFu) return;           // whole lists: nothing to search
-    const uint64_t n1 = p.n_terms + 1;
-    const uint64_t beg = p.poff[s * n1 + td.x], end = p.poff[s * n1 + td.y];
-    const uint32_t len = (uint32_t)(end - beg);
-    const SegView sv = ms.segs[s];
-    const uint32_t b_lo = sv.blk_off[td.x], b_hi = sv.blk_off[td.x + 1u];
-    uint32_t res = 0;
-    if (b_hi > b_lo) {
-        const uint32_t f0 = sv.skip[b_lo].first_doc, fl = sv.skip[b_hi - 1u].first_doc;
-        // first block of the list whose first doc is > td.w (the doc ids of a large term's list are close to uniform)
-        const uint32_t a = upper_bound_guess([&](uint32_t j) { return sv.skip[j].first_doc; }, b_lo, b_hi, td.w, f0, fl);
-        if (a > b_lo) {                                       // block a - 1 starts at or before td.w: the boundary lies inside it (or at its end)
-            const uint32_t base = (a - 1u - b_lo) * II2_DV1_BLOCK;
-            const uint32_t *lst = p.raw + beg + base;
-            const uint32_t cntb = len - base < II2_DV1_BLOCK ? len - base : II2_DV1_BLOCK;
-            const uint32_t fb = sv.skip[a - 1u].first_doc;
-            const uint32_t fn = a < b_hi ? sv.skip[a].first_doc : (cntb ? lst[cntb - 1u] : fb);
-            res = base + upper_bound_guess([&](uint32_t j) { return lst[j]; }, 0u, cntb, td.w, fb, fn);
-        }
-    }
-    ends[i] = res;
+// blocks [b0, b1) of a list (blocks [b_lo, b_hi) of its segment) that may hold docs of [dlo, dhi]: from the last block
+// that starts at or before dlo up to the last block that starts at or before dhi
+__device__ __forceinline__ uint2 blocks_of_range(const ii2_skip *__restrict__ skip, uint32_t b_lo, uint32_t b_hi, uint32_t dlo, uint32_t dhi) {
+    if (b_hi <= b_lo || dlo > dhi) return make_uint2(b_lo, b_lo);
+    const uint32_t f0 = skip[b_lo].first_doc, fl = skip[b_hi - 1u].first_doc;
+    auto get = [&](uint32_t j) { return skip[j].first_doc; };
+    const uint32_t a = upper_bound_guess(get, b_lo, b_hi, dlo, f0, fl);
+    const uint32_t b1 = dhi == 0xFFFFFFFFu ? b_hi : upper_bound_guess(get, a, b_hi, dhi, dlo, fl);
+    return make_uint2(a > b_lo ? a - 1u : b_lo, b1);
 }
 
-// where every segment's list enters and leaves a tile's doc range: rng[2 * (tile * k + s)] =
-// (position in raw of the first posting inside the range: lo, hi; postings inside; postings of list (s, t0) before it),
-// rng[.. + 1] = (first doc, last doc of the slice, -, -).  A range starts where the previous tile of the term ended.
-__global__ void k_merge_tile_ranges(MergeParams p, const uint4 *__restrict__ desc, const uint32_t *__restrict__ ends, uint4 *__restrict__ rng) {
+// runs[tile * k + s]: the blocks of list (s, t0) a range tile has to decode (tiles that take whole lists read blk_off)
+__global__ void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams p) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (uint64_t)*p.n_tiles_dev * p.k) return;
     const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
-    const uint4 td = desc[tile];
-    const uint64_t n1 = p.n_terms + 1;
-    const uint64_t beg = p.poff[s * n1 + td.x], end = p.poff[s * n1 + td.y];
-    const uint32_t len = (uint32_t)(end - beg);
-    const uint32_t *lst = p.raw + beg;
-    uint32_t a = 0, e = len;
-    if (td.z > td.w) { a = 0; e = 0; }                       // empty doc range
-    else if (!(td.z == 0u && td.w == 0xFFFFFFFFu)) {
-        e = ends[i];
-        a = td.z == 0u ? 0u : ends[i - p.k];                 // td.z > 0: the tile before belongs to the same term and ends at td.z - 1
-    }
-    const uint64_t rs = beg + a;
-    rng[2 * i] = make_uint4((uint32_t)rs, (uint32_t)(rs >> 32), e - a, a);
-    rng[2 * i + 1] = e > a ? make_uint4(lst[a], lst[e - 1u], 0u, 0u) : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);
+    const uint4 td = p.desc[tile];
+    if (td.z == 0u && td.w == 0xFFFFFFFFu) return;            // whole lists: nothing to search
+    const SegView &sv = ms->segs[s];
+    p.runs[i] = blocks_of_range(sv.skip, sv.blk_off[td.x], sv.blk_off[td.x + 1u], td.z, td.w);
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------
 struct __align__(16) MergeSmem {
-    uint32_t vals[2][MCAP];
-    uint16_t tids[2][MCAP];             // (run << 10 | term) of each element
-    uint32_t offs[2][OFFMAX];           // per run: nt+1 list offsets inside the run
-    uint32_t runbase[2][MAX_LISTS + 2];
-    unsigned long long rs[MAX_LISTS];   // position in raw of each run's first posting
-    uint32_t spre[MAX_LISTS + 1];       // run lengths
-    uint32_t sbl_rank[MAX_LISTS];       // postings of each list that precede the range
-    uint2 tterm[MT];                    // batches: per term {smallest doc, float bits of buckets per doc}
-    uint16_t ttb[MT + 2];               // batches: per term its first bucket = its first position after the fold
-    uint32_t rmin[MAX_LISTS], rmax[MAX_LISTS];   // first / last doc of each run (single-term tiles)
+    union {
+        struct {
+            uint32_t V[MCAP];               // the tile's postings: arrival order, then bucket order
+            uint16_t TG[MCAP];              // per posting: term slot (while decoding), then its bucket
+            uint32_t C32[MCAP / 2u + 4u];   // bucket counters, then exclusive bucket bases: two 16-bit values per word
+        } s;
+        uint32_t bm[BMW];                   // bitmap tiles: one bit per doc of the tile's range
+    } u;
+    union {
+        struct {                            // while a chunk of blocks is decoded
+            uint32_t PX[PCAP];              // exclusive prefix of the pieces' gap sums
+            uint32_t BF[MT], BQ[MT], BI[MT];   // per block: first doc, payload offset, run | term slot << 6 | payload bytes << 15
+            uint16_t PB[MT + 2u];           // per block: its first piece
+        } d;
+        struct {                            // while a decoded tile is sorted
+            uint2 TT[MERGE_NT_MAX];         // per term of a batch: {smallest doc, float bits of buckets per doc}
+            uint16_t TB[MERGE_NT_MAX + 4u]; // per term: its first bucket
+            uint32_t DB[MCAP / 32u + 1u];   // dead mask over the sorted positions: duplicates and tombstoned ids
+            uint32_t DP[MCAP / 32u + 2u];   // exclusive prefix of the dead mask's popcounts
+        } f;
+    } x;
+    const uint8_t *pay[MAX_LISTS];
+    const ii2_skip *skp[MAX_LISTS];
+    const uint32_t *bls[MAX_LISTS];
+    const uint32_t *bof[MAX_LISTS];
+    uint32_t lbase[MAX_LISTS];
+    uint32_t RR0[MAX_LISTS], RR1[MAX_LISTS];   // block range of each run for the tile's root doc range
+    uint32_t R0[MAX_LISTS];                 // first block of each run for the range being merged
+    uint32_t RB[MAX_LISTS + 2u];            // exclusive prefix of the runs' block counts
     uint32_t wsum[MW];
-    uint32_t wmax[MW];
-    uint32_t vmin, vmax;                // doc range the tile's postings really span
-    uint32_t n_in;
-    uint32_t rank;                      // input postings of the tile's term(s) that precede the tile's doc range
-    uint32_t stk[70][2];                // bisection stack of doc ranges (oversized tiles)
+    uint32_t fill;                          // postings of the range that arrived in V (may exceed MCAP: the range is then split)
+    uint32_t ovf;                           // a bucket overflowed
+    uint32_t tp;                            // pieces of the chunk
+    uint32_t ab;                            // allocation inside the term's parking region
+    uint32_t stk[72][2];                    // bisection stack of doc ranges
 };
 
 // block-wide exclusive scan of one value per thread (MT threads); returns exclusive prefix, total in *tot
@@ -389,12 +259,10 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return pre + incl - v;
 }
 
-// KFIX: segment count known at compile time (0 = read it from the parameters); 16-way merges get their own instantiation
-template <uint32_t KFIX>
-__global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p, const uint4 *__restrict__ tile_desc) {
+__global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSegs *__restrict__ ms, MergeParams p) {
     __shared__ MergeSmem sm;
-    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
-    const uint32_t k = KFIX ? KFIX : p.k;
+    const int tid = (int)threadIdx.x, l = tid & 63;
+    const uint32_t k = p.k;
     // diagnostics only: thread 0 sums the cycles spent in each step of the tile loop
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
@@ -407,747 +275,534 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(MergeParams p,
     }
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
-    const uint32_t n_tiles = *p.n_tiles_dev;       // computed by the plan kernels; the host only knows an upper bound
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint4 td = tile_desc[tile];
-        const uint32_t t0 = td.x, t1 = td.y;
-        const uint32_t nt = t1 - t0;
-        const uint32_t stride = nt + 1u;
-        const uint64_t n1 = p.n_terms + 1;
+    if ((uint32_t)tid < k) {
+        const SegView &sv = ms->segs[tid];
+        sm.pay[tid] = sv.payload;
+        sm.skp[tid] = sv.skip;
+        sm.bls[tid] = sv.blk_list;
+        sm.bof[tid] = sv.blk_off;
+        sm.lbase[tid] = sv.list_base;
+    }
+    __syncthreads();
 
-        // ---- step A: the k runs of the doc range [dlo, dhi] — where they start in raw, how long they
-        // are, where they go in LDS.  root: the planning pass already searched the range (rng);
-        // otherwise (a bisected leaf) every segment's list is binary-searched here.
-        // Returns false when the range does not fit LDS.
-        auto load_range = [&](uint32_t dlo, uint32_t dhi, bool root) -> bool {
-            __syncthreads();
-            if (nt == 1u && k > 1u) {       // bucket counters of the single-term fold (they live in the unused list-offset table)
-                uint4 *z = reinterpret_cast<uint4 *>(&sm.offs[0][0]);
-                for (uint32_t i = (uint32_t)tid; i < (NBK + 4u) / 4u; i += MT) z[i] = make_uint4(0, 0, 0, 0);
-            } else if (k > 1u) {            // batches: 4096 16-bit bucket counters in the second list-offset table
-                reinterpret_cast<uint4 *>(&sm.offs[1][0])[tid] = make_uint4(0, 0, 0, 0);
-            }
-            if ((uint32_t)tid < k) {
-                if (root) {
-                    const uint4 r0 = p.rng[2u * ((uint64_t)tile * k + (uint32_t)tid)], r1 = p.rng[2u * ((uint64_t)tile * k + (uint32_t)tid) + 1u];
-                    sm.rs[tid] = (unsigned long long)r0.x | ((unsigned long long)r0.y << 32);
-                    sm.spre[tid] = r0.z;
-                    sm.sbl_rank[tid] = r0.w;
-                    sm.rmin[tid] = r1.x;
-                    sm.rmax[tid] = r1.y;
-                } else {
-                    const uint64_t beg = p.poff[(uint32_t)tid * n1 + t0], end = p.poff[(uint32_t)tid * n1 + t1];
-                    const uint32_t len = (uint32_t)(end - beg);
-                    const uint32_t *lst = p.raw + beg;
-                    uint32_t lo = 0, hi = len;
-                    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] < dlo) lo = mid + 1u; else hi = mid; }
-                    const uint32_t a = lo;
-                    hi = len;
-                    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (lst[mid] <= dhi) lo = mid + 1u; else hi = mid; }
-                    const uint32_t e = lo;
-                    sm.rs[tid] = beg + a;
-                    sm.spre[tid] = e - a;
-                    sm.sbl_rank[tid] = a;
-                    sm.rmin[tid] = e > a ? lst[a] : 0xFFFFFFFFu;
-                    sm.rmax[tid] = e > a ? lst[e - 1u] : 0u;
-                }
-            }
-            __syncthreads();
-            if (wv == 0) {
-                const uint32_t c = (uint32_t)l < k ? sm.spre[l] : 0u;
-                const uint32_t incl = wave_incl_scan(c);
-                if ((uint32_t)l < k) sm.runbase[0][l] = incl - c;
-                if (l == 63) { sm.runbase[0][k] = incl; sm.n_in = incl; }
-                const uint32_t r = wave_sum((uint32_t)l < k ? sm.sbl_rank[l] : 0u);
-                if (l == 0) sm.rank = r;
-                uint32_t mn = (uint32_t)l < k ? sm.rmin[l] : 0xFFFFFFFFu, mx = (uint32_t)l < k ? sm.rmax[l] : 0u;
-                for (int d = 32; d >= 1; d >>= 1) {
-                    const uint32_t on = (uint32_t)__shfl_xor((int)mn, d, 64), ox = (uint32_t)__shfl_xor((int)mx, d, 64);
-                    mn = on < mn ? on : mn;
-                    mx = ox > mx ? ox : mx;
-                }
-                if (l == 0) { sm.vmin = mn; sm.vmax = mx; }
-            }
-            // list offsets inside each run (batches of several terms)
-            if (nt > 1u) {
-                for (uint32_t e = (uint32_t)tid; e < k * stride; e += MT) {
-                    const uint32_t s = e / stride, t = e % stride;
-                    sm.offs[0][e] = (uint32_t)(p.poff[s * n1 + t0 + t] - p.poff[s * n1 + t0]);
-                }
-            }
-            __syncthreads();
-            II2_STAMP(0)      // A: run ranges, list table
-            return sm.n_in <= MCAP;
-        };
+    // ---- the runs of a doc range: which blocks of every list have to be decoded.
+    // mode 0: whole lists of the terms [t0, t1); 1: the tile's root range (searched by the plan); 2: a sub-range of the root
+    auto setup_runs = [&](uint32_t mode, uint32_t t0, uint32_t t1, uint32_t tile, uint32_t lo, uint32_t hi) {
+        __syncthreads();
+        if ((uint32_t)tid < k) {
+            uint2 r;
+            if (mode == 0u) r = make_uint2(sm.bof[tid][t0], sm.bof[tid][t1]);
+            else if (mode == 1u) r = p.runs[(uint64_t)tile * k + (uint32_t)tid];
+            else r = blocks_of_range(sm.skp[tid], sm.RR0[tid], sm.RR1[tid], lo, hi);
+            if (mode != 2u) { sm.RR0[tid] = r.x; sm.RR1[tid] = r.y; }
+            sm.R0[tid] = r.x;
+            sm.RB[tid] = r.y - r.x;            // (count; scanned below)
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t c = (uint32_t)l < k ? sm.RB[l] : 0u;
+            const uint32_t incl = wave_incl_scan(c);
+            if ((uint32_t)l < k) sm.RB[l] = incl - c;
+            if (l == 63) sm.RB[k] = incl;
+            if (l == 0) { sm.fill = 0u; sm.ovf = 0u; }
+        }
+        __syncthreads();
+    };
 
-        // ---- steps D-F on a loaded range: copy the runs into LDS, fold them, dedupe + tombstones + compact.
-        // Survivors land in sm.vals[*outbuf][0..return) (*outbuf = 2: in the tag arrays); per-term counts go to out_counts when asked.
-        auto merge_range = [&](uint32_t *outbuf, bool emit_counts, bool atomic_counts) -> uint32_t {
-            const uint32_t n_in = sm.n_in;
-            *outbuf = 0;
-            if (n_in == 0) return 0u;
-            // Single-term tiles whose doc range fits a bitmap in the two value arrays (2 * MCAP words = 262144 docs: terms
-            // with >= 1 posting per 64 docs, a third of a Zipf workload's postings): mark, clear the tombstoned bits word
-            // by word (coalesced loads of exactly the tile's range — no per-posting probe), count, extract.  The union,
-            // the dedupe and the order come for free; ~5x fewer instructions per posting than the bucket fold below.
-            if (p.bitmap_tiles && nt == 1u && k > 1u && sm.vmax - (sm.vmin & ~31u) < 2u * MCAP * 32u) {
-                const uint32_t lo32 = sm.vmin & ~31u;
-                const uint32_t nw = ((sm.vmax - lo32) >> 5) + 1u;                 // <= 2 * MCAP
-                uint32_t *bm = &sm.vals[0][0];                                    // vals[0] and vals[1] are contiguous
-                for (uint32_t i = 4u * (uint32_t)tid; i < nw; i += 4u * MT) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
-                __syncthreads();
-                {   // every wave marks whole runs (run s to wave s mod MW), loads four deep
-                    const uint32_t *RB = sm.runbase[0];
-                    for (uint32_t s2 = (uint32_t)wv; s2 < k; s2 += MW) {
-                        const uint32_t len = RB[s2 + 1u] - RB[s2];
-                        const uint32_t *src = p.raw + sm.rs[s2];
-                        for (uint32_t i0 = 0; i0 < len; i0 += 256u) {
-                            uint32_t v4[4];
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
-                                v4[j] = i < len ? src[i] : 0u;
-                            }
-#pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
-                                if (i < len) atomicOr(&bm[(v4[j] - lo32) >> 5], 1u << (v4[j] & 31u));
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (p.tomb) {     // the tombstone words of exactly this range, coalesced and four in flight per thread
-                    const uint32_t twb = lo32 >> 5;
-                    for (uint32_t i0 = (uint32_t)tid; i0 < nw; i0 += 4u * MT) {
-                        uint32_t t4[4];
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++) {
-                            const uint32_t i = i0 + j * MT;
-                            t4[j] = (i < nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
-                        }
-#pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++)
-                            if (t4[j]) bm[i0 + j * MT] &= ~t4[j];
-                    }
-                    __syncthreads();
-                }
-                II2_STAMP(3)      // D: gather (here: mark, tombstones)
-                // consecutive words per thread, as few as cover the range (a dense tile spans few words: one each).  Two
-                // passes over the thread's own words in LDS instead of sixteen registers: this kernel has none to spare.  The ids go to the tag arrays (4096 words, unused by this path): the
-                // bitmap occupies both value arrays.
-                const uint32_t wpt = (nw + MT - 1u) / MT;                         // 1 .. 16
-                const uint32_t w0 = wpt * (uint32_t)tid;
-                const uint32_t w1 = w0 + wpt < nw ? w0 + wpt : nw;
-                uint32_t cnt = 0;
-#pragma unroll 1
-                for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(bm[w]);
-                uint32_t tot;
-                uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
-                uint32_t *V2 = reinterpret_cast<uint32_t *>(&sm.tids[0][0]);
-#pragma unroll 1
-                for (uint32_t w = w0; w < w1; w++) {
-                    uint32_t x = bm[w];
-                    const uint32_t base = lo32 + 32u * w;
-                    while (x) {
-                        V2[pos++] = base + (uint32_t)__ffs((int)x) - 1u;
-                        x &= x - 1u;
-                    }
-                }
-                *outbuf = 2u;     // (the tag arrays)
-                if (emit_counts && tid == 0 && tot) {
-                    if (atomic_counts) atomicAdd(&p.out_counts[t0], tot);
-                    else p.out_counts[t0] = tot;
-                }
-                __syncthreads();
-                II2_STAMP(1)      // E1: single-term fold (here: tombstones, count, extract)
-                return tot;
-            }
-            // Single-term tiles (the tiles of large terms — most of the postings) are folded by a bucket sort:
-            // a monotone map of the doc id onto NBK buckets, slot inside the bucket from an LDS counter,
-            // then every posting ranks itself among the few that share its bucket.  Docs clustered so that a
-            // bucket overflows BKT_LIMIT send the tile to the pairwise merge below instead.
-            const bool bucketed = nt == 1u && k > 1u;
-            uint32_t *bkt = &sm.offs[0][0];
-            const uint32_t vmin = sm.vmin;
-            const float binv = (float)NBK / ((float)(sm.vmax - vmin) + 1.0f);
-            auto bucket_of = [&](uint32_t v) -> uint32_t {
-                const uint32_t b = (uint32_t)((float)(v - vmin) * binv);
-                return b < NBK - 1u ? b : NBK - 1u;
-            };
-            // ---- D. gather the runs into vals[0] (coalesced inside every run) ----
-            // MCAP = 8 * MT: eight postings per thread, all global loads issued before the first LDS write
-            if (bucketed) {
-                // single-term tile: every wave copies whole runs (run s to wave s mod MW), lane i of the wave the run's
-                // elements i, i + 64, ... — no search for the run an element belongs to, loads four deep
-                const uint32_t *RB = sm.runbase[0];
-                for (uint32_t s2 = (uint32_t)wv; s2 < k; s2 += MW) {
-                    const uint32_t base = RB[s2], len = RB[s2 + 1u] - base;
-                    const uint32_t *src = p.raw + sm.rs[s2];
-                    for (uint32_t i0 = 0; i0 < len; i0 += 256u) {
-                        uint32_t v4[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
-                            v4[j] = i < len ? src[i] : 0u;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
-                            if (i < len) {
-                                sm.vals[0][base + i] = v4[j];
-                                sm.tids[0][base + i] = (uint16_t)atomicAdd(&bkt[bucket_of(v4[j])], 1u);
-                            }
-                        }
-                    }
-                }
-            } else {
-                // batches (and the odd single-run tile): the same wave-by-wave copy of whole runs; the (run, term) tag of
-                // every element comes from markers instead of a search per element — the first element of every
-                // non-empty list gets its tag, and since the tags ascend along the run-major order an inclusive
-                // max-scan over the positions fills in the rest
-                const uint32_t *RB = sm.runbase[0];
-                uint32_t *tg32 = reinterpret_cast<uint32_t *>(&sm.tids[0][0]);
-                for (uint32_t i = (uint32_t)tid; i < (n_in + 1u) / 2u; i += MT) tg32[i] = 0u;
-                __syncthreads();
-                for (uint32_t s2 = (uint32_t)wv; s2 < k; s2 += MW) {
-                    const uint32_t base = RB[s2], len = RB[s2 + 1u] - base;
-                    if (len == 0u) continue;                                   // (wave-uniform)
-                    if (nt > 1u) {
-                        const uint32_t *O = sm.offs[0] + s2 * stride;
-                        for (uint32_t t = (uint32_t)l; t < nt; t += 64u) {
-                            const uint32_t o0 = O[t], o1 = O[t + 1u];
-                            if (o1 > o0) sm.tids[0][base + o0] = (uint16_t)((s2 << 10) | t);
-                        }
-                    } else if (l == 0) sm.tids[0][base] = (uint16_t)(s2 << 10);
-                    const uint32_t *src = p.raw + sm.rs[s2];
-                    for (uint32_t i0 = 0; i0 < len; i0 += 256u) {
-                        uint32_t v4[4];
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
-                            v4[j] = i < len ? src[i] : 0u;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t i = i0 + 64u * (uint32_t)j + (uint32_t)l;
-                            if (i < len) sm.vals[0][base + i] = v4[j];
-                        }
-                    }
-                }
-                __syncthreads();
-                {   // inclusive max-scan of the tags: eight consecutive positions per thread, then across the workgroup
-                    uint4 *tg4 = reinterpret_cast<uint4 *>(&sm.tids[0][0]);
-                    const uint4 q = tg4[tid];
-                    uint32_t g[8] = {q.x & 0xFFFFu, q.x >> 16, q.y & 0xFFFFu, q.y >> 16, q.z & 0xFFFFu, q.z >> 16, q.w & 0xFFFFu, q.w >> 16};
-#pragma unroll
-                    for (int j = 1; j < 8; j++) g[j] = g[j] > g[j - 1] ? g[j] : g[j - 1];
-                    uint32_t m = g[7];                                         // inclusive max over the wave's threads up to mine
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t o = (uint32_t)__shfl_up((int)m, d, 64);
-                        if (l >= d) m = o > m ? o : m;
-                    }
-                    if (l == 63) sm.wmax[wv] = m;
-                    uint32_t before = (uint32_t)__shfl_up((int)m, 1, 64);      // exclusive: the threads before mine in the wave
-                    if (l == 0) before = 0u;
-                    __syncthreads();
-                    for (int w2 = 0; w2 < wv; w2++) before = sm.wmax[w2] > before ? sm.wmax[w2] : before;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) g[j] = g[j] > before ? g[j] : before;
-                    tg4[tid] = make_uint4(g[0] | (g[1] << 16), g[2] | (g[3] << 16), g[4] | (g[5] << 16), g[6] | (g[7] << 16));
-                }
-            }
-            __syncthreads();
-            II2_STAMP(3)      // D: gather
-            // ---- E. fold the runs ----
-            uint32_t cur = 0, nruns = k;
-            bool flagged = false;          // the bucket folds already marked duplicates and tombstoned ids (bit 15 of the tag)
-            if (bucketed) {
-                // exclusive scan of the bucket counters in place (8 per thread) and the fullest bucket
-                uint32_t c[8], sum = 0, mxc = 0;
-                {
-                    const uint4 a4 = *reinterpret_cast<const uint4 *>(&bkt[8u * (uint32_t)tid]);
-                    const uint4 b4 = *reinterpret_cast<const uint4 *>(&bkt[8u * (uint32_t)tid + 4u]);
-                    c[0] = a4.x; c[1] = a4.y; c[2] = a4.z; c[3] = a4.w; c[4] = b4.x; c[5] = b4.y; c[6] = b4.z; c[7] = b4.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) { sum += c[j]; mxc = c[j] > mxc ? c[j] : mxc; }
-                for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mxc, d, 64); mxc = o > mxc ? o : mxc; }
-                if (l == 0) sm.wmax[wv] = mxc;
-                uint32_t tot_;
-                uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
-                mxc = 0;
-                for (int w = 0; w < (int)MW; w++) mxc = sm.wmax[w] > mxc ? sm.wmax[w] : mxc;
-                if (mxc <= BKT_LIMIT) {
-                    uint32_t ex[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { ex[j] = run; run += c[j]; }
-                    *reinterpret_cast<uint4 *>(&bkt[8u * (uint32_t)tid]) = make_uint4(ex[0], ex[1], ex[2], ex[3]);
-                    *reinterpret_cast<uint4 *>(&bkt[8u * (uint32_t)tid + 4u]) = make_uint4(ex[4], ex[5], ex[6], ex[7]);
-                    if (tid == (int)MT - 1) bkt[NBK] = run;
-                    __syncthreads();
-                    // scatter into bucket order
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
-                        if (e < n_in) {
-                            const uint32_t v = sm.vals[0][e];
-                            sm.vals[1][bkt[bucket_of(v)] + sm.tids[0][e]] = v;
-                        }
-                    }
-                    __syncthreads();
-                    // rank inside the bucket (equal ids keep their bucket order: the dedupe below wants them adjacent)
-#pragma unroll 4
-                    for (uint32_t q = (uint32_t)tid; q < n_in; q += MT) {
-                        const uint32_t v = sm.vals[1][q];
-                        const uint32_t b = bucket_of(v);
-                        const uint32_t lo = bkt[b], hi = bkt[b + 1u];
-                        const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
-                        uint32_t r = 0, dup = 0;
-                        {   // the first four of the bucket without a loop (buckets hold one posting on average: lanes that
-                            // loop make the whole wave wait for the fullest bucket among its 64); reading past the bucket
-                            // is harmless (masked), past vals[1] lands in the tag arrays
-                            const uint32_t *B4 = &sm.vals[1][lo];
-                            const uint32_t u0 = B4[0], u1 = B4[1], u2 = B4[2], u3 = B4[3];
-                            const uint32_t nb = hi - lo;
-                            const uint32_t e0 = (u0 == v && lo < q) ? 1u : 0u;
-                            const uint32_t e1 = (nb > 1u && u1 == v && lo + 1u < q) ? 1u : 0u;
-                            const uint32_t e2 = (nb > 2u && u2 == v && lo + 2u < q) ? 1u : 0u;
-                            const uint32_t e3 = (nb > 3u && u3 == v && lo + 3u < q) ? 1u : 0u;
-                            r = (u0 < v ? 1u : 0u) + ((nb > 1u && u1 < v) ? 1u : 0u) + ((nb > 2u && u2 < v) ? 1u : 0u) + ((nb > 3u && u3 < v) ? 1u : 0u) +
-                                e0 + e1 + e2 + e3;
-                            dup = e0 | e1 | e2 | e3;
-                        }
-                        for (uint32_t m = lo + 4u; m < hi; m++) {
-                            const uint32_t u = sm.vals[1][m];
-                            const uint32_t eq = (u == v && m < q) ? 1u : 0u;
-                            r += (u < v ? 1u : 0u) + eq;
-                            dup |= eq;
-                        }
-                        sm.vals[0][lo + r] = v;
-                        uint32_t dead = dup;
-                        if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
-                        sm.tids[0][lo + r] = (uint16_t)(dead << 15);   // dead: duplicate or tombstoned
-                    }
-                    __syncthreads();
-                    nruns = 1u;
-                    flagged = true;
-                    II2_STAMP(1)      // E1: bucket fold
-                }
-            }
-            // Batches of several terms: the same bucket sort with one bucket per posting, shared out among the
-            // terms in proportion to their sizes — term t owns buckets [ttb[t], ttb[t+1]) (= its positions
-            // after the fold) and maps its own doc range onto them, so the bucket order is the (term, doc) order.
-            if (nt > 1u && k > 1u && nt <= MT) {
-                const uint32_t *O = sm.offs[0];
-                const uint32_t *RB = sm.runbase[0];
-                uint32_t *c32 = &sm.offs[1][0];                 // two 16-bit counters per word
-                {
-                    uint32_t n_t = 0, mn = 0xFFFFFFFFu, mx = 0u;
-                    if ((uint32_t)tid < nt) {
-                        for (uint32_t r = 0; r < k; r++) {
-                            const uint32_t o0 = O[r * stride + (uint32_t)tid], o1 = O[r * stride + (uint32_t)tid + 1u];
-                            if (o1 > o0) {
-                                n_t += o1 - o0;
-                                const uint32_t f = sm.vals[0][RB[r] + o0], la = sm.vals[0][RB[r] + o1 - 1u];
-                                mn = f < mn ? f : mn;
-                                mx = la > mx ? la : mx;
-                            }
-                        }
-                    }
-                    uint32_t tot_;
-                    const uint32_t tb = block_excl_scan(n_t, sm.wsum, &tot_);
-                    if ((uint32_t)tid < nt) {
-                        sm.ttb[tid] = (uint16_t)tb;
-                        sm.tterm[tid] = make_uint2(mn, __float_as_uint(n_t ? (float)n_t / ((float)(mx - mn) + 1.0f) : 0.0f));
-                    }
-                    if (tid == 0) sm.ttb[nt] = (uint16_t)n_in;
-                    __syncthreads();
-                }
-                auto bucket_mt = [&](uint32_t t, uint32_t v) -> uint32_t {
-                    const uint32_t tb = sm.ttb[t], nb = sm.ttb[t + 1u] - tb;
-                    const uint2 te = sm.tterm[t];
-                    const uint32_t b = (uint32_t)((float)(v - te.x) * __uint_as_float(te.y));
-                    return tb + (b < nb - 1u ? b : nb - 1u);
-                };
-                auto base_of = [&](uint32_t b) -> uint32_t { return (c32[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu; };
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
-                    if (e < n_in) {
-                        const uint32_t t = sm.tids[0][e] & 1023u;
-                        const uint32_t b = bucket_mt(t, sm.vals[0][e]);
-                        const uint32_t sh = 16u * (b & 1u);
-                        uint32_t slot = (atomicAdd(&c32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                        slot = slot < 15u ? slot : 15u;           // a fuller bucket sends the tile to the pairwise fold anyway
-                        // from here on an element is known by its bucket (12 bits; the bucket implies the term): the
-                        // flagged fold below and step F need no term tag, so the bucket is computed once
-                        sm.tids[0][e] = (uint16_t)((slot << 12) | b);
-                    }
-                }
-                __syncthreads();
-                // exclusive scan of the counters in place (8 per thread) and the fullest bucket
-                uint32_t c[8], sum = 0, mxc = 0;
-                {
-                    const uint4 w4 = reinterpret_cast<const uint4 *>(c32)[tid];
-                    c[0] = w4.x & 0xFFFFu; c[1] = w4.x >> 16; c[2] = w4.y & 0xFFFFu; c[3] = w4.y >> 16;
-                    c[4] = w4.z & 0xFFFFu; c[5] = w4.z >> 16; c[6] = w4.w & 0xFFFFu; c[7] = w4.w >> 16;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) { sum += c[j]; mxc = c[j] > mxc ? c[j] : mxc; }
-                for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mxc, d, 64); mxc = o > mxc ? o : mxc; }
-                if (l == 0) sm.wmax[wv] = mxc;
-                uint32_t tot_;
-                uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
-                mxc = 0;
-                for (int w = 0; w < (int)MW; w++) mxc = sm.wmax[w] > mxc ? sm.wmax[w] : mxc;
-                if (mxc <= BKT_LIMIT_MT) {
-                    uint32_t ex[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) { ex[j] = run; run += c[j]; }
-                    reinterpret_cast<uint4 *>(c32)[tid] = make_uint4(ex[0] | (ex[1] << 16), ex[2] | (ex[3] << 16), ex[4] | (ex[5] << 16), ex[6] | (ex[7] << 16));
-                    __syncthreads();
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const uint32_t e = (uint32_t)tid + (uint32_t)j * MT;
-                        if (e < n_in) {
-                            const uint32_t v = sm.vals[0][e];
-                            const uint32_t tag = sm.tids[0][e];
-                            const uint32_t dst = base_of(tag & 4095u) + (tag >> 12);
-                            sm.vals[1][dst] = v;
-                            sm.tids[1][dst] = (uint16_t)(tag & 4095u);
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll 4
-                    for (uint32_t q = (uint32_t)tid; q < n_in; q += MT) {
-                        const uint32_t v = sm.vals[1][q];
-                        const uint32_t b = sm.tids[1][q];
-                        const uint32_t lo = base_of(b), hi = b + 1u < MCAP ? base_of(b + 1u) : n_in;
-                        const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the loop
-                        uint32_t r = 0, dup = 0;
-                        {   // the first four of the bucket without a loop (buckets hold one posting on average: lanes that
-                            // loop make the whole wave wait for the fullest bucket among its 64); reading past the bucket
-                            // is harmless (masked), past vals[1] lands in the tag arrays
-                            const uint32_t *B4 = &sm.vals[1][lo];
-                            const uint32_t u0 = B4[0], u1 = B4[1], u2 = B4[2], u3 = B4[3];
-                            const uint32_t nb = hi - lo;
-                            const uint32_t e0 = (u0 == v && lo < q) ? 1u : 0u;
-                            const uint32_t e1 = (nb > 1u && u1 == v && lo + 1u < q) ? 1u : 0u;
-                            const uint32_t e2 = (nb > 2u && u2 == v && lo + 2u < q) ? 1u : 0u;
-                            const uint32_t e3 = (nb > 3u && u3 == v && lo + 3u < q) ? 1u : 0u;
-                            r = (u0 < v ? 1u : 0u) + ((nb > 1u && u1 < v) ? 1u : 0u) + ((nb > 2u && u2 < v) ? 1u : 0u) + ((nb > 3u && u3 < v) ? 1u : 0u) +
-                                e0 + e1 + e2 + e3;
-                            dup = e0 | e1 | e2 | e3;
-                        }
-                        for (uint32_t m = lo + 4u; m < hi; m++) {
-                            const uint32_t u = sm.vals[1][m];
-                            const uint32_t eq = (u == v && m < q) ? 1u : 0u;
-                            r += (u < v ? 1u : 0u) + eq;
-                            dup |= eq;
-                        }
-                        sm.vals[0][lo + r] = v;
-                        uint32_t dead = dup;
-                        if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
-                        sm.tids[0][lo + r] = (uint16_t)(dead << 15);         // bit 15: duplicate or tombstoned
-                    }
-                    __syncthreads();
-                    nruns = 1u;
-                    flagged = true;
-                } else {
-                    // clustered docs: back to (run, term) tags for the pairwise fold
-                    __syncthreads();
-                    for (uint32_t e = (uint32_t)tid; e < n_in; e += MT) {
-                        uint32_t sa = 0, sb = k;
-                        while (sb - sa > 1u) { const uint32_t sm_ = (sa + sb) >> 1; if (RB[sm_] <= e) sa = sm_; else sb = sm_; }
-                        const uint32_t i = e - RB[sa];
-                        const uint32_t *Os = O + sa * stride;
-                        uint32_t ta = 0, tb2 = nt;
-                        while (tb2 - ta > 1u) { const uint32_t tm = (ta + tb2) >> 1; if (Os[tm] <= i) ta = tm; else tb2 = tm; }
-                        sm.tids[0][e] = (uint16_t)((sa << 10) | ta);
-                    }
-                    __syncthreads();
-                }
-            }
-            // One term in the tile (the tiles of large terms — most of the postings): plain two-way merges.
-            // Each thread produces a few consecutive outputs: one merge-path search to find where its
-            // chunk starts in the two runs, then a sequential merge (A first on ties) — a handful of
-            // instructions per posting and level instead of a binary search per posting.
-            while (nt == 1u && nruns > 1u) {
-                const uint32_t *V = sm.vals[cur];
-                const uint32_t *RB = sm.runbase[cur];
-                uint32_t *V2 = sm.vals[cur ^ 1u];
-                const uint32_t npairs = (nruns + 1u) >> 1;
-                const uint32_t VT = (n_in + MT - 1u) / MT;
-                uint32_t o = (uint32_t)tid * VT;
-                const uint32_t oe = o + VT < n_in ? o + VT : n_in;
-                while (o < oe) {
-                    uint32_t ja = 0, jb = npairs;             // pair j with RB[2j] <= o < RB[2j+2]
-                    while (jb - ja > 1u) { const uint32_t jm = (ja + jb) >> 1; if (RB[2u * jm] <= o) ja = jm; else jb = jm; }
-                    const uint32_t ra = 2u * ja, rb = ra + 1u;
-                    const uint32_t abase = RB[ra], bbase = RB[rb];
-                    const uint32_t la = bbase - abase;
-                    const uint32_t lb = rb < nruns ? RB[rb + 1u] - bbase : 0u;
-                    const uint32_t *A = V + abase, *B = V + bbase;
-                    const uint32_t d = o - abase;
-                    uint32_t lo = d > lb ? d - lb : 0u, hi = d < la ? d : la;
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (A[mid] <= B[d - 1u - mid]) lo = mid + 1u; else hi = mid;
-                    }
-                    uint32_t ia = lo, ib = d - lo;
-                    const uint32_t pend = abase + la + lb;
-                    const uint32_t stop = oe < pend ? oe : pend;
-                    uint32_t va = ia < la ? A[ia] : 0u, vb = ib < lb ? B[ib] : 0u;
-                    for (; o < stop; o++) {
-                        const bool takeA = ib >= lb || (ia < la && va <= vb);
-                        V2[o] = takeA ? va : vb;
-                        if (takeA) { ia++; va = ia < la ? A[ia] : 0u; }
-                        else { ib++; vb = ib < lb ? B[ib] : 0u; }
-                    }
-                }
-                __syncthreads();
-                uint32_t *RB2 = sm.runbase[cur ^ 1u];
-                for (uint32_t r2 = (uint32_t)tid; r2 <= npairs; r2 += MT) RB2[r2] = r2 < npairs ? RB[2u * r2] : n_in;
-                __syncthreads();
-                cur ^= 1u;
-                nruns = npairs;
-            }
-            II2_STAMP(2)      // E2: pairwise merge of a single term (bucket overflow)
-            while (nruns > 1u) {
-                const uint32_t *V = sm.vals[cur];
-                const uint16_t *T = sm.tids[cur];
-                const uint32_t *O = sm.offs[cur];
-                const uint32_t *RB = sm.runbase[cur];
-                uint32_t *V2 = sm.vals[cur ^ 1u];
-                uint16_t *T2 = sm.tids[cur ^ 1u];
-                for (uint32_t e = (uint32_t)tid; e < n_in; e += MT) {
-                    const uint32_t v = V[e];
-                    const uint32_t tag = T[e];
-                    const uint32_t r = tag >> 10, t = tag & 1023u;
-                    const uint32_t ro = r ^ 1u;
-                    const uint32_t myoff = O[r * stride + t];
-                    const uint32_t i = e - RB[r] - myoff;
-                    uint32_t rank = 0, poff = 0;
-                    if (ro < nruns) {
-                        poff = O[ro * stride + t];
-                        const uint32_t plen = O[ro * stride + t + 1u] - poff;
-                        const uint32_t *P = V + RB[ro] + poff;
-                        uint32_t a = 0, b = plen;
-                        if (r & 1u) {            // odd run: count partner elements <= v
-                            while (a < b) { const uint32_t mid = (a + b) >> 1; if (P[mid] <= v) a = mid + 1u; else b = mid; }
-                        } else {                 // even run: count partner elements < v
-                            while (a < b) { const uint32_t mid = (a + b) >> 1; if (P[mid] < v) a = mid + 1u; else b = mid; }
-                        }
-                        rank = a;
-                    }
-                    const uint32_t dst = RB[r & ~1u] + myoff + poff + i + rank;
-                    V2[dst] = v;
-                    T2[dst] = (uint16_t)(((r >> 1) << 10) | t);
-                }
-                __syncthreads();
-                const uint32_t nr2 = (nruns + 1u) >> 1;
-                uint32_t *O2 = sm.offs[cur ^ 1u];
-                uint32_t *RB2 = sm.runbase[cur ^ 1u];
-                for (uint32_t e = (uint32_t)tid; e < nr2 * stride; e += MT) {
-                    const uint32_t r2 = e / stride, t = e % stride;
-                    const uint32_t ra = 2u * r2, rb = ra + 1u;
-                    O2[e] = O[ra * stride + t] + (rb < nruns ? O[rb * stride + t] : 0u);
-                }
-                for (uint32_t r2 = (uint32_t)tid; r2 <= nr2; r2 += MT) RB2[r2] = r2 < nr2 ? RB[2u * r2] : n_in;
-                __syncthreads();
-                cur ^= 1u;
-                nruns = nr2;
-            }
-            II2_STAMP(4)      // E: fold
-            // ---- F. dedupe, tombstones, compact ----
-            const uint32_t *V = sm.vals[cur];
-            const uint16_t *T = sm.tids[cur];
-            uint32_t *V2 = sm.vals[cur ^ 1u];
-            uint16_t *T2 = sm.tids[cur ^ 1u];
-            // eight consecutive postings per thread (MCAP = 8 * MT), read as vectors; the tombstone words
-            // of all eight are fetched before any is tested
-            const uint32_t a = 8u * (uint32_t)tid;
-            uint32_t fv[8], ft[8];
-            uint32_t keepmask = 0, cnt = 0;
-            if (a < n_in && flagged) {
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(&V[a]), v1 = *reinterpret_cast<const uint4 *>(&V[a + 4u]);
-                fv[0] = v0.x; fv[1] = v0.y; fv[2] = v0.z; fv[3] = v0.w; fv[4] = v1.x; fv[5] = v1.y; fv[6] = v1.z; fv[7] = v1.w;
-                const uint4 t4 = *reinterpret_cast<const uint4 *>(&T[a]);
-                // bit 15 of every 16-bit tag -> one bit per posting
-                const uint32_t dead = ((t4.x >> 15) & 1u) | ((t4.x >> 30) & 2u) | (((t4.y >> 15) & 1u) << 2) | (((t4.y >> 30) & 2u) << 2) |
-                                      (((t4.z >> 15) & 1u) << 4) | (((t4.z >> 30) & 2u) << 4) | (((t4.w >> 15) & 1u) << 6) | (((t4.w >> 30) & 2u) << 6);
-                const uint32_t have = n_in - a >= 8u ? 0xFFu : ((1u << (n_in - a)) - 1u);
-                keepmask = ~dead & have;
-                cnt = (uint32_t)__popc(keepmask);
-#pragma unroll
-                for (int j = 0; j < 8; j++) ft[j] = 0;
-            } else if (a < n_in) {
-                const uint4 v0 = *reinterpret_cast<const uint4 *>(&V[a]), v1 = *reinterpret_cast<const uint4 *>(&V[a + 4u]);
-                fv[0] = v0.x; fv[1] = v0.y; fv[2] = v0.z; fv[3] = v0.w; fv[4] = v1.x; fv[5] = v1.y; fv[6] = v1.z; fv[7] = v1.w;
-                uint32_t pv = a ? V[a - 1u] : ~fv[0], pt = 0;
-                if (nt > 1u) {
-                    const uint4 t4 = *reinterpret_cast<const uint4 *>(&T[a]);
-                    ft[0] = t4.x & 1023u; ft[1] = (t4.x >> 16) & 1023u; ft[2] = t4.y & 1023u; ft[3] = (t4.y >> 16) & 1023u;
-                    ft[4] = t4.z & 1023u; ft[5] = (t4.z >> 16) & 1023u; ft[6] = t4.w & 1023u; ft[7] = (t4.w >> 16) & 1023u;
-                    pt = a ? (T[a - 1u] & 1023u) : 0u;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) ft[j] = 0;
-                }
-                uint32_t tw[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const uint32_t w = fv[j] >> 5;
-                    tw[j] = 0u;
-                    if (p.tomb && a + (uint32_t)j < n_in && w < p.tomb_nwords && ((p.tomb_summary[fv[j] >> 9] >> ((fv[j] >> 4) & 31u)) & 1u)) tw[j] = p.tomb[w];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const bool dup = fv[j] == pv && ft[j] == pt && (a + (uint32_t)j) > 0u;
-                    const bool keep = a + (uint32_t)j < n_in && !dup && !((tw[j] >> (fv[j] & 31u)) & 1u);
-                    if (keep) { keepmask |= 1u << j; cnt++; }
-                    pv = fv[j];
-                    pt = ft[j];
-                }
+    // ---- decode the runs' blocks; every posting with lo <= id <= hi goes
+    //   BM = false: to sm.u.s.V[arrival order] (and its term slot to TG when the tile is a batch),
+    //   BM = true:  into the bitmap of the range (bit id - lo32).
+    // A chunk = as many consecutive blocks (one per thread) as have PCAP 16-byte payload pieces between them; a thread then
+    // walks one piece: the 16 partial gap sums and which bytes end a posting; a scan over the chunk's pieces gives every
+    // piece the sum before it, and the difference to its block's first piece the id it starts from.
+    auto decode = [&](auto bm_tag, uint32_t lo, uint32_t hi, uint32_t lo32, bool batch, uint32_t t0, uint32_t nt, bool filter) {
+        constexpr bool BM = decltype(bm_tag)::value;
+        const uint32_t NB = sm.RB[k];
+        uint32_t g0 = 0;
+        while (g0 < NB) {
+            __syncthreads();                     // the chunk before is done with the tables
+            const uint32_t g = g0 + (uint32_t)tid;
+            const bool valid = g < NB;
+            uint32_t s = 0, np = 0, first = 0, q0 = 0, ti = 0, len = 0;
+            if (valid) {
+                uint32_t a = 0, e = k;            // RB[a] <= g < RB[e]
+                while (e - a > 1u) { const uint32_t m = (a + e) >> 1; if (sm.RB[m] <= g) a = m; else e = m; }
+                s = a;
+                const uint32_t b = sm.R0[s] + (g - sm.RB[s]);
+                const ii2_skip *sk = sm.skp[s];
+                const ii2_skip e0 = sk[b];
+                first = e0.first_doc;
+                q0 = e0.byte_off;
+                len = sk[b + 1u].byte_off - q0;
+                if (len > 1280u) len = 1280u;     // (a block holds <= 256 postings of <= 5 bytes; imported segments are validated)
+                np = (len + 15u) >> 4;
+                if (batch) { ti = sm.bls[s][b] - sm.lbase[s] - t0; ti = ti < nt ? ti : nt - 1u; }
             }
             uint32_t tot;
-            uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
-            const uint32_t pos0 = pos;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                if ((keepmask >> j) & 1u) { V2[pos] = fv[j]; if (!flagged) T2[pos] = (uint16_t)ft[j]; pos++; }
+            const uint32_t pex = block_excl_scan(np, sm.wsum, &tot);
+            const bool ok = valid && pex + np <= PCAP;          // a prefix of the threads (pex ascends); never empty (np <= 80)
+            const uint32_t nchunk = (uint32_t)__syncthreads_count(ok ? 1 : 0);
+            if (ok) {
+                sm.x.d.BF[tid] = first;
+                sm.x.d.BQ[tid] = q0;
+                sm.x.d.BI[tid] = s | (ti << 6) | (len << 15);
+                sm.x.d.PB[tid] = (uint16_t)pex;
+                if ((uint32_t)tid == nchunk - 1u) sm.tp = pex + np;
             }
-            *outbuf = cur ^ 1u;
-            if (emit_counts && nt == 1u) {
-                if (tid == 0 && tot) {
-                    if (atomic_counts) atomicAdd(&p.out_counts[t0], tot);
-                    else p.out_counts[t0] = tot;
-                }
-            } else if (emit_counts && flagged) {
-                // term t sat at [ttb[t], ttb[t+1]) before the compaction: survivors = difference of the keep prefix there
-                uint2 *kp = reinterpret_cast<uint2 *>(&sm.offs[0][0]);
-                kp[tid] = make_uint2(pos0, keepmask);
-                __syncthreads();
-                if ((uint32_t)tid < nt) {
-                    auto kept_before = [&](uint32_t x) -> uint32_t {
-                        if (x >= MCAP) return tot;
-                        const uint2 e = kp[x >> 3];
-                        return e.x + (uint32_t)__popc(e.y & ((1u << (x & 7u)) - 1u));
-                    };
-                    const uint32_t c = kept_before(sm.ttb[tid + 1]) - kept_before(sm.ttb[tid]);
-                    if (c) {
-                        if (atomic_counts) atomicAdd(&p.out_counts[t0 + (uint32_t)tid], c);
-                        else p.out_counts[t0 + (uint32_t)tid] = c;
-                    }
-                }
-            } else if (emit_counts) {
-                // per-term survivor counts from the boundaries of the compacted array
-                uint32_t *tstart = sm.offs[0], *tend = sm.offs[1];
-                __syncthreads();
-                for (uint32_t t = (uint32_t)tid; t < nt; t += MT) { tstart[t] = 0; tend[t] = 0; }
-                __syncthreads();
-                for (uint32_t q = (uint32_t)tid; q < tot; q += MT) {
-                    const uint32_t t = T2[q];
-                    if (q == 0 || T2[q - 1] != t) tstart[t] = q;
-                    if (q + 1u == tot || T2[q + 1] != t) tend[t] = q + 1u;
-                }
-                __syncthreads();
-                for (uint32_t t = (uint32_t)tid; t < nt; t += MT) {
-                    const uint32_t c = tend[t] - tstart[t];
-                    if (c) {
-                        if (atomic_counts) atomicAdd(&p.out_counts[t0 + t], c);
-                        else p.out_counts[t0 + t] = c;
+            {   // the blocks' first postings (their ids are in the skip entries)
+                const bool in = ok && first >= lo && first <= hi;
+                if (BM) {
+                    if (in) atomicOr(&sm.u.bm[(first - lo32) >> 5], 1u << (first & 31u));
+                } else {
+                    const unsigned long long m = __ballot(in);
+                    if (m != 0ull) {
+                        uint32_t wb = 0;
+                        if (l == 0) wb = atomicAdd(&sm.fill, (uint32_t)__popcll(m));
+                        wb = wave_bcast(wb, 0);
+                        const uint32_t pos = wb + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+                        if (in && pos < MCAP) { sm.u.s.V[pos] = first; if (batch) sm.u.s.TG[pos] = (uint16_t)ti; }
                     }
                 }
             }
             __syncthreads();
-            II2_STAMP(5)      // F: dedupe / filter / compact / counts
-            return tot;
-        };
-
-        const uint32_t dlo = td.z, dhi = td.w;
-        const bool root_full = dlo == 0u && dhi == 0xFFFFFFFFu;
-        // The tile parks its survivors in the scratch array at the input rank of its first posting
-        // (term slots start at the prefix of the terms' input counts), which no other tile can reach:
-        // survivors never outnumber the inputs that precede the next tile.  A later pass packs them.
-        // (Tried in round 2: writing survivors straight to their final place through a chained scan over the tiles — with
-        // ~500 tiles in flight every tile waits for its slowest predecessor; the scan + write-out took 61 % of a workgroup's
-        // time and the merge went from 4.3 to 7.3 ms.  Tiles must stay independent.)
-        const unsigned long long term_slot = p.ub_prefix[t0];
-        unsigned long long slot = term_slot;
-        uint32_t total = 0;
-        if (dlo <= dhi) {
-            uint32_t outbuf = 0;
-            const bool fits = load_range(dlo, dhi, true);
-            slot = term_slot + sm.rank;                  // rank of the range start (0 for whole-term tiles)
-            if (fits) {
-                // range tiles of a large term leave its count to k_merge_large_counts: an atomicAdd per tile would put
-                // thousands of same-address device atomics in flight (the top terms own most tiles)
-                total = merge_range(&outbuf, root_full, false);
-                const uint32_t *V = outbuf == 2u ? reinterpret_cast<const uint32_t *>(&sm.tids[0][0]) : sm.vals[outbuf];
-                for (uint32_t q = (uint32_t)tid; q < total; q += MT) p.tmp[slot + q] = V[q];
-            } else {
-                // the range holds more than LDS (a term whose lists are clustered differently): bisect the
-                // doc range; leaves are handled in doc order and appended to the tile's slot.
-                uint32_t sp = 1;
-                __syncthreads();
-                if (tid == 0) { sm.stk[0][0] = dlo; sm.stk[0][1] = dhi; }
-                while (sp > 0) {
-                    __syncthreads();
-                    const uint32_t lo = sm.stk[sp - 1][0], hi = sm.stk[sp - 1][1];
-                    sp--;
-                    if (!load_range(lo, hi, false)) {
-                        // lo < hi here: a single doc id never exceeds k postings
-                        const uint32_t mid = lo + ((hi - lo) >> 1);
-                        __syncthreads();
-                        if (tid == 0) {
-                            sm.stk[sp][0] = mid + 1u; sm.stk[sp][1] = hi;
-                            sm.stk[sp + 1][0] = lo;   sm.stk[sp + 1][1] = mid;
+            const uint32_t tp = sm.tp;
+            uint32_t carry = 0;
+            for (uint32_t it = 0; it < tp; it += MT) {
+                const uint32_t pc = it + (uint32_t)tid;
+                const bool pv = pc < tp;
+                uint32_t jb = 0, val[16], tmask = 0, bi = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) val[i] = 0;
+                if (pv) {
+                    uint32_t a = 0, e = nchunk;   // last block with PB <= pc (blocks without payload share their successor's PB)
+                    while (e - a > 1u) { const uint32_t m = (a + e) >> 1; if ((uint32_t)sm.x.d.PB[m] <= pc) a = m; else e = m; }
+                    jb = a;
+                    bi = sm.x.d.BI[jb];
+                    const uint32_t off = 16u * (pc - (uint32_t)sm.x.d.PB[jb]);
+                    const uint32_t blen = bi >> 15;
+                    const uint32_t nb = blen - off < 16u ? blen - off : 16u;
+                    const uint8_t *pp = sm.pay[bi & 63u] + sm.x.d.BQ[jb] + off;
+                    uint4 w4;
+                    __builtin_memcpy(&w4, pp, 16);                        // (segments carry 16 bytes of padding)
+                    const uint32_t prev = off ? load_u32_unaligned(pp - 4) : 0u;
+                    uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+                    if (nb < 16u) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t nj = nb > 4u * j ? (nb - 4u * j < 4u ? nb - 4u * j : 4u) : 0u;
+                            w[j] &= nj >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nj)) - 1u);
                         }
-                        sp += 2;
-                        continue;
                     }
-                    uint32_t ob2 = 0;
-                    const uint32_t c = merge_range(&ob2, nt > 1u, true);       // single-term leaves: counted from the tile totals
-                    const uint32_t *V = ob2 == 2u ? reinterpret_cast<const uint32_t *>(&sm.tids[0][0]) : sm.vals[ob2];
-                    for (uint32_t q = (uint32_t)tid; q < c; q += MT) p.tmp[slot + total + q] = V[q];
-                    total += c;
+                    // continuation bytes pending right before my first byte (varints are <= 5 bytes)
+                    uint32_t sh = 7u * ((uint32_t)__clz((int)~(prev | 0x7F7F7F7Fu)) >> 3);
+                    uint32_t sum = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                        sum += (c & 0x7Fu) << sh;
+                        if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
+                        else { sh = 0u; tmask |= 1u << i; }
+                        val[i] = sum;
+                    }
+                    tmask &= (1u << nb) - 1u;
+                }
+                uint32_t tots;
+                const uint32_t pex2 = carry + block_excl_scan(val[15], sm.wsum, &tots);
+                carry += tots;
+                if (pv) sm.x.d.PX[pc] = pex2;
+                __syncthreads();
+                if (pv) {
+                    const uint32_t base = sm.x.d.BF[jb] + pex2 - sm.x.d.PX[sm.x.d.PB[jb]];
+                    if (BM) {
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const uint32_t id = base + val[i];
+                            if (((tmask >> i) & 1u) && id >= lo && id <= hi) atomicOr(&sm.u.bm[(id - lo32) >> 5], 1u << (id & 31u));
+                        }
+                    } else if (filter) {
+                        uint32_t im = 0;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const uint32_t id = base + val[i];
+                            if (id >= lo && id <= hi) im |= 1u << i;
+                        }
+                        tmask &= im;
+                    }
+                }
+                if (!BM) {
+                    const uint32_t c = (uint32_t)__popc(tmask);
+                    const uint32_t incl = wave_incl_scan(c);
+                    const uint32_t wtot = wave_bcast(incl, 63);
+                    if (wtot) {
+                        uint32_t wb = 0;
+                        if (l == 0) wb = atomicAdd(&sm.fill, wtot);
+                        wb = wave_bcast(wb, 0);
+                        uint32_t pos = wb + incl - c;
+                        if (wb + wtot <= MCAP) {
+                            const uint32_t base = pv ? sm.x.d.BF[jb] + pex2 - sm.x.d.PX[sm.x.d.PB[jb]] : 0u;
+                            const uint16_t tg = (uint16_t)((bi >> 6) & 511u);
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                if ((tmask >> i) & 1u) {
+                                    sm.u.s.V[pos] = base + val[i];
+                                    if (batch) sm.u.s.TG[pos] = tg;
+                                    pos++;
+                                }
+                            }
+                        }       // else: the range holds more than LDS; the caller sees fill > MCAP and splits it
+                    }
                 }
             }
+            g0 += nchunk;
         }
-        if (tid == 0) { p.tile_count[tile] = total; p.tile_slot[tile] = slot; }
         __syncthreads();
-        II2_STAMP(6)          // G: park survivors
+    };
+
+    // ---- sort the decoded postings of [lo, hi] (terms [t0, t0 + nt)) by buckets and write the survivors to `out` in
+    // (term, id) order.  Returns false when the range has to be split (more postings than LDS, or clustered ids that
+    // overflow a bucket) — nothing was written then.  alloc(n) is called once, by every thread, with the survivor count,
+    // before anything is written, and returns where they go.  Batches also store per-term survivor counts.
+    auto sort_range = [&](uint32_t lo, uint32_t hi, bool batch, uint32_t t0, uint32_t nt, auto alloc, uint32_t *n_out) -> bool {
+        const uint32_t n = sm.fill;
+        *n_out = 0;
+        if (n > MCAP) return false;
+        uint32_t *C32 = sm.u.s.C32;
+        for (uint32_t i = (uint32_t)tid; i < MCAP / 2u + 4u; i += MT) C32[i] = 0u;
+        if ((uint32_t)tid < MCAP / 32u + 1u) sm.x.f.DB[tid] = 0u;
+        // bucket maps: term t of a batch owns floor(n_t * MCAP / n) buckets, a range tile all MCAP of them
+        uint32_t u_mn = 0, u_nbm1 = 0;
+        float u_scale = 0.0f;
+        if (batch) {
+            uint32_t nbk = 0, mn = 0, mx = 0;
+            if ((uint32_t)tid < nt) {
+                const uint32_t n_t = p.tn[t0 + (uint32_t)tid];
+                mn = p.tmin[t0 + (uint32_t)tid];
+                mx = p.tmax[t0 + (uint32_t)tid];
+                nbk = n_t ? (uint32_t)(((uint64_t)n_t * MCAP) / n) : 0u;
+            }
+            uint32_t totb;
+            const uint32_t tb = block_excl_scan(nbk, sm.wsum, &totb);
+            if ((uint32_t)tid < nt) {
+                sm.x.f.TB[tid] = (uint16_t)tb;
+                sm.x.f.TT[tid] = make_uint2(mn, __float_as_uint(nbk ? (float)nbk / ((float)(mx - mn) + 1.0f) : 0.0f));
+            }
+            if (tid == 0) sm.x.f.TB[nt] = (uint16_t)totb;
+        } else {
+            const uint32_t t_mn = p.tmin[t0], t_mx = p.tmax[t0];
+            u_mn = lo > t_mn ? lo : t_mn;
+            const uint32_t mxr = hi < t_mx ? hi : t_mx;
+            u_nbm1 = MCAP - 1u;
+            u_scale = (float)MCAP / ((float)((mxr > u_mn ? mxr : u_mn) - u_mn) + 1.0f);
+        }
+        __syncthreads();
+        // ---- bucket of every posting, slot inside the bucket
+        unsigned long long slots = 0ull;
+        bool over = false;
+#pragma unroll
+        for (uint32_t j = 0; j < EPT; j++) {
+            const uint32_t i = (uint32_t)tid + j * MT;
+            if (i < n) {
+                const uint32_t v = sm.u.s.V[i];
+                uint32_t mn = u_mn, nbm1 = u_nbm1, tb = 0;
+                float sc = u_scale;
+                if (batch) {
+                    const uint32_t ti = sm.u.s.TG[i];
+                    const uint2 te = sm.x.f.TT[ti];
+                    tb = sm.x.f.TB[ti];
+                    nbm1 = (uint32_t)sm.x.f.TB[ti + 1u] - tb - 1u;
+                    mn = te.x;
+                    sc = __uint_as_float(te.y);
+                }
+                const uint32_t bq = (uint32_t)((float)(v - mn) * sc);
+                const uint32_t b = tb + (bq < nbm1 ? bq : nbm1);
+                sm.u.s.TG[i] = (uint16_t)b;
+                const uint32_t sh = 16u * (b & 1u);
+                uint32_t slot = (atomicAdd(&C32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                if (slot > BKT_LIMIT) { over = true; slot = BKT_LIMIT; }
+                slots |= (unsigned long long)slot << (4u * j);
+            }
+        }
+        if (over) sm.ovf = 1u;
+        __syncthreads();
+        if (sm.ovf) return false;
+        // ---- exclusive scan of the counters in place: EPT buckets = EPT / 2 words per thread
+        {
+            uint32_t c[EPT], sum = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < EPT / 2u; j++) {
+                const uint32_t w = C32[(EPT / 2u) * (uint32_t)tid + j];
+                c[2u * j] = w & 0xFFFFu;
+                c[2u * j + 1u] = w >> 16;
+                sum += c[2u * j] + c[2u * j + 1u];
+            }
+            uint32_t tot_;
+            uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
+#pragma unroll
+            for (uint32_t j = 0; j < EPT / 2u; j++) {
+                const uint32_t e0 = run;
+                run += c[2u * j];
+                const uint32_t e1 = run;
+                run += c[2u * j + 1u];
+                C32[(EPT / 2u) * (uint32_t)tid + j] = e0 | (e1 << 16);
+            }
+            if (tid == (int)MT - 1) C32[MCAP / 2u] = run;        // base of the bucket past the last one
+        }
+        __syncthreads();
+        auto base_of = [&](uint32_t b) -> uint32_t { return (C32[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu; };
+        // ---- scatter into bucket order (in place: all reads, then all writes)
+        {
+            uint32_t v[EPT], pk[EPT];
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) {
+                const uint32_t i = (uint32_t)tid + j * MT;
+                v[j] = 0; pk[j] = 0;
+                if (i < n) {
+                    v[j] = sm.u.s.V[i];
+                    const uint32_t b = sm.u.s.TG[i];
+                    pk[j] = (base_of(b) + (uint32_t)((slots >> (4u * j)) & 15ull)) | (b << 16);
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < EPT; j++) {
+                const uint32_t i = (uint32_t)tid + j * MT;
+                if (i < n) { sm.u.s.V[pk[j] & 0xFFFFu] = v[j]; sm.u.s.TG[pk[j] & 0xFFFFu] = (uint16_t)(pk[j] >> 16); }
+            }
+        }
+        __syncthreads();
+        // ---- every posting ranks itself inside its bucket: final position, duplicate / tombstone flag
+        uint32_t fv[EPT], fp[EPT];
+#pragma unroll
+        for (uint32_t j = 0; j < EPT; j++) {
+            const uint32_t q = (uint32_t)tid + j * MT;
+            fv[j] = 0; fp[j] = 0x80000000u;
+            if (q < n) {
+                const uint32_t v = sm.u.s.V[q];
+                const uint32_t b = sm.u.s.TG[q];
+                const uint32_t blo = base_of(b), bhi = base_of(b + 1u);
+                const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the ranking
+                uint32_t r = 0, dup = 0;
+                {   // the first four of the bucket without a loop (buckets hold one posting on average: lanes that loop make the
+                    // whole wave wait for the fullest bucket among its 64); reading past the bucket is harmless (masked)
+                    const uint32_t *B4 = &sm.u.s.V[blo];
+                    const uint32_t u0 = B4[0], u1 = B4[1], u2 = B4[2], u3 = B4[3];
+                    const uint32_t nb = bhi - blo;
+                    const uint32_t e0 = (u0 == v && blo < q) ? 1u : 0u;
+                    const uint32_t e1 = (nb > 1u && u1 == v && blo + 1u < q) ? 1u : 0u;
+                    const uint32_t e2 = (nb > 2u && u2 == v && blo + 2u < q) ? 1u : 0u;
+                    const uint32_t e3 = (nb > 3u && u3 == v && blo + 3u < q) ? 1u : 0u;
+                    r = (u0 < v ? 1u : 0u) + ((nb > 1u && u1 < v) ? 1u : 0u) + ((nb > 2u && u2 < v) ? 1u : 0u) + ((nb > 3u && u3 < v) ? 1u : 0u) +
+                        e0 + e1 + e2 + e3;
+                    dup = e0 | e1 | e2 | e3;
+                }
+                for (uint32_t m = blo + 4u; m < bhi; m++) {
+                    const uint32_t u = sm.u.s.V[m];
+                    const uint32_t eq = (u == v && m < q) ? 1u : 0u;
+                    r += (u < v ? 1u : 0u) + eq;
+                    dup |= eq;
+                }
+                uint32_t dead = dup;
+                if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
+                const uint32_t P = blo + r;
+                if (dead) atomicOr(&sm.x.f.DB[P >> 5], 1u << (P & 31u));
+                fv[j] = v;
+                fp[j] = P | (dead << 31);
+            }
+        }
+        __syncthreads();
+        // ---- dead ids before every 32 sorted positions
+        const uint32_t nw = (n + 31u) >> 5;
+        uint32_t totdead;
+        {
+            const uint32_t x = (uint32_t)tid < nw ? (uint32_t)__popc(sm.x.f.DB[tid]) : 0u;
+            const uint32_t ex = block_excl_scan(x, sm.wsum, &totdead);
+            if ((uint32_t)tid <= nw) sm.x.f.DP[tid] = ex;       // (DP[nw] = all of them)
+        }
+        const uint32_t nout = n - totdead;
+        uint32_t *out = alloc(nout);                            // (barriers inside)
+        __syncthreads();
+        auto dead_before = [&](uint32_t x) -> uint32_t {
+            return sm.x.f.DP[x >> 5] + (uint32_t)__popc(sm.x.f.DB[x >> 5] & ((1u << (x & 31u)) - 1u));
+        };
+#pragma unroll
+        for (uint32_t j = 0; j < EPT; j++) {
+            if (!(fp[j] >> 31)) out[fp[j] - dead_before(fp[j])] = fv[j];       // lanes hold neighbouring ranks: coalesced
+        }
+        if (batch && (uint32_t)tid < nt) {
+            // term t sits at the sorted positions [base of its first bucket, base of the next term's first bucket)
+            const uint32_t sp0 = base_of(sm.x.f.TB[tid]), sp1 = base_of(sm.x.f.TB[tid + 1]);
+            p.out_counts[t0 + (uint32_t)tid] = (sp1 - sp0) - (dead_before(sp1) - dead_before(sp0));
+        }
+        *n_out = nout;
+        return true;
+    };
+
+    // ---- a doc range of at most BMW * 32 docs (from lo & ~31) through the LDS bitmap: exact for any input
+    auto bitmap_range = [&](uint32_t lo, uint32_t hi, uint32_t t0, auto alloc) -> uint32_t {
+        const uint32_t lo32 = lo & ~31u;
+        const uint32_t nw = ((hi - lo32) >> 5) + 1u;                      // <= BMW
+        uint32_t *bm = sm.u.bm;
+        for (uint32_t i = 4u * (uint32_t)tid; i < nw; i += 4u * MT) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
+        decode(std::true_type{}, lo, hi, lo32, false, t0, 1u, true);    // (starts with a barrier)
+        II2_STAMP(1)      // decode + mark
+        if (p.tomb) {     // the tombstone words of exactly this range, coalesced and four in flight per thread
+            const uint32_t twb = lo32 >> 5;
+            for (uint32_t i0 = (uint32_t)tid; i0 < nw; i0 += 4u * MT) {
+                uint32_t t4[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    const uint32_t i = i0 + j * MT;
+                    t4[j] = (i < nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++)
+                    if (t4[j]) bm[i0 + j * MT] &= ~t4[j];
+            }
+            __syncthreads();
+        }
+        // consecutive words per thread, as few as cover the range
+        const uint32_t wpt = (nw + MT - 1u) / MT;
+        const uint32_t w0 = wpt * (uint32_t)tid;
+        const uint32_t w1 = w0 + wpt < nw ? w0 + wpt : nw;
+        uint32_t cnt = 0;
+#pragma unroll 1
+        for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(bm[w]);
+        uint32_t tot;
+        uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
+        uint32_t *out = alloc(tot);
+#pragma unroll 1
+        for (uint32_t w = w0; w < w1; w++) {
+            uint32_t x = bm[w];
+            const uint32_t base = lo32 + 32u * w;
+            while (x) {
+                out[pos++] = base + (uint32_t)__ffs((int)x) - 1u;
+                x &= x - 1u;
+            }
+        }
+        II2_STAMP(2)      // tombstones, count, extract
+        return tot;
+    };
+
+    const uint32_t n_tiles = *p.n_tiles_dev;       // computed by the plan kernels; the host only knows an upper bound
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint4 td = p.desc[tile];
+        const uint32_t t0 = td.x, t1 = td.y & 0x3FFFFFFFu;
+        const uint32_t nt = t1 - t0;
+        const bool large = (td.y & MERGE_DESC_LARGE) != 0u, bm_tile = (td.y & MERGE_DESC_BITMAP) != 0u;
+        const uint32_t dlo = td.z, dhi = td.w;
+        const bool whole = dlo == 0u && dhi == 0xFFFFFFFFu;
+        unsigned long long slot = p.npre[t0];
+        uint32_t total = 0;
+
+        // One term's doc range [lo, hi], bisected until every piece fits: leaves in doc order, appended at dst + *acc.
+        // from_root: the runs of [lo, hi] are already set up.
+        auto single_term = [&](uint32_t t, uint32_t lo, uint32_t hi, bool from_root, uint32_t *dst, uint32_t *acc) {
+            uint32_t sp = 1;
+            bool first = from_root;
+            __syncthreads();
+            if (tid == 0) { sm.stk[0][0] = lo; sm.stk[0][1] = hi; }
+            while (sp > 0) {
+                __syncthreads();
+                const uint32_t a = sm.stk[sp - 1][0], b = sm.stk[sp - 1][1];
+                sp--;
+                if (!first) setup_runs(2u, t, t + 1u, 0u, a, b);
+                first = false;
+                auto alloc = [&](uint32_t) -> uint32_t * { return dst + *acc; };
+                if (sm.RB[k] == 0u) continue;
+                if (b - (a & ~31u) < BMW * 32u) { *acc += bitmap_range(a, b, t, alloc); continue; }
+                decode(std::false_type{}, a, b, 0u, false, t, 1u, true);
+                uint32_t c = 0;
+                if (sort_range(a, b, false, t, 1u, alloc, &c)) { *acc += c; continue; }
+                const uint32_t mid = a + ((b - a) >> 1);     // a < b here: a range of one doc fits the bitmap
+                __syncthreads();
+                if (tid == 0) {
+                    sm.stk[sp][0] = mid + 1u; sm.stk[sp][1] = b;
+                    sm.stk[sp + 1][0] = a;    sm.stk[sp + 1][1] = mid;
+                }
+                sp += 2;
+            }
+        };
+
+        if (!large) {
+            // ---- batch of small terms: whole lists; survivors go to the batch's own region of the parking array
+            setup_runs(0u, t0, t1, tile, 0u, 0xFFFFFFFFu);
+            II2_STAMP(0)
+            decode(std::false_type{}, 0u, 0xFFFFFFFFu, 0u, true, t0, nt, false);
+            II2_STAMP(1)
+            uint32_t *dst = p.tmp + slot;
+            auto alloc = [&](uint32_t) -> uint32_t * { return dst; };
+            if (!sort_range(0u, 0xFFFFFFFFu, true, t0, nt, alloc, &total)) {
+                // clustered ids: term by term, each through the bisection
+                total = 0;
+                for (uint32_t t = t0; t < t1; t++) {
+                    const uint32_t before = total;
+                    setup_runs(0u, t, t + 1u, tile, 0u, 0xFFFFFFFFu);
+                    single_term(t, 0u, 0xFFFFFFFFu, true, dst, &total);
+                    __syncthreads();
+                    if (tid == 0) p.out_counts[t] = total - before;
+                }
+            }
+            II2_STAMP(3)
+        } else if (dlo <= dhi) {
+            // ---- a doc range of a large term; its place inside the term's region comes from the term's bump allocator
+            // (range tiles finish in any order; the packing pass only needs every tile's slot and count)
+            setup_runs(whole ? 0u : 1u, t0, t1, tile, dlo, dhi);
+            II2_STAMP(0)
+            auto alloc = [&](uint32_t c) -> uint32_t * {
+                __syncthreads();
+                if (tid == 0) sm.ab = c ? atomicAdd(&p.term_alloc[t0], c) : 0u;
+                __syncthreads();
+                slot = p.npre[t0] + sm.ab;
+                return p.tmp + slot;
+            };
+            if (sm.RB[k] == 0u) {
+                total = 0;
+            } else if (bm_tile) {
+                total = bitmap_range(dlo, dhi, t0, alloc);
+            } else {
+                decode(std::false_type{}, dlo, dhi, 0u, false, t0, 1u, !whole);
+                II2_STAMP(1)
+                if (!sort_range(dlo, dhi, false, t0, 1u, alloc, &total)) {
+                    // more postings than LDS or clustered ids: reserve room for all the range's postings, then bisect
+                    uint32_t *dst = alloc(sm.fill);
+                    total = 0;
+                    single_term(t0, dlo, dhi, false, dst, &total);
+                }
+                II2_STAMP(3)
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { p.tile_count[tile] = total; p.tile_slot[tile] = slot; }
+        II2_STAMP(6)
     }
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
 #undef II2_STAMP
 }
 
-// packs the parked survivors: tile t's ids go to out[off[t] ...]
+// packs the parked survivors: tile t's ids go to out[off[t] ...].  Nothing is written when the result does not fit the
+// caller's buffer (the call then fails with II2_ECAPACITY: all-or-nothing).
 __global__ __launch_bounds__(256) void k_merge_pack(const uint32_t *__restrict__ tmp, const unsigned long long *__restrict__ slot,
                                                     const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ off, const uint32_t *__restrict__ n_tiles_dev,
                                                     uint32_t *__restrict__ out, uint64_t out_cap, uint64_t *__restrict__ d_total) {
     const uint32_t n_tiles = *n_tiles_dev;
+    const uint64_t total = off[n_tiles];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = total;
+    if (total > out_cap) return;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint32_t c = cnt[tile];
         const uint64_t ob = off[tile];
         const uint32_t *src = tmp + slot[tile];
-        for (uint32_t q = threadIdx.x; q < c; q += 256u)
-            if (ob + q < out_cap) out[ob + q] = src[q];
+        for (uint32_t q = threadIdx.x; q < c; q += 256u) out[ob + q] = src[q];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *d_total = off[n_tiles];
 }
 
 // survivors of every large term = survivors of its tiles (tile_off = exclusive scan of the tile counts)
-__global__ void k_merge_large_counts(const uint32_t *__restrict__ ntl, const uint32_t *__restrict__ term_tile, const uint64_t *__restrict__ tile_off,
-                                     uint64_t n_terms, uint32_t *__restrict__ out_counts) {
+__global__ void k_merge_large_counts(MergeParams p, const uint64_t *__restrict__ tile_off) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_terms || ntl[t] == 0u) return;
-    const uint32_t a = term_tile[t];
-    out_counts[t] = (uint32_t)(tile_off[a + ntl[t]] - tile_off[a]);
+    if (t >= p.n_terms || p.ntl[t] == 0u) return;
+    const uint32_t a = p.term_tile[t];
+    p.out_counts[t] = (uint32_t)(tile_off[a + p.ntl[t]] - tile_off[a]);
 }
 
 // one atomic per workgroup, few workgroups: a single address sustains only ~90 device atomics per microsecond
@@ -1166,58 +821,37 @@ __global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *__restric
 
 static unsigned grid_for(uint64_t n) { return (unsigned)((n + 255) / 256); }
 
-hipError_t launch_mseg_blocks(const MergeSegs &p, uint32_t *segtab, hipStream_t s) {
-    hipLaunchKernelGGL(k_mseg_blocks, dim3(1), dim3(64), 0, s, p, segtab);
+hipError_t launch_merge_plan_terms(const MergeSegs *ms, const MergeParams &p, hipStream_t s) {
+    hipLaunchKernelGGL(k_mp_terms, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, ms, p);
     return hipGetLastError();
 }
-hipError_t launch_mlist_counts(const MergeSegs &p, uint32_t *lc, hipStream_t s) {
-    hipLaunchKernelGGL(k_mlist_counts, dim3(grid_for((uint64_t)p.k * (p.n_terms + 1))), dim3(256), 0, s, p, lc);
+hipError_t launch_merge_heads(const MergeParams &p, const uint64_t *wpre, uint32_t *head, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_heads, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, wpre, head);
     return hipGetLastError();
 }
-hipError_t launch_mbig_count(const MergeSegs &p, uint32_t *wgcnt, hipStream_t s) {
-    const uint64_t total = p.total_ub;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_mbig_count, dim3(grid_for(total)), dim3(256), 0, s, p, wgcnt);
+hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *head, const uint32_t *hpre, const uint32_t *lpre,
+                                  uint32_t *term_tile, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_term_tile, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, head, hpre, lpre, term_tile);
     return hipGetLastError();
 }
-hipError_t launch_mdec_write(const MergeSegs &p, const unsigned long long *poff, uint32_t *raw, const uint32_t *wgbase, void *ent0, void *ent1,
-                             uint32_t grid_rows, hipStream_t s) {
-    const uint64_t total = p.total_ub;
-    if (total == 0) return hipSuccess;
-    const unsigned nwg = grid_for(total);
-    hipLaunchKernelGGL(k_mdec_lane, dim3(nwg), dim3(256), 0, s, p, poff, raw, wgbase, (uint4 *)ent0, (uint2 *)ent1);
-    hipLaunchKernelGGL(k_mdec_rows, dim3(grid_rows), dim3(256), 0, s, p, raw, (const uint4 *)ent0, (const uint2 *)ent1, wgbase + nwg);
-    return hipGetLastError();
-}
-hipError_t launch_merge_tile_ranges(const MergeParams &p, const MergeSegs &ms, const void *desc, uint32_t *ends, void *rng, hipStream_t s) {
+hipError_t launch_merge_tile_desc(const MergeSegs *ms, const MergeParams &p, hipStream_t s) {
     if (p.n_tiles_ub == 0) return hipSuccess;
-    const unsigned g = grid_for((uint64_t)p.n_tiles_ub * p.k);
-    hipLaunchKernelGGL(k_merge_tile_ends, dim3(g), dim3(256), 0, s, p, ms, (const uint4 *)desc, ends);
-    hipLaunchKernelGGL(k_merge_tile_ranges, dim3(g), dim3(256), 0, s, p, (const uint4 *)desc, (const uint32_t *)ends, (uint4 *)rng);
+    hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles_ub)), dim3(256), 0, s, ms, p);
     return hipGetLastError();
 }
-
-hipError_t launch_merge_plan1(const MergeParams &p, uint32_t *ub, uint32_t *weight, uint32_t *ntl, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_term_ub, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ub, weight, ntl);
-    return hipGetLastError();
-}
-hipError_t launch_merge_heads(const MergeParams &p, const uint32_t *ntl, const uint64_t *wpre, uint32_t *head, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_heads, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ntl, wpre, head);
-    return hipGetLastError();
-}
-hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *ntl, const uint32_t *head, const uint32_t *hpre,
-                                  const uint32_t *lpre, uint32_t *term_tile, hipStream_t s) {
-    hipLaunchKernelGGL(k_merge_term_tile, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, ntl, head, hpre, lpre, term_tile);
-    return hipGetLastError();
-}
-hipError_t launch_merge_tile_desc(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, void *desc, hipStream_t s) {
+hipError_t launch_merge_tile_runs(const MergeSegs *ms, const MergeParams &p, hipStream_t s) {
     if (p.n_tiles_ub == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_tile_desc, dim3(grid_for(p.n_tiles_ub)), dim3(256), 0, s, p, ntl, term_tile, (uint4 *)desc);
+    hipLaunchKernelGGL(k_merge_tile_runs, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
     return hipGetLastError();
 }
-hipError_t launch_merge_large_counts(const MergeParams &p, const uint32_t *ntl, const uint32_t *term_tile, const uint64_t *tile_off, hipStream_t s) {
+hipError_t launch_merge_tiles(const MergeSegs *ms, const MergeParams &p, uint32_t grid, hipStream_t s) {
+    if (p.n_tiles_ub == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_tiles, dim3(grid < p.n_tiles_ub ? grid : p.n_tiles_ub), dim3(MERGE_THREADS), 0, s, ms, p);
+    return hipGetLastError();
+}
+hipError_t launch_merge_large_counts(const MergeParams &p, const uint64_t *tile_off, hipStream_t s) {
     if (p.n_terms == 0 || p.n_tiles_ub == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, ntl, term_tile, tile_off, p.n_terms, p.out_counts);
+    hipLaunchKernelGGL(k_merge_large_counts, dim3(grid_for(p.n_terms)), dim3(256), 0, s, p, tile_off);
     return hipGetLastError();
 }
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s) {
@@ -1225,14 +859,6 @@ hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hip
     const uint32_t g = p.n_tiles_ub < 16384u ? p.n_tiles_ub : 16384u;
     hipLaunchKernelGGL(k_merge_pack, dim3(g), dim3(256), 0, s, (const uint32_t *)p.tmp, (const unsigned long long *)p.tile_slot,
                        (const uint32_t *)p.tile_count, tile_off, p.n_tiles_dev, p.out_values, p.out_cap, p.d_total);
-    return hipGetLastError();
-}
-hipError_t launch_merge_tiles(const MergeParams &p, const void *tile_desc, uint32_t grid, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
-    if (p.n_tiles_ub == 0) return hipSuccess;
-    if (ev0) (void)hipEventRecord(ev0, s);
-    if (p.k == 16u) hipLaunchKernelGGL(k_merge_tiles<16u>, dim3(grid < p.n_tiles_ub ? grid : p.n_tiles_ub), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
-    else hipLaunchKernelGGL(k_merge_tiles<0u>, dim3(grid < p.n_tiles_ub ? grid : p.n_tiles_ub), dim3(MERGE_THREADS), 0, s, p, (const uint4 *)tile_desc);
-    if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();
 }
 hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s) {

@@ -44,45 +44,51 @@ template <class T> static T *carve(uint8_t *&cursor, size_t count) {
 // Core: k SegViews over n_terms aligned term slots -> d_out_off (u64[n_terms+1], may be null), d_out_values.
 // blocks_ub / postings_ub: host-side upper bounds of the views' blocks and postings — every grid and every scratch
 // array is sized from them, so the call enqueues all its kernels without a single host round trip and only reads three
-// scalars back at the end.
+// scalars back at the end.  Nothing is decoded ahead of the tile kernel: the plan works on the segments' per-list counts,
+// first / last docs and skip tables.
 static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n_terms, uint64_t blocks_ub, uint64_t postings_ub,
                       const ii2_tomb *tomb, uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap, ii2_merge_stats *stats) {
     hipStream_t st = ctx->stream;
     const uint64_t T = n_terms;
-    if (T >= (1ull << 31) - 2) return fail(ctx, II2_ERANGE, "too many term slots");
+    if (T >= (1ull << 30) - 2) return fail(ctx, II2_ERANGE, "merge: 2^30 or more term slots in one call");
     if (blocks_ub >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many input blocks");
-    if (postings_ub >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: more than 2^32 input postings in one call");
+    if (postings_ub >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: 2^32 or more input postings in one call");
     if (tomb && tomb->device != ctx->device) return fail(ctx, II2_EINVAL, "tombstones live on another device");
     MergeParams p;
     std::memset(&p, 0, sizeof p);
-    MergeSegs ms;
-    std::memset(&ms, 0, sizeof ms);
-    for (uint32_t s = 0; s < k; s++) ms.segs[s] = views[s];
-    ms.k = k;
-    ms.n_terms = T;
-    ms.total_ub = (uint32_t)blocks_ub;
+    // the views travel through a pinned staging block (the call ends with a stream sync, so the next call may reuse it)
+    if (!ctx->h_segs) {
+        if (hipHostMalloc((void **)&ctx->h_segs, sizeof(MergeSegs)) != hipSuccess || hipMalloc((void **)&ctx->d_segs, sizeof(MergeSegs)) != hipSuccess)
+            return fail(ctx, II2_ENOMEM, "merge: staging allocation failed");
+    }
+    MergeSegs *hs = (MergeSegs *)ctx->h_segs;
+    std::memset(hs, 0, sizeof *hs);
+    for (uint32_t s = 0; s < k; s++) hs->segs[s] = views[s];
+    hs->k = k;
+    hs->n_terms = T;
+    const MergeSegs *d_ms = (const MergeSegs *)ctx->d_segs;
     p.k = k;
     p.n_terms = T;
     p.tomb = tomb ? tomb->d_words : nullptr;
     p.tomb_summary = tomb ? tomb->d_summary : nullptr;
     p.tomb_nwords = tomb ? (uint32_t)std::min<uint64_t>(tomb->n_words, 0xFFFFFFFFull) : 0;
     const uint32_t cap = MERGE_CAP;
-    // terms per batch are bounded by the list-offset table: (nt + 1) * k <= MERGE_OFFMAX
-    uint32_t nt_max = MERGE_OFFMAX / k - 1u;
-    if (nt_max > 500u) nt_max = 500u;       // <= MERGE_THREADS terms per batch (one thread per term in the tile kernel)
-    if (nt_max < 1u) nt_max = 1u;
-    p.small_max = cap / 2u;                 // batched terms; a batch holds < batch_q + small_max <= cap
-    p.batch_q = cap - p.small_max;
-    p.wmin = (cap + nt_max - 1u) / nt_max;  // <= cap / wmin <= nt_max terms per batch
-    if (p.wmin > p.small_max) p.wmin = p.small_max;
+    // batches: small terms are packed in term order; a batch ends when its weight passes a multiple of batch_q, so it holds
+    // less than batch_q + small_max <= cap postings and, every term weighing at least wmin, at most MERGE_NT_MAX terms
+    p.small_max = (cap * 5u) / 14u;         // 2560
+    p.batch_q = cap - p.small_max;          // 4608
+    p.wmin = (cap + MERGE_NT_MAX - 1u) / MERGE_NT_MAX;
+    p.range_target = ctx->opt_merge_large_tile > 0 ? std::min<uint32_t>((uint32_t)ctx->opt_merge_large_tile, cap) : p.batch_q;
     p.bitmap_tiles = ctx->opt_merge_bitmap ? 1u : 0u;
-    p.large_tile = ctx->opt_merge_large_tile > 0 ? (uint32_t)ctx->opt_merge_large_tile : (cap / 4u) * 3u;   // exact counts: leave slack for uneven lists
+    p.bitmap_sparsity = ctx->opt_merge_bitmap > 1 ? (uint32_t)std::min<int64_t>(ctx->opt_merge_bitmap, 4096) : 40u;
     // upper bound of the tile count (the exact one is computed on the device and stays there): a large term has more than
-    // small_max postings and takes ceil(u / large_tile) tiles; a batch ends when its weight passes batch_q or a large term
-    // interrupts the run of small ones
+    // small_max postings and takes ceil(n / range_target) range tiles or, as a bitmap term with >= 1 posting per
+    // `sparsity` docs, ceil(span / MERGE_BM_DOCS) <= n * sparsity / MERGE_BM_DOCS + 1 bitmap tiles; a batch ends when its
+    // weight passes batch_q or a large term interrupts the run of small ones
     const uint64_t n_large_ub = postings_ub / ((uint64_t)p.small_max + 1u);
-    const uint64_t tiles_ub64 = postings_ub / p.large_tile + n_large_ub + (postings_ub + T * p.wmin) / p.batch_q + n_large_ub + 4;
-    if (tiles_ub64 >= (1ull << 31)) return fail(ctx, II2_ERANGE, "merge: too many tiles");
+    const uint64_t tiles_ub64 = postings_ub / p.range_target + (postings_ub * p.bitmap_sparsity) / MERGE_BM_DOCS + 2 * n_large_ub +
+                                (postings_ub + T * p.wmin) / p.batch_q + n_large_ub + 4;
+    if (tiles_ub64 >= (1ull << 31) || tiles_ub64 * k >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: too many tiles");
     p.n_tiles_ub = (uint32_t)tiles_ub64;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;          // option profile.events: the pair brackets the WHOLE call, first launch to last
@@ -98,81 +104,58 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
         bcap = want;
         return true;
     };
-    const size_t totalB = (size_t)blocks_ub;
     const size_t n1 = (size_t)T + 1;
-    const size_t nl = (size_t)k * n1;
-    const size_t scan_b = scan_temp_bytes(std::max<size_t>(nl + 1, totalB + 1));
-    // ws: list counts / offsets, the list of non-tiny blocks, plan arrays
-    const size_t nwg = (totalB + 255) / 256;
-    size_t need = align_up((totalB + 1) * sizeof(uint4)) + align_up((totalB + 1) * sizeof(uint2)) + 2 * align_up((nwg + 1) * sizeof(uint32_t)) +
-                  align_up(nl * sizeof(uint32_t)) +
-                  align_up(nl * sizeof(uint64_t)) + 8 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) +
-                  align_up((2 * MAX_LISTS + 2) * sizeof(uint32_t)) + scan_b + 4096;
+    const size_t scan_b = scan_temp_bytes(n1 + 1);
+    // ws: per-term plan arrays
+    size_t need = 11 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) + scan_b + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     uint8_t *cur = ctx->ws;
-    uint4 *d_ent0 = carve<uint4>(cur, totalB + 1);        // work list of the non-tiny blocks (row decoder)
-    uint2 *d_ent1 = carve<uint2>(cur, totalB + 1);
-    uint32_t *d_wgcnt = carve<uint32_t>(cur, nwg + 1);
-    uint32_t *d_wgbase = carve<uint32_t>(cur, nwg + 1);
-    uint32_t *d_lc = carve<uint32_t>(cur, nl);
-    unsigned long long *d_poff = (unsigned long long *)carve<uint64_t>(cur, nl);
-    uint32_t *d_ub = carve<uint32_t>(cur, n1);
-    uint32_t *d_w = carve<uint32_t>(cur, n1);
-    uint32_t *d_ntl = carve<uint32_t>(cur, n1);
+    p.tn = carve<uint32_t>(cur, n1);
+    p.tmin = carve<uint32_t>(cur, n1);
+    p.tmax = carve<uint32_t>(cur, n1);
+    p.tinfo = carve<uint32_t>(cur, n1);
+    p.weight = carve<uint32_t>(cur, n1);
+    p.ntl = carve<uint32_t>(cur, n1);
     uint32_t *d_head = carve<uint32_t>(cur, n1);
     uint32_t *d_hpre = carve<uint32_t>(cur, n1);
     uint32_t *d_lpre = carve<uint32_t>(cur, n1);
     uint32_t *d_tt = carve<uint32_t>(cur, n1);
     uint32_t *d_cnt = carve<uint32_t>(cur, n1);
     uint64_t *d_wpre = carve<uint64_t>(cur, n1);
-    uint64_t *d_ubpre = carve<uint64_t>(cur, n1);
-    uint32_t *d_segtab = carve<uint32_t>(cur, 2 * MAX_LISTS + 2);
+    uint64_t *d_npre = carve<uint64_t>(cur, n1);
     void *d_scan = cur;
-    if (!grow(ctx->aux2, ctx->aux2_cap, (postings_ub + 64) * sizeof(uint32_t))) return fail(ctx, II2_ENOMEM, "merge raw scratch allocation failed");
-    uint32_t *d_raw = (uint32_t *)ctx->aux2;
-    // per-tile arrays and the scratch in which the leaves of oversized tiles wait
+    // aux: per-tile arrays, the large terms' bump allocators and the parking array
     const size_t nt1 = (size_t)p.n_tiles_ub + 1;
     const size_t scan_t = scan_temp_bytes(nt1);
-    const size_t aux_need = align_up(nt1 * sizeof(uint32_t)) + align_up(nt1 * 16) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
-                            align_up(nt1 * k * 2 * sizeof(uint4)) + align_up(nt1 * k * sizeof(uint32_t)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
+    const size_t aux_need = align_up(nt1 * sizeof(uint32_t)) + align_up(n1 * sizeof(uint32_t)) + align_up(nt1 * 16) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
+                            align_up(nt1 * k * sizeof(uint2)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
     if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
-    p.tile_count = carve<uint32_t>(ac, nt1);               // (first in the allocation: zeroed by one memset from its start)
+    p.tile_count = carve<uint32_t>(ac, nt1);               // (first in the allocation: zeroed together with term_alloc by one memset)
+    p.term_alloc = carve<uint32_t>(ac, n1);
+    const size_t zero_bytes = (size_t)(ac - ctx->aux);
     p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
     uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
     void *d_scan_t = carve<uint8_t>(ac, scan_t);
-    void *d_tile_desc = carve<uint8_t>(ac, nt1 * 16);
-    uint4 *d_rng = carve<uint4>(ac, nt1 * k * 2);
-    uint32_t *d_ends = carve<uint32_t>(ac, nt1 * k);
+    p.desc = (uint4 *)carve<uint8_t>(ac, nt1 * 16);
+    p.runs = carve<uint2>(ac, nt1 * k);
     p.tmp = carve<uint32_t>(ac, postings_ub + 64);
 
-    // ---- pass 1: decode every input list once into a raw scratch array ----
-    ms.segtab = d_segtab;
-    HIP_TRY(ctx, launch_mseg_blocks(ms, d_segtab, st));
-    // list (s, t) goes to raw[poff[s, t] ...]: the segments know their lists' posting counts
-    HIP_TRY(ctx, launch_mlist_counts(ms, d_lc, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_lc, (uint64_t *)d_poff, nl, st));
-    HIP_TRY(ctx, hipMemsetAsync(d_wgcnt + nwg, 0, sizeof(uint32_t), st));
-    HIP_TRY(ctx, launch_mbig_count(ms, d_wgcnt, st));
-    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_wgcnt, d_wgbase, nwg + 1, st));
-    HIP_TRY(ctx, launch_mdec_write(ms, d_poff, d_raw, d_wgbase, d_ent0, d_ent1, (uint32_t)ctx->cu_count * 8u, st));
-    p.raw = d_raw;
-    p.poff = d_poff;
-
-    // ---- plan (device): exact per-term counts, batches, tiles ----
-    HIP_TRY(ctx, launch_merge_plan1(p, d_ub, d_w, d_ntl, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_w, d_wpre, n1, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_ub, d_ubpre, n1, st));
-    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_ntl, d_lpre, n1, st));
-    HIP_TRY(ctx, launch_merge_heads(p, d_ntl, d_wpre, d_head, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_segs, hs, sizeof(MergeSegs), hipMemcpyHostToDevice, st));
+    // ---- plan (device): per-term counts and doc ranges, batches, tiles, the blocks every range tile has to decode ----
+    HIP_TRY(ctx, launch_merge_plan_terms(d_ms, p, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, p.weight, d_wpre, n1, st));
+    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, p.tn, d_npre, n1, st));
+    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, p.ntl, d_lpre, n1, st));
+    HIP_TRY(ctx, launch_merge_heads(p, d_wpre, d_head, st));
     HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
-    HIP_TRY(ctx, launch_merge_term_tile(p, d_ntl, d_head, d_hpre, d_lpre, d_tt, st));
+    HIP_TRY(ctx, launch_merge_term_tile(p, d_head, d_hpre, d_lpre, d_tt, st));
+    p.term_tile = d_tt;
     p.n_tiles_dev = d_tt + T;                   // term_tile[T] = number of tiles
-    p.ub_prefix = (const unsigned long long *)d_ubpre;
-    HIP_TRY(ctx, launch_merge_tile_desc(p, d_ntl, d_tt, d_tile_desc, st));
-    HIP_TRY(ctx, launch_merge_tile_ranges(p, ms, d_tile_desc, d_ends, d_rng, st));
-    p.rng = d_rng;
+    p.npre = d_npre;
+    HIP_TRY(ctx, launch_merge_tile_desc(d_ms, p, st));
+    HIP_TRY(ctx, launch_merge_tile_runs(d_ms, p, st));
     p.out_counts = d_cnt;
     p.out_values = d_out_values;
     p.out_cap = out_cap;
@@ -185,14 +168,15 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
     HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(p.tile_count, 0, align_up(nt1 * sizeof(uint32_t)), st));      // tiles past the real count contribute 0 to the scan
-    // 2 workgroups of ~67 KB LDS per CU; each walks tiles w, w+grid, ...
-    HIP_TRY(ctx, launch_merge_tiles(p, d_tile_desc, (uint32_t)ctx->cu_count * 2u, st));
+    HIP_TRY(ctx, hipMemsetAsync(p.tile_count, 0, zero_bytes, st));      // tiles past the real count contribute 0 to the scan
+    // 2 workgroups of ~75 KB LDS per CU; each walks tiles w, w+grid, ...
+    HIP_TRY(ctx, launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * 2u, st));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
-    HIP_TRY(ctx, launch_merge_large_counts(p, d_ntl, d_tt, d_tile_off, st));
+    HIP_TRY(ctx, launch_merge_large_counts(p, d_tile_off, st));
     HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
     HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
-    if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, d_cnt, d_out_off, n1, st));
+    // all-or-nothing: like the packing pass, the offsets are only written when the result fits the caller's buffer
+    if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64_guarded(d_scan, scan_b, d_cnt, d_out_off, n1, ctx->d_mail, out_cap, st));
     if (e1) (void)hipEventRecord(e1, st);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 4, p.n_tiles_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -200,7 +184,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const uint32_t n_tiles = (uint32_t)(ctx->h_mail[4] & 0xFFFFFFFFull);
     if (n_tiles > p.n_tiles_ub) return fail(ctx, II2_EHIP, "merge: internal error (tile bound exceeded)");
     if (n_tiles == 0) ctx->h_mail[0] = 0;
-    if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small (content unspecified)");
+    if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small; nothing was written");
     if (stats) {
         stats->n_out = ctx->h_mail[0];
         stats->n_terms_out = ctx->h_mail[2];
@@ -226,7 +210,7 @@ static int merge_unlocked(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, 
     std::vector<SegView> views(k);
     uint64_t n_in = 0, n_blk = 0;
     for (uint32_t s = 0; s < k; s++) {
-        views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt, segs[s]->d_blk_list, 0u, 0u};
+        views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt, segs[s]->d_blk_list, segs[s]->d_last_doc, 0u, 0u};
         n_in += segs[s]->n_postings;       // (views made by ii2_seg_select carry their store's totals: upper bounds)
         n_blk += segs[s]->n_blocks;
     }
@@ -286,7 +270,7 @@ int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64
         if (!segs[i] || segs[i]->device != ctx->device || li >= segs[i]->n_lists) return fail(ctx, II2_EINVAL, "ii2_union: bad list");
         if (int rc0 = ii2_seg_host_blk_off(ctx, segs[i])) return rc0;
         // a one-term view of the segment: blk_off shifted to the list
-        views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_cnt + li, segs[i]->d_blk_list, (uint32_t)li, 0u};
+        views[i] = SegView{segs[i]->d_blk_off + li, segs[i]->d_skip, segs[i]->d_payload, segs[i]->d_cnt + li, segs[i]->d_blk_list, segs[i]->d_last_doc + li, (uint32_t)li, 0u};
         any |= segs[i]->h_blk_off[li + 1] > segs[i]->h_blk_off[li];
         blocks_ub += segs[i]->h_blk_off[li + 1] - segs[i]->h_blk_off[li];
     }
