@@ -32,6 +32,7 @@ struct ii2_ctx {
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
+    int64_t opt_merge_skip = 0;         // timing experiments: phases of the merge tile kernel left out (results wrong)
     int64_t opt_merge_bitmap = 1;       // single-term tiles whose doc range fits the LDS bitmap are merged by marking bits
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
     size_t aux_cap = 0;

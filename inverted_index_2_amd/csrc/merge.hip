@@ -34,7 +34,7 @@ constexpr uint32_t MCAP = MERGE_CAP;
 constexpr uint32_t MT = MERGE_THREADS;
 constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
 constexpr uint32_t EPT = MCAP / MT;               // elements per thread in the sort passes (14)
-constexpr uint32_t PCAP = 1024;                   // 16-byte payload pieces decoded per chunk of blocks
+constexpr uint32_t PCAP = 1536;                   // 16-byte payload pieces decoded per chunk of blocks
 constexpr uint32_t BKT_LIMIT = 15;                // fullest bucket the bucket sort accepts (slot numbers are 4 bits)
 constexpr uint32_t BMW = MERGE_BM_WORDS;
 static_assert(MCAP % MT == 0 && EPT * 4u <= 64u && (MCAP / 2u) % MT == 0, "sort passes: EPT elements and EPT / 2 counter words per thread");
@@ -207,6 +207,9 @@ __global__ void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams 
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------
+constexpr uint32_t PSLOT = PCAP / MT;             // piece slots per thread when the piece -> block map is built
+static_assert(PCAP % MT == 0, "piece map: PSLOT slots per thread");
+
 struct __align__(16) MergeSmem {
     union {
         struct {
@@ -219,7 +222,9 @@ struct __align__(16) MergeSmem {
     union {
         struct {                            // while a chunk of blocks is decoded
             uint32_t PX[PCAP];              // exclusive prefix of the pieces' gap sums
-            uint32_t BF[MT], BQ[MT], BI[MT];   // per block: first doc, payload offset, run | term slot << 6 | payload bytes << 15
+            uint16_t PJ[PCAP];              // block (thread of the chunk) that owns each piece
+            const uint8_t *BP[MT];          // per block: its payload
+            uint32_t BF[MT], BI[MT];        // per block: first doc; term slot | payload bytes << 16
             uint16_t PB[MT + 2u];           // per block: its first piece
         } d;
         struct {                            // while a decoded tile is sorted
@@ -232,12 +237,11 @@ struct __align__(16) MergeSmem {
     const uint8_t *pay[MAX_LISTS];
     const ii2_skip *skp[MAX_LISTS];
     const uint32_t *bls[MAX_LISTS];
-    const uint32_t *bof[MAX_LISTS];
     uint32_t lbase[MAX_LISTS];
-    uint32_t RR0[MAX_LISTS], RR1[MAX_LISTS];   // block range of each run for the tile's root doc range
+    uint32_t RR0[MAX_LISTS], RR1[MAX_LISTS];   // block range of each run for the root doc range of the term(s) being merged
     uint32_t R0[MAX_LISTS];                 // first block of each run for the range being merged
     uint32_t RB[MAX_LISTS + 2u];            // exclusive prefix of the runs' block counts
-    uint32_t wsum[MW];
+    uint32_t wsum[MW], wmax[MW];
     uint32_t fill;                          // postings of the range that arrived in V (may exceed MCAP: the range is then split)
     uint32_t ovf;                           // a bucket overflowed
     uint32_t tp;                            // pieces of the chunk
@@ -249,9 +253,9 @@ struct __align__(16) MergeSmem {
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, uint32_t *tot) {
     const int l = lane_id(), wv = (int)threadIdx.x >> 6;
     const uint32_t incl = wave_incl_scan(v);
-    __syncthreads();
+    lds_barrier();
     if (l == 63) wsum[wv] = incl;
-    __syncthreads();
+    lds_barrier();
     uint32_t pre = 0;
     uint32_t t = 0;
     for (int w = 0; w < (int)MW; w++) { if (w < wv) pre += wsum[w]; t += wsum[w]; }
@@ -259,14 +263,47 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum, 
     return pre + incl - v;
 }
 
+// number of threads of the workgroup whose predicate holds
+__device__ __forceinline__ uint32_t block_count(bool pred, uint32_t *wsum) {
+    const unsigned long long m = __ballot(pred);
+    lds_barrier();
+    if (lane_id() == 0) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    lds_barrier();
+    uint32_t t = 0;
+    for (int w = 0; w < (int)MW; w++) t += wsum[w];
+    return t;
+}
+
+// inclusive prefix maximum over the 64 lanes of a wave (same DPP steps as wave_incl_scan; lanes without a source see 0)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = y > x ? y : x;
+    return x;
+}
+
+// payload bytes live in global memory: say so (a pointer that went through LDS would be loaded with flat instructions)
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint4 gload16(const uint8_t *p) {
+    const u32x4_unaligned v = *(const __attribute__((address_space(1))) u32x4_unaligned *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t gload4(const uint8_t *p) { return *(const __attribute__((address_space(1))) u32_unaligned *)p; }
+
 __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSegs *__restrict__ ms, MergeParams p) {
     __shared__ MergeSmem sm;
-    const int tid = (int)threadIdx.x, l = tid & 63;
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6;
     const uint32_t k = p.k;
     // diagnostics only: thread 0 sums the cycles spent in each step of the tile loop
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
     const bool stamps = p.debug != nullptr;
+    const uint32_t xskip = p.pad0;             // timing experiments only (option debug.merge_skip): phases left out, results wrong
 #define II2_STAMP(i)                                                    \
     if (stamps) {                                                       \
         const unsigned long long tn_ = __builtin_amdgcn_s_memtime();    \
@@ -275,505 +312,543 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
     }
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
+    const uint32_t *my_bo = nullptr;               // blk_off of "my" run (threads 0 .. k-1)
     if ((uint32_t)tid < k) {
         const SegView &sv = ms->segs[tid];
+        my_bo = sv.blk_off;
         sm.pay[tid] = sv.payload;
         sm.skp[tid] = sv.skip;
         sm.bls[tid] = sv.blk_list;
-        sm.bof[tid] = sv.blk_off;
         sm.lbase[tid] = sv.list_base;
     }
-    __syncthreads();
-
-    // ---- the runs of a doc range: which blocks of every list have to be decoded.
-    // mode 0: whole lists of the terms [t0, t1); 1: the tile's root range (searched by the plan); 2: a sub-range of the root
-    auto setup_runs = [&](uint32_t mode, uint32_t t0, uint32_t t1, uint32_t tile, uint32_t lo, uint32_t hi) {
-        __syncthreads();
-        if ((uint32_t)tid < k) {
-            uint2 r;
-            if (mode == 0u) r = make_uint2(sm.bof[tid][t0], sm.bof[tid][t1]);
-            else if (mode == 1u) r = p.runs[(uint64_t)tile * k + (uint32_t)tid];
-            else r = blocks_of_range(sm.skp[tid], sm.RR0[tid], sm.RR1[tid], lo, hi);
-            if (mode != 2u) { sm.RR0[tid] = r.x; sm.RR1[tid] = r.y; }
-            sm.R0[tid] = r.x;
-            sm.RB[tid] = r.y - r.x;            // (count; scanned below)
-        }
-        __syncthreads();
-        if (tid < 64) {
-            const uint32_t c = (uint32_t)l < k ? sm.RB[l] : 0u;
-            const uint32_t incl = wave_incl_scan(c);
-            if ((uint32_t)l < k) sm.RB[l] = incl - c;
-            if (l == 63) sm.RB[k] = incl;
-            if (l == 0) { sm.fill = 0u; sm.ovf = 0u; }
-        }
-        __syncthreads();
-    };
-
-    // ---- decode the runs' blocks; every posting with lo <= id <= hi goes
-    //   BM = false: to sm.u.s.V[arrival order] (and its term slot to TG when the tile is a batch),
-    //   BM = true:  into the bitmap of the range (bit id - lo32).
-    // A chunk = as many consecutive blocks (one per thread) as have PCAP 16-byte payload pieces between them; a thread then
-    // walks one piece: the 16 partial gap sums and which bytes end a posting; a scan over the chunk's pieces gives every
-    // piece the sum before it, and the difference to its block's first piece the id it starts from.
-    auto decode = [&](auto bm_tag, uint32_t lo, uint32_t hi, uint32_t lo32, bool batch, uint32_t t0, uint32_t nt, bool filter) {
-        constexpr bool BM = decltype(bm_tag)::value;
-        const uint32_t NB = sm.RB[k];
-        uint32_t g0 = 0;
-        while (g0 < NB) {
-            __syncthreads();                     // the chunk before is done with the tables
-            const uint32_t g = g0 + (uint32_t)tid;
-            const bool valid = g < NB;
-            uint32_t s = 0, np = 0, first = 0, q0 = 0, ti = 0, len = 0;
-            if (valid) {
-                uint32_t a = 0, e = k;            // RB[a] <= g < RB[e]
-                while (e - a > 1u) { const uint32_t m = (a + e) >> 1; if (sm.RB[m] <= g) a = m; else e = m; }
-                s = a;
-                const uint32_t b = sm.R0[s] + (g - sm.RB[s]);
-                const ii2_skip *sk = sm.skp[s];
-                const ii2_skip e0 = sk[b];
-                first = e0.first_doc;
-                q0 = e0.byte_off;
-                len = sk[b + 1u].byte_off - q0;
-                if (len > 1280u) len = 1280u;     // (a block holds <= 256 postings of <= 5 bytes; imported segments are validated)
-                np = (len + 15u) >> 4;
-                if (batch) { ti = sm.bls[s][b] - sm.lbase[s] - t0; ti = ti < nt ? ti : nt - 1u; }
-            }
-            uint32_t tot;
-            const uint32_t pex = block_excl_scan(np, sm.wsum, &tot);
-            const bool ok = valid && pex + np <= PCAP;          // a prefix of the threads (pex ascends); never empty (np <= 80)
-            const uint32_t nchunk = (uint32_t)__syncthreads_count(ok ? 1 : 0);
-            if (ok) {
-                sm.x.d.BF[tid] = first;
-                sm.x.d.BQ[tid] = q0;
-                sm.x.d.BI[tid] = s | (ti << 6) | (len << 15);
-                sm.x.d.PB[tid] = (uint16_t)pex;
-                if ((uint32_t)tid == nchunk - 1u) sm.tp = pex + np;
-            }
-            {   // the blocks' first postings (their ids are in the skip entries)
-                const bool in = ok && first >= lo && first <= hi;
-                if (BM) {
-                    if (in) atomicOr(&sm.u.bm[(first - lo32) >> 5], 1u << (first & 31u));
-                } else {
-                    const unsigned long long m = __ballot(in);
-                    if (m != 0ull) {
-                        uint32_t wb = 0;
-                        if (l == 0) wb = atomicAdd(&sm.fill, (uint32_t)__popcll(m));
-                        wb = wave_bcast(wb, 0);
-                        const uint32_t pos = wb + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
-                        if (in && pos < MCAP) { sm.u.s.V[pos] = first; if (batch) sm.u.s.TG[pos] = (uint16_t)ti; }
-                    }
-                }
-            }
-            __syncthreads();
-            const uint32_t tp = sm.tp;
-            uint32_t carry = 0;
-            for (uint32_t it = 0; it < tp; it += MT) {
-                const uint32_t pc = it + (uint32_t)tid;
-                const bool pv = pc < tp;
-                uint32_t jb = 0, val[16], tmask = 0, bi = 0;
-#pragma unroll
-                for (int i = 0; i < 16; i++) val[i] = 0;
-                if (pv) {
-                    uint32_t a = 0, e = nchunk;   // last block with PB <= pc (blocks without payload share their successor's PB)
-                    while (e - a > 1u) { const uint32_t m = (a + e) >> 1; if ((uint32_t)sm.x.d.PB[m] <= pc) a = m; else e = m; }
-                    jb = a;
-                    bi = sm.x.d.BI[jb];
-                    const uint32_t off = 16u * (pc - (uint32_t)sm.x.d.PB[jb]);
-                    const uint32_t blen = bi >> 15;
-                    const uint32_t nb = blen - off < 16u ? blen - off : 16u;
-                    const uint8_t *pp = sm.pay[bi & 63u] + sm.x.d.BQ[jb] + off;
-                    uint4 w4;
-                    __builtin_memcpy(&w4, pp, 16);                        // (segments carry 16 bytes of padding)
-                    const uint32_t prev = off ? load_u32_unaligned(pp - 4) : 0u;
-                    uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
-                    if (nb < 16u) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t nj = nb > 4u * j ? (nb - 4u * j < 4u ? nb - 4u * j : 4u) : 0u;
-                            w[j] &= nj >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nj)) - 1u);
-                        }
-                    }
-                    // continuation bytes pending right before my first byte (varints are <= 5 bytes)
-                    uint32_t sh = 7u * ((uint32_t)__clz((int)~(prev | 0x7F7F7F7Fu)) >> 3);
-                    uint32_t sum = 0;
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                        sum += (c & 0x7Fu) << sh;
-                        if (c & 0x80u) sh = sh < 28u ? sh + 7u : 28u;
-                        else { sh = 0u; tmask |= 1u << i; }
-                        val[i] = sum;
-                    }
-                    tmask &= (1u << nb) - 1u;
-                }
-                uint32_t tots;
-                const uint32_t pex2 = carry + block_excl_scan(val[15], sm.wsum, &tots);
-                carry += tots;
-                if (pv) sm.x.d.PX[pc] = pex2;
-                __syncthreads();
-                if (pv) {
-                    const uint32_t base = sm.x.d.BF[jb] + pex2 - sm.x.d.PX[sm.x.d.PB[jb]];
-                    if (BM) {
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const uint32_t id = base + val[i];
-                            if (((tmask >> i) & 1u) && id >= lo && id <= hi) atomicOr(&sm.u.bm[(id - lo32) >> 5], 1u << (id & 31u));
-                        }
-                    } else if (filter) {
-                        uint32_t im = 0;
-#pragma unroll
-                        for (int i = 0; i < 16; i++) {
-                            const uint32_t id = base + val[i];
-                            if (id >= lo && id <= hi) im |= 1u << i;
-                        }
-                        tmask &= im;
-                    }
-                }
-                if (!BM) {
-                    const uint32_t c = (uint32_t)__popc(tmask);
-                    const uint32_t incl = wave_incl_scan(c);
-                    const uint32_t wtot = wave_bcast(incl, 63);
-                    if (wtot) {
-                        uint32_t wb = 0;
-                        if (l == 0) wb = atomicAdd(&sm.fill, wtot);
-                        wb = wave_bcast(wb, 0);
-                        uint32_t pos = wb + incl - c;
-                        if (wb + wtot <= MCAP) {
-                            const uint32_t base = pv ? sm.x.d.BF[jb] + pex2 - sm.x.d.PX[sm.x.d.PB[jb]] : 0u;
-                            const uint16_t tg = (uint16_t)((bi >> 6) & 511u);
-#pragma unroll
-                            for (int i = 0; i < 16; i++) {
-                                if ((tmask >> i) & 1u) {
-                                    sm.u.s.V[pos] = base + val[i];
-                                    if (batch) sm.u.s.TG[pos] = tg;
-                                    pos++;
-                                }
-                            }
-                        }       // else: the range holds more than LDS; the caller sees fill > MCAP and splits it
-                    }
-                }
-            }
-            g0 += nchunk;
-        }
-        __syncthreads();
-    };
-
-    // ---- sort the decoded postings of [lo, hi] (terms [t0, t0 + nt)) by buckets and write the survivors to `out` in
-    // (term, id) order.  Returns false when the range has to be split (more postings than LDS, or clustered ids that
-    // overflow a bucket) — nothing was written then.  alloc(n) is called once, by every thread, with the survivor count,
-    // before anything is written, and returns where they go.  Batches also store per-term survivor counts.
-    auto sort_range = [&](uint32_t lo, uint32_t hi, bool batch, uint32_t t0, uint32_t nt, auto alloc, uint32_t *n_out) -> bool {
-        const uint32_t n = sm.fill;
-        *n_out = 0;
-        if (n > MCAP) return false;
-        uint32_t *C32 = sm.u.s.C32;
-        for (uint32_t i = (uint32_t)tid; i < MCAP / 2u + 4u; i += MT) C32[i] = 0u;
-        if ((uint32_t)tid < MCAP / 32u + 1u) sm.x.f.DB[tid] = 0u;
-        // bucket maps: term t of a batch owns floor(n_t * MCAP / n) buckets, a range tile all MCAP of them
-        uint32_t u_mn = 0, u_nbm1 = 0;
-        float u_scale = 0.0f;
-        if (batch) {
-            uint32_t nbk = 0, mn = 0, mx = 0;
-            if ((uint32_t)tid < nt) {
-                const uint32_t n_t = p.tn[t0 + (uint32_t)tid];
-                mn = p.tmin[t0 + (uint32_t)tid];
-                mx = p.tmax[t0 + (uint32_t)tid];
-                nbk = n_t ? (uint32_t)(((uint64_t)n_t * MCAP) / n) : 0u;
-            }
-            uint32_t totb;
-            const uint32_t tb = block_excl_scan(nbk, sm.wsum, &totb);
-            if ((uint32_t)tid < nt) {
-                sm.x.f.TB[tid] = (uint16_t)tb;
-                sm.x.f.TT[tid] = make_uint2(mn, __float_as_uint(nbk ? (float)nbk / ((float)(mx - mn) + 1.0f) : 0.0f));
-            }
-            if (tid == 0) sm.x.f.TB[nt] = (uint16_t)totb;
-        } else {
-            const uint32_t t_mn = p.tmin[t0], t_mx = p.tmax[t0];
-            u_mn = lo > t_mn ? lo : t_mn;
-            const uint32_t mxr = hi < t_mx ? hi : t_mx;
-            u_nbm1 = MCAP - 1u;
-            u_scale = (float)MCAP / ((float)((mxr > u_mn ? mxr : u_mn) - u_mn) + 1.0f);
-        }
-        __syncthreads();
-        // ---- bucket of every posting, slot inside the bucket
-        unsigned long long slots = 0ull;
-        bool over = false;
-#pragma unroll
-        for (uint32_t j = 0; j < EPT; j++) {
-            const uint32_t i = (uint32_t)tid + j * MT;
-            if (i < n) {
-                const uint32_t v = sm.u.s.V[i];
-                uint32_t mn = u_mn, nbm1 = u_nbm1, tb = 0;
-                float sc = u_scale;
-                if (batch) {
-                    const uint32_t ti = sm.u.s.TG[i];
-                    const uint2 te = sm.x.f.TT[ti];
-                    tb = sm.x.f.TB[ti];
-                    nbm1 = (uint32_t)sm.x.f.TB[ti + 1u] - tb - 1u;
-                    mn = te.x;
-                    sc = __uint_as_float(te.y);
-                }
-                const uint32_t bq = (uint32_t)((float)(v - mn) * sc);
-                const uint32_t b = tb + (bq < nbm1 ? bq : nbm1);
-                sm.u.s.TG[i] = (uint16_t)b;
-                const uint32_t sh = 16u * (b & 1u);
-                uint32_t slot = (atomicAdd(&C32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                if (slot > BKT_LIMIT) { over = true; slot = BKT_LIMIT; }
-                slots |= (unsigned long long)slot << (4u * j);
-            }
-        }
-        if (over) sm.ovf = 1u;
-        __syncthreads();
-        if (sm.ovf) return false;
-        // ---- exclusive scan of the counters in place: EPT buckets = EPT / 2 words per thread
-        {
-            uint32_t c[EPT], sum = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < EPT / 2u; j++) {
-                const uint32_t w = C32[(EPT / 2u) * (uint32_t)tid + j];
-                c[2u * j] = w & 0xFFFFu;
-                c[2u * j + 1u] = w >> 16;
-                sum += c[2u * j] + c[2u * j + 1u];
-            }
-            uint32_t tot_;
-            uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
-#pragma unroll
-            for (uint32_t j = 0; j < EPT / 2u; j++) {
-                const uint32_t e0 = run;
-                run += c[2u * j];
-                const uint32_t e1 = run;
-                run += c[2u * j + 1u];
-                C32[(EPT / 2u) * (uint32_t)tid + j] = e0 | (e1 << 16);
-            }
-            if (tid == (int)MT - 1) C32[MCAP / 2u] = run;        // base of the bucket past the last one
-        }
-        __syncthreads();
-        auto base_of = [&](uint32_t b) -> uint32_t { return (C32[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu; };
-        // ---- scatter into bucket order (in place: all reads, then all writes)
-        {
-            uint32_t v[EPT], pk[EPT];
-#pragma unroll
-            for (uint32_t j = 0; j < EPT; j++) {
-                const uint32_t i = (uint32_t)tid + j * MT;
-                v[j] = 0; pk[j] = 0;
-                if (i < n) {
-                    v[j] = sm.u.s.V[i];
-                    const uint32_t b = sm.u.s.TG[i];
-                    pk[j] = (base_of(b) + (uint32_t)((slots >> (4u * j)) & 15ull)) | (b << 16);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (uint32_t j = 0; j < EPT; j++) {
-                const uint32_t i = (uint32_t)tid + j * MT;
-                if (i < n) { sm.u.s.V[pk[j] & 0xFFFFu] = v[j]; sm.u.s.TG[pk[j] & 0xFFFFu] = (uint16_t)(pk[j] >> 16); }
-            }
-        }
-        __syncthreads();
-        // ---- every posting ranks itself inside its bucket: final position, duplicate / tombstone flag
-        uint32_t fv[EPT], fp[EPT];
-#pragma unroll
-        for (uint32_t j = 0; j < EPT; j++) {
-            const uint32_t q = (uint32_t)tid + j * MT;
-            fv[j] = 0; fp[j] = 0x80000000u;
-            if (q < n) {
-                const uint32_t v = sm.u.s.V[q];
-                const uint32_t b = sm.u.s.TG[q];
-                const uint32_t blo = base_of(b), bhi = base_of(b + 1u);
-                const uint32_t ts = (p.tomb && (v >> 5) < p.tomb_nwords) ? p.tomb_summary[v >> 9] : 0u;   // in flight during the ranking
-                uint32_t r = 0, dup = 0;
-                {   // the first four of the bucket without a loop (buckets hold one posting on average: lanes that loop make the
-                    // whole wave wait for the fullest bucket among its 64); reading past the bucket is harmless (masked)
-                    const uint32_t *B4 = &sm.u.s.V[blo];
-                    const uint32_t u0 = B4[0], u1 = B4[1], u2 = B4[2], u3 = B4[3];
-                    const uint32_t nb = bhi - blo;
-                    const uint32_t e0 = (u0 == v && blo < q) ? 1u : 0u;
-                    const uint32_t e1 = (nb > 1u && u1 == v && blo + 1u < q) ? 1u : 0u;
-                    const uint32_t e2 = (nb > 2u && u2 == v && blo + 2u < q) ? 1u : 0u;
-                    const uint32_t e3 = (nb > 3u && u3 == v && blo + 3u < q) ? 1u : 0u;
-                    r = (u0 < v ? 1u : 0u) + ((nb > 1u && u1 < v) ? 1u : 0u) + ((nb > 2u && u2 < v) ? 1u : 0u) + ((nb > 3u && u3 < v) ? 1u : 0u) +
-                        e0 + e1 + e2 + e3;
-                    dup = e0 | e1 | e2 | e3;
-                }
-                for (uint32_t m = blo + 4u; m < bhi; m++) {
-                    const uint32_t u = sm.u.s.V[m];
-                    const uint32_t eq = (u == v && m < q) ? 1u : 0u;
-                    r += (u < v ? 1u : 0u) + eq;
-                    dup |= eq;
-                }
-                uint32_t dead = dup;
-                if ((ts >> ((v >> 4) & 31u)) & 1u) dead |= (p.tomb[v >> 5] >> (v & 31u)) & 1u;     // rarely: the bitmap itself
-                const uint32_t P = blo + r;
-                if (dead) atomicOr(&sm.x.f.DB[P >> 5], 1u << (P & 31u));
-                fv[j] = v;
-                fp[j] = P | (dead << 31);
-            }
-        }
-        __syncthreads();
-        // ---- dead ids before every 32 sorted positions
-        const uint32_t nw = (n + 31u) >> 5;
-        uint32_t totdead;
-        {
-            const uint32_t x = (uint32_t)tid < nw ? (uint32_t)__popc(sm.x.f.DB[tid]) : 0u;
-            const uint32_t ex = block_excl_scan(x, sm.wsum, &totdead);
-            if ((uint32_t)tid <= nw) sm.x.f.DP[tid] = ex;       // (DP[nw] = all of them)
-        }
-        const uint32_t nout = n - totdead;
-        uint32_t *out = alloc(nout);                            // (barriers inside)
-        __syncthreads();
-        auto dead_before = [&](uint32_t x) -> uint32_t {
-            return sm.x.f.DP[x >> 5] + (uint32_t)__popc(sm.x.f.DB[x >> 5] & ((1u << (x & 31u)) - 1u));
-        };
-#pragma unroll
-        for (uint32_t j = 0; j < EPT; j++) {
-            if (!(fp[j] >> 31)) out[fp[j] - dead_before(fp[j])] = fv[j];       // lanes hold neighbouring ranks: coalesced
-        }
-        if (batch && (uint32_t)tid < nt) {
-            // term t sits at the sorted positions [base of its first bucket, base of the next term's first bucket)
-            const uint32_t sp0 = base_of(sm.x.f.TB[tid]), sp1 = base_of(sm.x.f.TB[tid + 1]);
-            p.out_counts[t0 + (uint32_t)tid] = (sp1 - sp0) - (dead_before(sp1) - dead_before(sp0));
-        }
-        *n_out = nout;
-        return true;
-    };
-
-    // ---- a doc range of at most BMW * 32 docs (from lo & ~31) through the LDS bitmap: exact for any input
-    auto bitmap_range = [&](uint32_t lo, uint32_t hi, uint32_t t0, auto alloc) -> uint32_t {
-        const uint32_t lo32 = lo & ~31u;
-        const uint32_t nw = ((hi - lo32) >> 5) + 1u;                      // <= BMW
-        uint32_t *bm = sm.u.bm;
-        for (uint32_t i = 4u * (uint32_t)tid; i < nw; i += 4u * MT) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
-        decode(std::true_type{}, lo, hi, lo32, false, t0, 1u, true);    // (starts with a barrier)
-        II2_STAMP(1)      // decode + mark
-        if (p.tomb) {     // the tombstone words of exactly this range, coalesced and four in flight per thread
-            const uint32_t twb = lo32 >> 5;
-            for (uint32_t i0 = (uint32_t)tid; i0 < nw; i0 += 4u * MT) {
-                uint32_t t4[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    const uint32_t i = i0 + j * MT;
-                    t4[j] = (i < nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++)
-                    if (t4[j]) bm[i0 + j * MT] &= ~t4[j];
-            }
-            __syncthreads();
-        }
-        // consecutive words per thread, as few as cover the range
-        const uint32_t wpt = (nw + MT - 1u) / MT;
-        const uint32_t w0 = wpt * (uint32_t)tid;
-        const uint32_t w1 = w0 + wpt < nw ? w0 + wpt : nw;
-        uint32_t cnt = 0;
-#pragma unroll 1
-        for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(bm[w]);
-        uint32_t tot;
-        uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
-        uint32_t *out = alloc(tot);
-#pragma unroll 1
-        for (uint32_t w = w0; w < w1; w++) {
-            uint32_t x = bm[w];
-            const uint32_t base = lo32 + 32u * w;
-            while (x) {
-                out[pos++] = base + (uint32_t)__ffs((int)x) - 1u;
-                x &= x - 1u;
-            }
-        }
-        II2_STAMP(2)      // tombstones, count, extract
-        return tot;
-    };
+    lds_barrier();
+    uint16_t *C16 = reinterpret_cast<uint16_t *>(sm.u.s.C32);
 
     const uint32_t n_tiles = *p.n_tiles_dev;       // computed by the plan kernels; the host only knows an upper bound
+    // what a tile needs from global memory before it can start is fetched one tile ahead: its descriptor, its runs and
+    // (one step later, when the descriptor is there) its terms' plan entries
+    uint4 td_nx = blockIdx.x < n_tiles ? p.desc[blockIdx.x] : make_uint4(0, 0, 1, 0);
+    uint2 rn_nx = (blockIdx.x < n_tiles && (uint32_t)tid < k) ? p.runs[(uint64_t)blockIdx.x * k + (uint32_t)tid] : make_uint2(0, 0);
+    uint2 bo_nx = make_uint2(0, 0);                // the same for a tile that takes whole lists: blk_off[t0], blk_off[t1]
+    if (blockIdx.x < n_tiles && (uint32_t)tid < k) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const uint4 td = p.desc[tile];
-        const uint32_t t0 = td.x, t1 = td.y & 0x3FFFFFFFu;
-        const uint32_t nt = t1 - t0;
-        const bool large = (td.y & MERGE_DESC_LARGE) != 0u, bm_tile = (td.y & MERGE_DESC_BITMAP) != 0u;
-        const uint32_t dlo = td.z, dhi = td.w;
-        const bool whole = dlo == 0u && dhi == 0xFFFFFFFFu;
-        unsigned long long slot = p.npre[t0];
-        uint32_t total = 0;
-
-        // One term's doc range [lo, hi], bisected until every piece fits: leaves in doc order, appended at dst + *acc.
-        // from_root: the runs of [lo, hi] are already set up.
-        auto single_term = [&](uint32_t t, uint32_t lo, uint32_t hi, bool from_root, uint32_t *dst, uint32_t *acc) {
-            uint32_t sp = 1;
-            bool first = from_root;
-            __syncthreads();
-            if (tid == 0) { sm.stk[0][0] = lo; sm.stk[0][1] = hi; }
-            while (sp > 0) {
-                __syncthreads();
-                const uint32_t a = sm.stk[sp - 1][0], b = sm.stk[sp - 1][1];
-                sp--;
-                if (!first) setup_runs(2u, t, t + 1u, 0u, a, b);
-                first = false;
-                auto alloc = [&](uint32_t) -> uint32_t * { return dst + *acc; };
-                if (sm.RB[k] == 0u) continue;
-                if (b - (a & ~31u) < BMW * 32u) { *acc += bitmap_range(a, b, t, alloc); continue; }
-                decode(std::false_type{}, a, b, 0u, false, t, 1u, true);
-                uint32_t c = 0;
-                if (sort_range(a, b, false, t, 1u, alloc, &c)) { *acc += c; continue; }
-                const uint32_t mid = a + ((b - a) >> 1);     // a < b here: a range of one doc fits the bitmap
-                __syncthreads();
-                if (tid == 0) {
-                    sm.stk[sp][0] = mid + 1u; sm.stk[sp][1] = b;
-                    sm.stk[sp + 1][0] = a;    sm.stk[sp + 1][1] = mid;
-                }
-                sp += 2;
-            }
-        };
-
-        if (!large) {
-            // ---- batch of small terms: whole lists; survivors go to the batch's own region of the parking array
-            setup_runs(0u, t0, t1, tile, 0u, 0xFFFFFFFFu);
-            II2_STAMP(0)
-            decode(std::false_type{}, 0u, 0xFFFFFFFFu, 0u, true, t0, nt, false);
-            II2_STAMP(1)
-            uint32_t *dst = p.tmp + slot;
-            auto alloc = [&](uint32_t) -> uint32_t * { return dst; };
-            if (!sort_range(0u, 0xFFFFFFFFu, true, t0, nt, alloc, &total)) {
-                // clustered ids: term by term, each through the bisection
-                total = 0;
-                for (uint32_t t = t0; t < t1; t++) {
-                    const uint32_t before = total;
-                    setup_runs(0u, t, t + 1u, tile, 0u, 0xFFFFFFFFu);
-                    single_term(t, 0u, 0xFFFFFFFFu, true, dst, &total);
-                    __syncthreads();
-                    if (tid == 0) p.out_counts[t] = total - before;
-                }
-            }
-            II2_STAMP(3)
-        } else if (dlo <= dhi) {
-            // ---- a doc range of a large term; its place inside the term's region comes from the term's bump allocator
-            // (range tiles finish in any order; the packing pass only needs every tile's slot and count)
-            setup_runs(whole ? 0u : 1u, t0, t1, tile, dlo, dhi);
-            II2_STAMP(0)
-            auto alloc = [&](uint32_t c) -> uint32_t * {
-                __syncthreads();
-                if (tid == 0) sm.ab = c ? atomicAdd(&p.term_alloc[t0], c) : 0u;
-                __syncthreads();
-                slot = p.npre[t0] + sm.ab;
-                return p.tmp + slot;
-            };
-            if (sm.RB[k] == 0u) {
-                total = 0;
-            } else if (bm_tile) {
-                total = bitmap_range(dlo, dhi, t0, alloc);
-            } else {
-                decode(std::false_type{}, dlo, dhi, 0u, false, t0, 1u, !whole);
-                II2_STAMP(1)
-                if (!sort_range(dlo, dhi, false, t0, 1u, alloc, &total)) {
-                    // more postings than LDS or clustered ids: reserve room for all the range's postings, then bisect
-                    uint32_t *dst = alloc(sm.fill);
-                    total = 0;
-                    single_term(t0, dlo, dhi, false, dst, &total);
-                }
-                II2_STAMP(3)
+        const uint4 td = td_nx;
+        const uint2 rn = rn_nx, bo = bo_nx;
+        {
+            const uint32_t nx = tile + gridDim.x;
+            if (nx < n_tiles) {
+                td_nx = p.desc[nx];
+                if ((uint32_t)tid < k) rn_nx = p.runs[(uint64_t)nx * k + (uint32_t)tid];
             }
         }
-        __syncthreads();
-        if (tid == 0) { p.tile_count[tile] = total; p.tile_slot[tile] = slot; }
-        II2_STAMP(6)
+        const uint32_t t0 = td.x, t1 = td.y & 0x3FFFFFFFu;
+        // plan entries of the tile's terms (a batch: one term per thread), in flight while the tile is decoded
+        const uint32_t my_t = t0 + ((uint32_t)tid < t1 - t0 ? (uint32_t)tid : 0u);
+        const uint32_t pf_tn = p.tn[my_t], pf_mn = p.tmin[my_t], pf_mx = p.tmax[my_t];
+        const uint32_t pf_mn0 = p.tmin[t0], pf_mx0 = p.tmax[t0];
+        const bool large = (td.y & MERGE_DESC_LARGE) != 0u, bm_tile = (td.y & MERGE_DESC_BITMAP) != 0u;
+        const bool whole = td.z == 0u && td.w == 0xFFFFFFFFu;
+        // Work list of the tile: doc ranges of cur_t0 .. cur_t0 + cur_nt, handled one after the other in doc order, their
+        // survivors appended at dst + acc.  Normally one range (the tile's).  A range that does not fit LDS or whose ids are
+        // clustered is bisected until its pieces fit the bitmap (exact for any input); a batch whose sort fails is redone
+        // term by term.
+        unsigned long long slot = p.npre[t0];
+        uint32_t *dst = p.tmp + slot;
+        bool allocated = !large;                   // tiles of a large term take their room from the term's bump allocator
+        uint32_t acc = 0;
+        uint32_t cur_t0 = t0, cur_nt = t1 - t0;
+        bool cur_batch = !large;
+        uint32_t root_mode = large ? (whole ? 0u : 1u) : 0u;      // how the runs of a root range are found (see below)
+        bool root = true;
+        uint32_t fb_next = 0, fb_end = 0, fb_acc0 = 0;
+        bool fb_active = false;
+        uint32_t sp = td.z <= td.w ? 1u : 0u;
+        lds_barrier();
+        if (tid == 0) { sm.stk[0][0] = td.z; sm.stk[0][1] = td.w; }
+
+        // room for c survivors: every thread calls it, once per range, before the range's survivors are written
+        auto alloc = [&](uint32_t c) -> uint32_t * {
+            if (!allocated) {
+                lds_barrier();
+                if (tid == 0) sm.ab = c ? atomicAdd(&p.term_alloc[t0], c) : 0u;
+                lds_barrier();
+                slot = p.npre[t0] + sm.ab;
+                dst = p.tmp + slot;
+                allocated = true;
+            }
+            return dst + acc;
+        };
+
+        while (true) {
+            if (sp == 0u) {
+                if (fb_active) {                       // a term of a batch that is redone term by term is complete
+                    lds_barrier();
+                    if (tid == 0) p.out_counts[cur_t0] = acc - fb_acc0;
+                }
+                if (fb_next >= fb_end) break;
+                cur_t0 = fb_next++;
+                cur_nt = 1u;
+                cur_batch = false;
+                fb_acc0 = acc;
+                fb_active = true;
+                root = true;
+                root_mode = 0u;
+                lds_barrier();
+                if (tid == 0) { sm.stk[0][0] = 0u; sm.stk[0][1] = 0xFFFFFFFFu; }
+                sp = 1u;
+            }
+            lds_barrier();
+            const uint32_t lo = sm.stk[sp - 1u][0], hi = sm.stk[sp - 1u][1];
+            sp--;
+            // ---- the runs of [lo, hi]: which blocks of every list have to be decoded.  mode 0: the whole lists of the
+            // terms; 1: the tile's range, searched by the plan; 2: a sub-range of the root (searched here)
+            {
+                const uint32_t mode = root ? root_mode : 2u;
+                lds_barrier();
+                if ((uint32_t)tid < k) {
+                    uint2 r;
+                    if (mode == 0u) r = (cur_t0 == t0 && cur_nt == t1 - t0) ? bo : make_uint2(my_bo[cur_t0], my_bo[cur_t0 + cur_nt]);
+                    else if (mode == 1u) r = rn;
+                    else r = blocks_of_range(sm.skp[tid], sm.RR0[tid], sm.RR1[tid], lo, hi);
+                    if (mode != 2u) { sm.RR0[tid] = r.x; sm.RR1[tid] = r.y; }
+                    sm.R0[tid] = r.x;
+                    sm.RB[tid] = r.y - r.x;            // (count; scanned below)
+                }
+                lds_barrier();
+                if (tid < 64) {
+                    const uint32_t c = (uint32_t)l < k ? sm.RB[l] : 0u;
+                    const uint32_t incl = wave_incl_scan(c);
+                    if ((uint32_t)l < k) sm.RB[l] = incl - c;
+                    if (l == 63) sm.RB[k] = incl;
+                    if (l == 0) { sm.fill = 0u; sm.ovf = 0u; }
+                }
+                lds_barrier();
+            }
+            const bool was_root = root;
+            root = false;
+            const uint32_t NB = sm.RB[k];
+            if (NB == 0u || (xskip & 8u)) continue;
+            const bool BM = (was_root && bm_tile) || (!was_root && hi - (lo & ~31u) < BMW * 32u);
+            const uint32_t lo32 = lo & ~31u;
+            const bool filter = !(lo == 0u && hi == 0xFFFFFFFFu);
+            const uint32_t bm_nw = BM ? ((hi - lo32) >> 5) + 1u : 0u;                      // <= BMW
+            if (BM) {
+                for (uint32_t i = 4u * (uint32_t)tid; i < bm_nw; i += 4u * MT) *reinterpret_cast<uint4 *>(&sm.u.bm[i]) = make_uint4(0, 0, 0, 0);
+            }
+            II2_STAMP(0)
+
+            // ---- decode the runs' blocks; every posting with lo <= id <= hi goes
+            //   BM: into the bitmap of the range (bit id - lo32);  else: to V[arrival order] (its term slot to TG in a batch).
+            // A chunk = as many consecutive blocks (one per thread) as have PCAP 16-byte payload pieces between them; a thread
+            // then walks one piece: the 16 partial gap sums and which bytes end a posting; a scan over the chunk's pieces gives
+            // every piece the sum before it, and the difference to its block's first piece the id it starts from.
+            for (uint32_t g0 = 0; g0 < NB;) {
+                lds_barrier();                     // the chunk before is done with the tables
+                const uint32_t g = g0 + (uint32_t)tid;
+                const bool valid = g < NB;
+                uint32_t np = 0, first = 0, ti = 0, len = 0;
+                const uint8_t *bp = nullptr;
+                if (valid) {
+                    uint32_t a = 0, e = k;            // RB[a] <= g < RB[e]
+                    while (e - a > 1u) { const uint32_t m = (a + e) >> 1; if (sm.RB[m] <= g) a = m; else e = m; }
+                    const uint32_t b = sm.R0[a] + (g - sm.RB[a]);
+                    const ii2_skip *sk = sm.skp[a];
+                    const ii2_skip e0 = sk[b];
+                    first = e0.first_doc;
+                    len = sk[b + 1u].byte_off - e0.byte_off;
+                    if (len > 1280u) len = 1280u;     // (a block holds <= 256 postings of <= 5 bytes; imported segments are validated)
+                    np = (len + 15u) >> 4;
+                    bp = sm.pay[a] + e0.byte_off;
+                    if (cur_batch) { ti = sm.bls[a][b] - sm.lbase[a] - cur_t0; ti = ti < cur_nt ? ti : cur_nt - 1u; }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < PSLOT; j++) sm.x.d.PJ[(uint32_t)tid + j * MT] = 0;
+                uint32_t tot;
+                const uint32_t pex = block_excl_scan(np, sm.wsum, &tot);
+                const bool ok = valid && pex + np <= PCAP;          // a prefix of the threads (pex ascends); never empty (np <= 80)
+                const uint32_t nchunk = block_count(ok, sm.wsum);
+                if (ok) {
+                    sm.x.d.BF[tid] = first;
+                    sm.x.d.BP[tid] = bp;
+                    sm.x.d.BI[tid] = ti | (len << 16);
+                    sm.x.d.PB[tid] = (uint16_t)pex;
+                    if (np) sm.x.d.PJ[pex] = (uint16_t)(tid + 1);     // marks the block's first piece
+                    if ((uint32_t)tid == nchunk - 1u) sm.tp = pex + np;
+                }
+                {   // the blocks' first postings (their ids are in the skip entries)
+                    const bool in = ok && first >= lo && first <= hi;
+                    if (BM) {
+                        if (in) atomicOr(&sm.u.bm[(first - lo32) >> 5], 1u << (first & 31u));
+                    } else {
+                        const unsigned long long m = __ballot(in);
+                        if (m != 0ull) {
+                            uint32_t wb = 0;
+                            if (l == 0) wb = atomicAdd(&sm.fill, (uint32_t)__popcll(m));
+                            wb = wave_bcast(wb, 0);
+                            const uint32_t pos = wb + (uint32_t)__popcll(m & ((1ull << l) - 1ull));
+                            if (in && pos < MCAP) { sm.u.s.V[pos] = first; if (cur_batch) sm.u.s.TG[pos] = (uint16_t)ti; }
+                        }
+                    }
+                }
+                lds_barrier();
+                const uint32_t tp = sm.tp;
+                {   // piece -> block: inclusive prefix maximum over the marks, PSLOT consecutive pieces per thread
+                    uint32_t m[PSLOT], run = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < PSLOT; j++) { m[j] = sm.x.d.PJ[PSLOT * (uint32_t)tid + j]; run = m[j] > run ? m[j] : run; m[j] = run; }
+                    const uint32_t wi = wave_incl_max(run);
+                    if (l == 63) sm.wmax[wv] = wi;
+                    uint32_t before = (uint32_t)__shfl_up((int)wi, 1, 64);
+                    if (l == 0) before = 0u;
+                    lds_barrier();
+                    for (int w2 = 0; w2 < wv; w2++) before = sm.wmax[w2] > before ? sm.wmax[w2] : before;
+#pragma unroll
+                    for (uint32_t j = 0; j < PSLOT; j++) sm.x.d.PJ[PSLOT * (uint32_t)tid + j] = (uint16_t)(m[j] > before ? m[j] : before);
+                }
+                lds_barrier();
+                uint32_t carry = 0;
+                for (uint32_t it = 0; it < tp; it += MT) {
+                    const uint32_t pc = it + (uint32_t)tid;
+                    const bool pv = pc < tp;
+                    uint32_t jb = 0, val[16], tmask = 0, bi = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) val[i] = 0;
+                    if (pv) {
+                        jb = (uint32_t)sm.x.d.PJ[pc] - 1u;
+                        bi = sm.x.d.BI[jb];
+                        const uint32_t off = 16u * (pc - (uint32_t)sm.x.d.PB[jb]);
+                        const uint32_t rem = (bi >> 16) - off;                 // payload bytes from my first one on (>= 1)
+                        const uint8_t *pp = sm.x.d.BP[jb] + off;
+                        const uint4 w4 = gload16(pp);                          // (segments carry 16 bytes of padding)
+                        const uint32_t prev = off ? gload4(pp - 4) : 0u;
+                        uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+                        if (rem < 16u) {      // a block's last piece: the bytes past its end count as zero gaps (the sums stay exact ids)
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t nj = rem > 4u * j ? (rem - 4u * j < 4u ? rem - 4u * j : 4u) : 0u;
+                                w[j] &= nj >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nj)) - 1u);
+                            }
+                        }
+                        // continuation bytes pending right before my first byte (varints are <= 5 bytes)
+                        uint32_t sh = 7u * ((uint32_t)__clz((int)~(prev | 0x7F7F7F7Fu)) >> 3);
+                        uint32_t sum = 0;
+#pragma unroll
+                        for (int i = 0; i < 16; i++) {
+                            const uint32_t c7 = __builtin_amdgcn_ubfe(w[i >> 2], 8 * (i & 3), 7);
+                            const uint32_t cm = (uint32_t)__builtin_amdgcn_sbfe((int)w[i >> 2], 8 * (i & 3) + 7, 1);    // -1: continuation byte
+                            sum += c7 << (sh & 31u);
+                            sh = (sh + 7u) & cm;
+                            tmask |= ~cm & (1u << i);
+                            val[i] = sum;
+                        }
+                        if (rem < 16u) tmask &= (1u << rem) - 1u;      // bytes past the block's end are not postings
+                    }
+                    if (xskip & 1u) tmask = 0;
+                    uint32_t tots;
+                    const uint32_t pex2 = carry + block_excl_scan(val[15], sm.wsum, &tots);
+                    carry += tots;
+                    if (pv) sm.x.d.PX[pc] = pex2;
+                    lds_barrier();
+                    const uint32_t base = pv ? sm.x.d.BF[jb] + pex2 - sm.x.d.PX[sm.x.d.PB[jb]] : 0u;
+                    if (BM) {
+                        if (pv) {
+                            const uint32_t rb = base - lo32, span = hi - lo32;
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                const uint32_t rel = rb + val[i];
+                                if (((tmask >> i) & 1u) && rel <= span) atomicOr(&sm.u.bm[rel >> 5], 1u << (rel & 31u));
+                            }
+                        }
+                    } else {
+                        // pieces that reach over an end of the range drop the ids outside it (the others skip the test)
+                        if (filter && __ballot(pv && (base + val[0] < lo || base + val[15] > hi)) != 0ull) {
+                            uint32_t im = 0;
+#pragma unroll
+                            for (int i = 0; i < 16; i++) im |= (base + val[i] - lo <= hi - lo) ? 1u << i : 0u;
+                            tmask &= im;
+                        }
+                        const uint32_t c = (uint32_t)__popc(tmask);
+                        const uint32_t incl = wave_incl_scan(c);
+                        const uint32_t wtot = wave_bcast(incl, 63);
+                        if (wtot) {
+                            uint32_t wb = 0;
+                            if (l == 0) wb = atomicAdd(&sm.fill, wtot);
+                            wb = wave_bcast(wb, 0);
+                            uint32_t pos = wb + incl - c;
+                            if (wb + wtot <= MCAP) {
+                                const uint16_t tg = (uint16_t)(bi & 0xFFFFu);
+#pragma unroll
+                                for (int i = 0; i < 16; i++) {
+                                    if ((tmask >> i) & 1u) {
+                                        sm.u.s.V[pos] = base + val[i];
+                                        if (cur_batch) sm.u.s.TG[pos] = tg;
+                                        pos++;
+                                    }
+                                }
+                            }       // else: the range holds more than LDS (fill > MCAP): it is split below
+                        }
+                    }
+                }
+                g0 += nchunk;
+            }
+            lds_barrier();
+            II2_STAMP(BM ? 5 : (cur_batch ? 1 : 3))
+            if (was_root && (uint32_t)tid < k && tile + gridDim.x < n_tiles) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
+
+            if (BM) {
+                // ---- bitmap: the union, the dedupe and the order came with the representation; clear the tombstoned docs
+                // word by word (coalesced loads of exactly the range's words), count, extract
+                uint32_t *bm = sm.u.bm;
+                if (tid == 0) {     // a sub-range need not start or end at a word
+                    if (lo & 31u) bm[0] &= ~((1u << (lo & 31u)) - 1u);
+                    if ((hi & 31u) != 31u) bm[bm_nw - 1u] &= (2u << (hi & 31u)) - 1u;
+                }
+                if (p.tomb) {
+                    const uint32_t twb = lo32 >> 5;
+                    for (uint32_t i0 = (uint32_t)tid; i0 < bm_nw; i0 += 4u * MT) {
+                        uint32_t t4[4];
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++) {
+                            const uint32_t i = i0 + j * MT;
+                            t4[j] = (i < bm_nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < 4u; j++)
+                            if (t4[j]) bm[i0 + j * MT] &= ~t4[j];
+                    }
+                }
+                lds_barrier();
+                // consecutive words per thread, as few as cover the range
+                const uint32_t wpt = (bm_nw + MT - 1u) / MT;
+                const uint32_t w0 = wpt * (uint32_t)tid;
+                const uint32_t w1 = w0 + wpt < bm_nw ? w0 + wpt : bm_nw;
+                uint32_t cnt = 0;
+#pragma unroll 1
+                for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(bm[w]);
+                uint32_t tot;
+                uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
+                uint32_t *out = alloc(tot);
+#pragma unroll 1
+                for (uint32_t w = w0; w < w1; w++) {
+                    uint32_t x = bm[w];
+                    const uint32_t base = lo32 + 32u * w;
+                    while (x) {
+                        out[pos++] = base + (uint32_t)__ffs((int)x) - 1u;
+                        x &= x - 1u;
+                    }
+                }
+                acc += tot;
+                II2_STAMP(6)
+                continue;
+            }
+
+            // ---- sort the decoded postings by buckets and write the survivors in (term, id) order
+            if (xskip & 2u) { acc += 0; continue; }
+            const uint32_t n = sm.fill;
+            bool sorted = n <= MCAP;
+            // a large term's range takes room for all its input postings from the term's bump allocator (inputs never
+            // outnumber the region); the atomic is issued here and its answer is only needed when the survivors are written
+            uint32_t ab_reg = 0;                    // (thread 0 parks the answer in LDS only when it is about to be needed)
+            if (!allocated && tid == 0) ab_reg = n ? atomicAdd(&p.term_alloc[t0], n) : 0u;
+            const uint32_t nj = (n + MT - 1u) / MT;               // sort passes that have postings (<= EPT)
+            uint32_t *C32 = sm.u.s.C32;
+            uint32_t u_mn = 0, u_nbm1 = 0;
+            float u_scale = 0.0f;
+            unsigned long long slots = 0ull;
+            if (sorted) {
+                for (uint32_t i = (uint32_t)tid; i < MCAP / 2u + 4u; i += MT) C32[i] = 0u;
+                if ((uint32_t)tid < MCAP / 32u + 1u) sm.x.f.DB[tid] = 0u;
+                // bucket maps: term t of a batch owns floor(n_t * MCAP / n) buckets, a range tile all MCAP of them
+                if (cur_batch) {
+                    uint32_t nbk = 0, mn = 0, mx = 0;
+                    if ((uint32_t)tid < cur_nt) {
+                        const uint32_t n_t = pf_tn;            // (a batch is always the tile's own terms)
+                        mn = pf_mn;
+                        mx = pf_mx;
+                        nbk = n_t ? (uint32_t)(((uint64_t)n_t * MCAP) / n) : 0u;
+                    }
+                    uint32_t totb;
+                    const uint32_t tb = block_excl_scan(nbk, sm.wsum, &totb);
+                    if ((uint32_t)tid < cur_nt) {
+                        sm.x.f.TB[tid] = (uint16_t)tb;
+                        sm.x.f.TT[tid] = make_uint2(mn, __float_as_uint(nbk ? (float)nbk / ((float)(mx - mn) + 1.0f) : 0.0f));
+                    }
+                    if (tid == 0) sm.x.f.TB[cur_nt] = (uint16_t)totb;
+                } else {
+                    const uint32_t t_mn = cur_t0 == t0 ? pf_mn0 : p.tmin[cur_t0], t_mx = cur_t0 == t0 ? pf_mx0 : p.tmax[cur_t0];
+                    u_mn = lo > t_mn ? lo : t_mn;
+                    const uint32_t mxr = hi < t_mx ? hi : t_mx;
+                    u_nbm1 = MCAP - 1u;
+                    u_scale = (float)MCAP / ((float)((mxr > u_mn ? mxr : u_mn) - u_mn) + 1.0f);
+                }
+                lds_barrier();
+                // ---- bucket of every posting, slot inside the bucket
+                bool over = false;
+#pragma unroll
+                for (uint32_t j = 0; j < EPT; j++) {
+                    const uint32_t i = (uint32_t)tid + j * MT;
+                    if (j < nj && i < n) {
+                        const uint32_t v = sm.u.s.V[i];
+                        uint32_t mn = u_mn, nbm1 = u_nbm1, tb = 0;
+                        float sc = u_scale;
+                        if (cur_batch) {
+                            const uint32_t ti = sm.u.s.TG[i];
+                            const uint2 te = sm.x.f.TT[ti];
+                            tb = sm.x.f.TB[ti];
+                            nbm1 = (uint32_t)sm.x.f.TB[ti + 1u] - tb - 1u;
+                            mn = te.x;
+                            sc = __uint_as_float(te.y);
+                        }
+                        const uint32_t bq = (uint32_t)((float)(v - mn) * sc);
+                        const uint32_t b = tb + (bq < nbm1 ? bq : nbm1);
+                        sm.u.s.TG[i] = (uint16_t)b;
+                        const uint32_t sh = 16u * (b & 1u);
+                        uint32_t slot_ = (atomicAdd(&C32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                        if (slot_ > BKT_LIMIT) { over = true; slot_ = BKT_LIMIT; }
+                        slots |= (unsigned long long)slot_ << (4u * j);
+                    }
+                }
+                if (over) sm.ovf = 1u;
+                lds_barrier();
+                sorted = sm.ovf == 0u;
+            }
+            if (sorted) {
+                // ---- exclusive scan of the counters in place: EPT buckets = EPT / 2 words per thread
+                {
+                    uint32_t c[EPT], sum = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < EPT / 2u; j++) {
+                        const uint32_t w = C32[(EPT / 2u) * (uint32_t)tid + j];
+                        c[2u * j] = w & 0xFFFFu;
+                        c[2u * j + 1u] = w >> 16;
+                        sum += c[2u * j] + c[2u * j + 1u];
+                    }
+                    uint32_t tot_;
+                    uint32_t run = block_excl_scan(sum, sm.wsum, &tot_);
+#pragma unroll
+                    for (uint32_t j = 0; j < EPT / 2u; j++) {
+                        const uint32_t e0 = run;
+                        run += c[2u * j];
+                        const uint32_t e1 = run;
+                        run += c[2u * j + 1u];
+                        C32[(EPT / 2u) * (uint32_t)tid + j] = e0 | (e1 << 16);
+                    }
+                    if (tid == (int)MT - 1) C32[MCAP / 2u] = run;        // base of the bucket past the last one
+                }
+                lds_barrier();
+                // ---- scatter into bucket order (in place: all reads, then all writes)
+                {
+                    uint32_t v[EPT], pk[EPT], ts[EPT];
+#pragma unroll
+                    for (uint32_t j = 0; j < EPT; j++) {
+                        const uint32_t i = (uint32_t)tid + j * MT;
+                        v[j] = 0; pk[j] = 0; ts[j] = 0;
+                        if (j < nj && i < n) {
+                            v[j] = sm.u.s.V[i];
+                            const uint32_t b = sm.u.s.TG[i];
+                            pk[j] = ((uint32_t)C16[b] + (uint32_t)((slots >> (4u * j)) & 15ull)) | (b << 16);
+                            // tombstones: most tests stop at the summary (1 bit per 16 docs, L2-resident)
+                            if (p.tomb && (v[j] >> 5) < p.tomb_nwords) ts[j] = p.tomb_summary[v[j] >> 9];
+                        }
+                    }
+                    lds_barrier();
+#pragma unroll
+                    for (uint32_t j = 0; j < EPT; j++) {
+                        const uint32_t i = (uint32_t)tid + j * MT;
+                        if (j < nj && i < n) {
+                            uint32_t tag = pk[j] >> 16;
+                            if ((ts[j] >> ((v[j] >> 4) & 31u)) & 1u) tag |= ((p.tomb[v[j] >> 5] >> (v[j] & 31u)) & 1u) << 15;     // rarely: the bitmap itself
+                            sm.u.s.V[pk[j] & 0xFFFFu] = v[j];
+                            sm.u.s.TG[pk[j] & 0xFFFFu] = (uint16_t)tag;
+                        }
+                    }
+                }
+                lds_barrier();
+                if (xskip & 4u) continue;
+                // ---- every posting ranks itself inside its bucket: final position, duplicate / tombstone flag
+                uint32_t fv[EPT], fp[EPT];
+#pragma unroll
+                for (uint32_t j = 0; j < EPT; j++) {
+                    const uint32_t q = (uint32_t)tid + j * MT;
+                    fv[j] = 0; fp[j] = 0x80000000u;
+                    if (j < nj && q < n) {
+                        const uint32_t v = sm.u.s.V[q];
+                        const uint32_t tg = sm.u.s.TG[q];                         // bucket | tombstoned << 15
+                        const uint32_t b = tg & 0x7FFFu;
+                        const uint32_t blo = C16[b], nb = (uint32_t)C16[b + 1u] - blo;
+                        const uint32_t qi = q - blo;                              // my place in the bucket
+                        // the first four of the bucket without a loop (buckets hold one posting on average: lanes that loop make
+                        // the whole wave wait for the fullest bucket among its 64).  A place past the bucket counts as my own id
+                        // at a later place: neither smaller nor an earlier copy.
+                        const uint32_t *B4 = &sm.u.s.V[blo];
+                        const uint32_t u0 = B4[0], u1 = nb > 1u ? B4[1] : v, u2 = nb > 2u ? B4[2] : v, u3 = nb > 3u ? B4[3] : v;
+                        const uint32_t e0 = (u0 == v && 0u < qi) ? 1u : 0u, e1 = (u1 == v && 1u < qi) ? 1u : 0u;
+                        const uint32_t e2 = (u2 == v && 2u < qi) ? 1u : 0u, e3 = (u3 == v && 3u < qi) ? 1u : 0u;
+                        uint32_t r = (u0 < v ? 1u : 0u) + (u1 < v ? 1u : 0u) + (u2 < v ? 1u : 0u) + (u3 < v ? 1u : 0u) + e0 + e1 + e2 + e3;
+                        uint32_t dead = e0 | e1 | e2 | e3 | (tg >> 15);
+#pragma unroll 1
+                        for (uint32_t m = 4u; m < nb; m++) {
+                            const uint32_t u = B4[m];
+                            const uint32_t eq = (u == v && m < qi) ? 1u : 0u;
+                            r += (u < v ? 1u : 0u) + eq;
+                            dead |= eq;
+                        }
+                        const uint32_t P = blo + r;
+                        if (dead) atomicOr(&sm.x.f.DB[P >> 5], 1u << (P & 31u));
+                        fv[j] = v;
+                        fp[j] = P | (dead << 31);
+                    }
+                }
+                lds_barrier();
+                // ---- dead ids before every 32 sorted positions
+                const uint32_t nw = (n + 31u) >> 5;
+                uint32_t totdead;
+                {
+                    const uint32_t x = (uint32_t)tid < nw ? (uint32_t)__popc(sm.x.f.DB[tid]) : 0u;
+                    const uint32_t ex = block_excl_scan(x, sm.wsum, &totdead);
+                    if ((uint32_t)tid <= nw) sm.x.f.DP[tid] = ex;       // (DP[nw] = all of them)
+                }
+                const uint32_t nout = n - totdead;
+                if (!allocated && tid == 0) sm.ab = ab_reg;
+                lds_barrier();
+                if (!allocated) { slot = p.npre[t0] + sm.ab; dst = p.tmp + slot; allocated = true; }
+                uint32_t *out = dst + acc;
+                auto dead_before = [&](uint32_t x) -> uint32_t {
+                    return sm.x.f.DP[x >> 5] + (uint32_t)__popc(sm.x.f.DB[x >> 5] & ((1u << (x & 31u)) - 1u));
+                };
+#pragma unroll
+                for (uint32_t j = 0; j < EPT; j++) {
+                    if (!(fp[j] >> 31)) out[fp[j] - dead_before(fp[j])] = fv[j];       // lanes hold neighbouring ranks: coalesced
+                }
+                if (cur_batch && (uint32_t)tid < cur_nt) {
+                    // term t sits at the sorted positions [base of its first bucket, base of the next term's first bucket)
+                    const uint32_t sp0 = C16[sm.x.f.TB[tid]], sp1 = C16[sm.x.f.TB[tid + 1]];
+                    p.out_counts[cur_t0 + (uint32_t)tid] = (sp1 - sp0) - (dead_before(sp1) - dead_before(sp0));
+                }
+                acc += nout;
+                II2_STAMP(cur_batch ? 2 : 4)
+                continue;
+            }
+            // ---- the range does not fit LDS, or its ids are clustered so that a bucket overflowed
+            if (cur_batch) {
+                fb_next = cur_t0;                  // the batch again, term by term (nothing of it was written)
+                fb_end = cur_t0 + cur_nt;
+                acc = 0;
+                continue;
+            }
+            const uint32_t mid = lo + ((hi - lo) >> 1);     // lo < hi here: a range of one doc fits the bitmap
+            if (!allocated && tid == 0) sm.ab = ab_reg;
+            lds_barrier();
+            if (!allocated) { slot = p.npre[t0] + sm.ab; dst = p.tmp + slot; allocated = true; }     // (room for all n postings, see above)
+            if (tid == 0) {
+                sm.stk[sp][0] = mid + 1u; sm.stk[sp][1] = hi;
+                sm.stk[sp + 1u][0] = lo;  sm.stk[sp + 1u][1] = mid;
+            }
+            sp += 2u;
+            II2_STAMP(7)
+        }
+        if (tid == 0) { p.tile_count[tile] = acc; p.tile_slot[tile] = slot; }
+        II2_STAMP(7)
     }
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];

@@ -78,9 +78,9 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.small_max = (cap * 5u) / 14u;         // 2560
     p.batch_q = cap - p.small_max;          // 4608
     p.wmin = (cap + MERGE_NT_MAX - 1u) / MERGE_NT_MAX;
-    p.range_target = ctx->opt_merge_large_tile > 0 ? std::min<uint32_t>((uint32_t)ctx->opt_merge_large_tile, cap) : p.batch_q;
+    p.range_target = ctx->opt_merge_large_tile > 0 ? std::min<uint32_t>((uint32_t)ctx->opt_merge_large_tile, cap) : (cap / 7u) * 6u;
     p.bitmap_tiles = ctx->opt_merge_bitmap ? 1u : 0u;
-    p.bitmap_sparsity = ctx->opt_merge_bitmap > 1 ? (uint32_t)std::min<int64_t>(ctx->opt_merge_bitmap, 4096) : 40u;
+    p.bitmap_sparsity = ctx->opt_merge_bitmap > 1 ? (uint32_t)std::min<int64_t>(ctx->opt_merge_bitmap, 4096) : 80u;
     // upper bound of the tile count (the exact one is computed on the device and stays there): a large term has more than
     // small_max postings and takes ceil(n / range_target) range tiles or, as a bitmap term with >= 1 posting per
     // `sparsity` docs, ceil(span / MERGE_BM_DOCS) <= n * sparsity / MERGE_BM_DOCS + 1 bitmap tiles; a batch ends when its
@@ -161,6 +161,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.out_cap = out_cap;
     p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
     p.debug = nullptr;
+    p.pad0 = (uint32_t)ctx->opt_merge_skip;
     if (ctx->opt_debug_stamps) {
         if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
