@@ -13,16 +13,25 @@ One run times BOTH halves of the metric ("intersect + segment-merge") and prints
   workload with >= 64 host cores; with fewer, the tail of the term range at ~3M postings per core, the head terms
   checked for order and tombstones only: --cpu-sample).
 * `merge_strong` (every N): configs[3] — ONE fixed problem, 64 segments x 1M terms, the terms cut into N contiguous
-  ranges balanced by estimated merge cost (shard.go:362-378 ranges are contiguous too); every rank merges its range, then the
-  merged postings are concatenated in rank order with ii2_allgatherv (RCCL).  This is the STRONG-scaling figure the
-  1 -> 8 GPU target is about.  (The headline is WEAK scaling: every rank intersects its own doc-range shard.)
+  ranges balanced by estimated merge cost (shard.go:362-378 ranges are contiguous too); every rank merges its range in
+  chunks into DV1 segments (what Shard.Merge writes) and the merged segments are exchanged ENCODED with ii2_seg_allgather
+  (RCCL), chunk i on a second context while chunk i + 1 merges.  Its `value` counts the exchange: this is the
+  STRONG-scaling figure the 1 -> 8 GPU target is about.  (The headline is WEAK scaling: every rank intersects its own
+  100M-doc universe, no exchange in the timed region.)
+* `c5` (every N): configs[4] — one 8-term AND over a 1B-doc index (Zipf ranks 2 ... 16384, a common core in every list),
+  the doc-id space cut into N contiguous ranges (sharding.doc_range), every rank checked bit-exactly against the oracle on
+  its range, results concatenated in rank order with ii2_allgatherv inside the timed region.
 
-N > 1: one process per GPU, launched by torch.distributed.run; ranks do not talk during the timed steps of the
-intersection (the reference's shards are independent, inverted_index.go:83-103).
+N > 1: one process per GPU.  `python bench.py --gpus N` starts the N ranks itself (torch.distributed.run on 127.0.0.1)
+when no launcher did (WORLD_SIZE unset) — before this process touches the GPU; under a launcher the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*.  Ranks do not talk during the timed steps of the intersection (the
+reference's shards are independent, inverted_index.go:83-103).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -42,7 +51,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--docs", type=int, default=100_000_000, help="doc-id universe per GPU (config 2: 100M)")
-    ap.add_argument("--workload", choices=["all", "intersect", "merge", "strong"], default="all")
+    ap.add_argument("--workload", choices=["all", "intersect", "merge", "strong", "c5"], default="all")
     ap.add_argument("--tombstones", action="store_true", help="apply a 1%% tombstone bitmap during the intersection")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-timeout", type=int, default=120, help="seconds the all-gatherv exchange may take (N > 1)")
@@ -52,6 +61,11 @@ def parse():
     ap.add_argument("--merge-mean", type=float, default=1000.0)
     ap.add_argument("--merge-steps", type=int, default=0, help="timed merges (0: min(steps, 10))")
     ap.add_argument("--cold-pairs", type=int, default=4)
+    ap.add_argument("--strong-chunks", type=int, default=4, help="merge_strong: chunks a rank's term range is merged and exchanged in")
+    ap.add_argument("--c5-docs", type=int, default=1_000_000_000, help="c5: doc-id universe of the whole index (config 5: 1B)")
+    ap.add_argument("--c5-steps", type=int, default=0, help="c5: timed queries (0: min(steps, 20))")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: the ranks only come up (gloo), count themselves and rank 0 prints the line's frame - checks the launch")
     ap.add_argument("--cpu-sample", choices=["auto", "full", "bounded"], default="auto",
                     help="merge: what the oracle checks and times - the whole workload (auto with >= 64 host cores) or the tail of "
                          "the term range, about 3M postings per core (auto with fewer)")
@@ -59,6 +73,40 @@ def parse():
                     help="N > 1 on a ONE-GPU box: every rank uses cuda:0, the process group is gloo and the exchange takes the "
                          "torch fallback (RCCL refuses two ranks on one device) - checks the multi-rank control flow, the numbers mean nothing")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`bench.py --gpus N` without a launcher: the N ranks are started here, as children, before this process touches
+    the GPU (a process that has initialised the GPU must not be replaced or forked).  Rank 0's JSON line passes through
+    on stdout; the exit code is the launcher's (non-zero when any rank failed)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL between processes needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, cores_available() // max(args.gpus, 1))))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The launch, without a GPU: every rank joins a gloo group, the ranks count themselves, rank 0 prints the frame."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    n = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        n = int(t.item())
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "postings/s", "n_gpus": world, "ranks_counted": n, "steps": args.steps,
+                          "warmup": args.warmup, "dry_run": True}), flush=True)
+    return 0 if n == world else 6
 
 
 def cores_available():
@@ -132,6 +180,7 @@ class Job:
         self.ctx = Context(device)
         self.ctx.selftest()
         self.comm = None           # "ii2" | "torch" once decided (identically on every rank)
+        self.comm_main = False     # the job's own context has its communicator
         self.rc = 0
 
     def sync_all(self):
@@ -147,11 +196,18 @@ class Job:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
-    def init_comm(self):
-        """The library's own RCCL communicator (torch's only carries the unique id).  Every rank learns whether EVERY
-        rank got one — ranks must never run different collectives against each other."""
-        if self.comm is not None or self.world == 1:
+    def init_comm(self, ctx=None):
+        """The library's own RCCL communicator (torch's only carries the unique id) for `ctx` (default: the job's context).
+        Every rank learns whether EVERY rank got one — ranks must never run different collectives against each other."""
+        if self.world == 1:
             return
+        if ctx is None:
+            if self.comm_main:
+                return
+            ctx = self.ctx
+            self.comm_main = True
+        if self.comm == "torch":
+            return                    # a communicator already failed somewhere: every rank stays on the torch exchange
         from inverted_index_2_amd import comm_unique_id
         ok = 1
         try:
@@ -159,7 +215,7 @@ class Job:
                 raise RuntimeError("rehearsal on one GPU: the library communicator is not attempted")
             uid = [comm_unique_id() if self.rank == 0 else None]
             self.dist.broadcast_object_list(uid, src=0)
-            self.ctx.comm_init(self.world, self.rank, uid[0])
+            ctx.comm_init(self.world, self.rank, uid[0])
         except Exception as e:  # noqa: BLE001
             print("rank %d: ii2_comm_init failed: %r" % (self.rank, e), file=sys.stderr, flush=True)
             ok = 0
@@ -517,8 +573,10 @@ def bench_merge(job):
 
 def bench_merge_strong(job):
     """configs[3]: ONE 64-segment x 1M-term merge, the terms cut into `world` contiguous ranges balanced by estimated
-    merge cost; every rank merges its range; the merged postings are concatenated in rank order over RCCL."""
+    merge cost; every rank merges its range chunk by chunk into DV1 segments (ii2_merge_segments_to_seg) and the merged
+    segments are exchanged encoded (ii2_seg_allgather on a second context: chunk i travels while chunk i + 1 merges)."""
     args, ctx, world, rank = job.args, job.ctx, job.world, job.rank
+    from concurrent.futures import ThreadPoolExecutor
     from inverted_index_2_amd import sharding, synth
     T, k = args.merge_terms, args.strong_segments
     ranges = sharding.balanced_term_ranges(T, args.merge_mean, args.docs, world)
@@ -543,50 +601,285 @@ def bench_merge_strong(job):
         raise SystemExit(f"rank {rank}: merged lists are not strictly ascending")
     if np.isin(g_vals[:: max(1, g_vals.size // 4_000_000)], removed).any():
         raise SystemExit(f"rank {rank}: a tombstoned id survived the merge")
-    del offs, vals
+    del vals
     steps = args.merge_steps or min(args.steps, 10)
-    dt, dev_ms, dev_n = time_merges(job, segs, tomb, out_off, out_vals, steps)
+    dt_raw, dev_ms, dev_n = time_merges(job, segs, tomb, out_off, out_vals, steps)     # the raw-output merge of the whole range, for reference
+    out_off.free()
+    out_vals.free()
+
+    # ---- the range in chunks (contiguous term sub-ranges of about equal estimated cost), each chunk's k views made once
+    per_term = np.zeros(t1 - t0, np.int64)
+    for o in offs:
+        per_term += np.diff(o.astype(np.int64))
+    del offs
+    n_chunks = max(1, min(args.strong_chunks, t1 - t0))
+    cum = np.concatenate([[0.0], np.cumsum(sharding.merge_cost_weights(per_term))])
+    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * c / n_chunks)) for c in range(1, n_chunks)] + [t1 - t0]
+    cuts = [max(a, b) for a, b in zip(cuts, np.maximum.accumulate(cuts))]
+    views = []
+    for a, b2 in zip(cuts[:-1], cuts[1:]):
+        idx = np.arange(a, b2, dtype=np.int64)
+        views.append([ctx.select(sg, idx) for sg in segs] if b2 > a else None)
+    # the exchange runs on a second context of the same GPU (own stream, own communicator): the two only share segments
+    from inverted_index_2_amd import Context
+    xctx = Context(ctx.device)
+    impl = "ii2_seg_allgather on one rank (a device copy)"
+    if world > 1:
+        job.init_comm(xctx)
+        impl = ("ii2_seg_allgather: ncclAllGather of the shapes + three grouped ncclSend/ncclRecv exchanges (list table, skip table, "
+                "payload) per chunk over xGMI" if job.comm == "ii2" else "torch.distributed.all_gather of the padded DV1 arrays (ii2_comm_init failed on some rank)")
+
+    def exchange(seg):
+        """One chunk's merged segment to every rank; returns (bytes this rank received, own part intact)."""
+        if seg is None:
+            seg_bytes = 0
+        else:
+            inf = seg.info
+            seg_bytes = int(inf.n_bytes + 8 * inf.n_blocks + 4 * inf.n_lists)
+        if world == 1 and seg is None:
+            return 0, True
+        if world == 1 or job.comm == "ii2":
+            if seg is None:          # a chunk in which nothing survived still takes part in the collective
+                seg = empty_seg
+            g = xctx.seg_allgather(seg)
+            ginf = g.info
+            got = int(ginf.n_bytes + 8 * ginf.n_blocks + 4 * ginf.n_lists)
+            ok = ginf.n_postings >= seg.info.n_postings and ginf.n_lists >= seg.info.n_lists
+            g.free()
+            return got, bool(ok)
+        # fallback (the library communicator failed somewhere): the three arrays through torch's communicator, padded
+        torch, dist = job.torch, job.dist
+        blk, skip, payload = seg.export() if seg is not None else (np.zeros(1, np.uint32), np.zeros(1, np.uint64), np.zeros(0, np.uint8))
+        raw = np.concatenate([blk.view(np.uint8), skip.view(np.uint8), payload.view(np.uint8)])
+        n = torch.tensor([raw.size], dtype=torch.int64, device=job.dev)
+        ns = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(ns, n)
+        cap = max(int(x.item()) for x in ns)
+        mine = torch.from_numpy(np.concatenate([raw, np.zeros(cap - raw.size, np.uint8)])).to(job.dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        ok = bool(torch.equal(parts[rank][: raw.size].cpu(), torch.from_numpy(raw)))
+        return int(sum(int(x.item()) for x in ns)), ok
+
+    empty_seg = ctx.encode_lists([np.empty(0, np.uint32)]) if world > 1 else None
+
+    def one_pass(with_exchange):
+        """All chunks of this rank: merge to a segment, hand it to the exchange thread, merge the next."""
+        pending, merged = [], []
+        for vw in views:
+            sg = None
+            if vw is not None:
+                sg, _ = ctx.merge_to_segment(vw, tomb)
+            merged.append(sg)
+            if with_exchange:
+                pending.append(pool.submit(exchange, sg))
+        got = [f.result() for f in pending]
+        for sg in merged:
+            if sg is not None:
+                sg.free()
+        return got
+
+    pool = ThreadPoolExecutor(max_workers=1)
+    # correctness of the chunked, encoded path, once: the chunks' merged segments decode to the raw merge of the range
+    chk_ok = True
+    pos = 0
+    for vw, a, b2 in zip(views, cuts[:-1], cuts[1:]):
+        if vw is None:
+            continue
+        sg, stc = ctx.merge_to_segment(vw, tomb)
+        n_c = int(g_off[b2] - g_off[a])
+        if sg is None:
+            chk_ok &= n_c == 0
+            continue
+        po, vv = sg.decode()
+        keep = np.diff(g_off[a:b2 + 1]) > 0                   # the encoder keeps every term slot; empty ones have no postings
+        chk_ok &= vv.size == n_c and np.array_equal(vv, g_vals[int(g_off[a]):int(g_off[b2])]) and \
+            np.array_equal(np.diff(po.astype(np.int64)) > 0, keep)
+        sg.free()
+        pos += n_c
+    if not chk_ok:
+        print(f"rank {rank}: the chunked merge-to-segment path differs from the raw merge", file=sys.stderr, flush=True)
+        job.rc = 5
+    one_pass(True)                                            # warm-up: staging buffers and, N > 1, the communicator's channels
+    job.sync_all()
+    t_a = time.perf_counter()
+    for _ in range(steps):
+        one_pass(False)
+    job.sync_all()
+    dt_merge = job.max_over_ranks(time.perf_counter() - t_a)
+    exch_ok, recv_bytes = True, 0
+
+    def timed_with_exchange():
+        nonlocal exch_ok, recv_bytes
+        t_b = time.perf_counter()
+        for _ in range(steps):
+            for got, ok in one_pass(True):
+                recv_bytes += got
+                exch_ok &= ok
+        job.sync_all()
+        return time.perf_counter() - t_b
+    dt_x = job.max_over_ranks(job.guarded("the merge's segment exchange", timed_with_exchange))
+    pool.shutdown()
     tot = job.torch.tensor([float(n_in_local), float(st.n_out)], dtype=job.torch.float64, device=job.dev)
     if world > 1:
         job.dist.all_reduce(tot)
     n_in_total, n_out_total = int(tot[0].item()), int(tot[1].item())
     res = {
-        "value": n_in_total * steps / dt, "unit": "postings/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "scaling": "strong",
+        "value": n_in_total * steps / dt_x, "unit": "postings/s", "ms_per_step": dt_x / steps * 1e3, "steps": steps, "scaling": "strong",
+        "what": "whole job per step: every rank merges its term range chunk by chunk into DV1 segments and every chunk is exchanged "
+                "encoded with all ranks (overlapped with the next chunk's merge) - the exchange is INSIDE the timed region",
         "config": {"workload": "ONE %d-way segment merge of %d terms x mean %.0f postings (BASELINE configs[3]), terms cut into "
-                               "%d contiguous ranges balanced by estimated merge cost (sharding.merge_cost_weights)" % (k, T, args.merge_mean, world),
+                               "%d contiguous ranges balanced by estimated merge cost (sharding.merge_cost_weights), %d chunks per rank"
+                               % (k, T, args.merge_mean, world, n_chunks),
                    "postings_in_total": n_in_total, "postings_out_total": n_out_total,
                    "rank0_terms": [int(t0), int(t1)] if rank == 0 else None, "rank0_postings_in": n_in_local if rank == 0 else None,
                    "parallelism": "terms%d" % world},
-        "rank0_device_ms_per_step": dev_ms / max(dev_n, 1),
+        "merge_to_segment_only": {"value": n_in_total * steps / dt_merge, "ms_per_step": dt_merge / steps * 1e3,
+                                  "what": "the same chunked merge + encode without the exchange"},
+        "raw_output_merge": {"value": n_in_total * steps / dt_raw, "ms_per_step": dt_raw / steps * 1e3, "rank0_device_ms_per_step": dev_ms / max(dev_n, 1),
+                             "what": "one ii2_merge_segments call per rank over its whole range (u32 CSR out), no exchange"},
+        "exchange": {"impl": impl, "bytes_received_per_rank_per_step": recv_bytes // max(steps, 1),
+                     "bytes_if_raw_u32": 4 * n_out_total,
+                     "check": ("chunks decode to the raw merge; every gathered segment holds this rank's part" if (exch_ok and chk_ok)
+                               else "MISMATCH on rank %d" % rank)},
+    }
+    if not exch_ok:
+        print(f"rank {rank}: segment exchange mismatch", file=sys.stderr, flush=True)
+        job.rc = 4
+    for vw in views:
+        for v in (vw or []):
+            v.free()
+    if empty_seg is not None:
+        empty_seg.free()
+    for sg in segs:
+        sg.free()
+    xctx.close()
+    return res
+
+
+C5_RANKS = (2, 4, 16, 64, 256, 1024, 4096, 16384)
+C5_GEN_SHARDS = 8
+
+
+def c5_lists(D, world, rank):
+    """This rank's doc range of the config-5 index.  The index is defined on 8 fixed doc shards (every (term, shard) list
+    has its own seed), so the data is the same whether 1, 2, 4 or 8 ranks hold it; a rank generates only its shards."""
+    from inverted_index_2_amd import sharding, synth
+    n_gen = C5_GEN_SHARDS if C5_GEN_SHARDS % world == 0 else world
+    lo, hi = sharding.doc_range(rank, world, D)
+    rng = np.random.default_rng(55)
+    core = np.unique(rng.integers(0, D, 10_000)).astype(np.uint32)
+    core = sharding.slice_list_to_docs(core, lo, hi)
+    lists = []
+    for zr in C5_RANKS:
+        parts = []
+        for g in range(n_gen):
+            a, b = sharding.doc_range(g, n_gen, D)
+            if a >= lo and b <= hi:
+                parts.append(synth.geometric_postings(1.0 / zr, b - a, synth.term_seed(zr * 64 + g), a))
+        parts.append(core)
+        lists.append(np.unique(np.concatenate(parts)).astype(np.uint32))
+    return lists, (lo, hi)
+
+
+def bench_c5(job):
+    """configs[4]: one 8-term conjunctive query over a 1B-doc index, doc-range sharded, all-gatherv in rank order."""
+    args, ctx, world, rank = job.args, job.ctx, job.world, job.rank
+    from oracle import oracle as orc
+    D = args.c5_docs
+    if D > (1 << 32):
+        raise SystemExit("c5: the doc-id space is uint32")
+    g0 = time.perf_counter()
+    lists, (lo, hi) = c5_lists(D, world, rank)
+    gen_s = time.perf_counter() - g0
+    n_in = int(sum(l.size for l in lists))
+    seg = ctx.encode_lists(lists)
+    sel = [(seg, i) for i in range(len(lists))]
+    cap = int(min(l.size for l in lists)) + 512
+    out = ctx.empty(cap)
+    d_count = ctx.empty(8, np.uint64)
+    _, n_out = ctx.intersect(sel, out=out)
+    got = out.download(n_out)
+    t_o = time.perf_counter()
+    want = orc.intersect(lists[::-1])                     # the oracle on this rank's doc range (shortest list first)
+    oracle_s = time.perf_counter() - t_o
+    if n_out != want.size or not np.array_equal(got, want):
+        raise SystemExit(f"rank {rank}: the 8-term intersection differs from the oracle on doc range [{lo}, {hi})")
+    steps = args.c5_steps or min(args.steps, 20)
+    for _ in range(min(args.warmup, 5)):
+        ctx.intersect_async(sel, None, out, d_count)
+    job.sync_all()
+    ctx.profile_region(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.intersect_async(sel, None, out, d_count)
+    ctx.profile_region(False)
+    job.sync_all()
+    dt = job.max_over_ranks(time.perf_counter() - t0)
+    dev_s = ctx.profile_region_ms() * 1e-3
+    tot = job.torch.tensor([float(n_in), float(n_out), float(int(got.astype(np.uint64).sum()) % (1 << 52))], dtype=job.torch.float64, device=job.dev)
+    if world > 1:
+        job.dist.all_reduce(tot)
+    n_in_total, n_out_total, sum_total = int(tot[0].item()), int(tot[1].item()), int(tot[2].item())
+    info = seg.info
+    res = {
+        "value": n_in_total * steps / dt, "unit": "postings/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+        "scaling": "strong (one query, the doc-id space cut into %d ranges)" % world,
+        "config": {"workload": "8-term AND, Zipf ranks %s over a %d-doc index with a 10,000-id common core (BASELINE configs[4]), "
+                               "doc-range sharded (sharding.doc_range), DV1 decoded in-kernel, galloping over the skip tables"
+                               % (list(C5_RANKS), D),
+                   "postings_in_total": n_in_total, "result_ids_total": n_out_total, "rank0_doc_range": [int(lo), int(hi)] if rank == 0 else None,
+                   "rank0_list_lengths": [int(l.size) for l in lists] if rank == 0 else None, "parallelism": "docrange%d" % world,
+                   "generate_s": round(gen_s, 1)},
+        "rank0_device_us_per_query": dev_s / steps * 1e6,
+        "rank0_encoded_bytes": int(info.n_bytes + 8 * info.n_blocks),
+        "check": "every rank's result equals the oracle's on its doc range (rank 0: %d ids, oracle %.2f s)" % (n_out, oracle_s),
     }
     if world > 1:
-        def exchange():
-            job.torch.cuda.synchronize()
-            cap = job.torch.tensor([int(st.n_out)], dtype=job.torch.int64, device=job.dev)
-            job.dist.all_reduce(cap, op=job.dist.ReduceOp.MAX)
-            g0 = time.perf_counter()
-            gout, counts, impl = job.gather(out_vals, int(st.n_out), int(cap.item()))
-            ms = (time.perf_counter() - g0) * 1e3
-            mine = gout.download(int(sum(counts[:rank + 1])))[int(sum(counts[:rank])):]
-            good = bool(np.array_equal(mine, g_vals))
-            gout.free()
-            return ms, counts, impl, good
-        ms, counts, impl, good = job.guarded("the merge's all-gatherv", exchange)
-        res["allgatherv"] = {"ms": ms, "ids": int(sum(counts)), "impl": impl, "GBps_per_rank_received": sum(counts) * 4 / ms / 1e6,
-                             "check": "every rank found its own merged postings at its rank offset" if good else "MISMATCH on rank %d" % rank}
-        res["value_with_allgatherv"] = n_in_total / (dt / steps + ms * 1e-3)
+        # the exchange inside the timed region: query + rank-order concatenation of the results, per step
+        job.init_comm()
+        capx = job.torch.tensor([cap], dtype=job.torch.int64, device=job.dev)
+        job.dist.all_reduce(capx, op=job.dist.ReduceOp.MAX)
+
+        def with_exchange():
+            good, total = True, 0
+            job.sync_all()
+            t1 = time.perf_counter()
+            for it in range(steps):
+                _, n1 = ctx.intersect(sel, out=out)
+                gout, counts, impl = job.gather(out, n1, int(capx.item()))
+                total = int(sum(counts))
+                if it == steps - 1:
+                    allv = gout.download(total)
+                    good = bool(np.all(np.diff(allv.astype(np.int64)) > 0) and total == n_out_total and
+                                int(allv.astype(np.uint64).sum()) % (1 << 52) == sum_total % (1 << 52) and
+                                np.array_equal(allv[sum(counts[:rank]):sum(counts[:rank + 1])], got))
+                gout.free()
+            job.sync_all()
+            return time.perf_counter() - t1, total, impl, good
+        dtx, total, impl, good = job.guarded("c5's all-gatherv", with_exchange)
+        dtx = job.max_over_ranks(dtx)
+        res["with_allgatherv"] = {"value": n_in_total * steps / dtx, "ms_per_step": dtx / steps * 1e3, "ids": total, "impl": impl,
+                                  "check": ("ascending, the ranks' counts and id checksum add up, this rank's ids at its rank offset"
+                                            if good else "MISMATCH on rank %d" % rank)}
         if not good:
-            print(f"rank {rank}: merge all-gatherv mismatch", file=sys.stderr, flush=True)
+            print(f"rank {rank}: c5 all-gatherv mismatch", file=sys.stderr, flush=True)
             job.rc = 4
-    for s in segs:
-        s.free()
-    out_off.free()
-    out_vals.free()
+    seg.free()
+    out.free()
+    d_count.free()
     return res
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != max(args.gpus, 1):
+        print("bench.py: --gpus %d but the launcher started %s ranks; the line reports the ranks that run" % (args.gpus, os.environ["WORLD_SIZE"]),
+              file=sys.stderr, flush=True)
     job = Job(args)
     world, rank = job.world, job.rank
     parts = {}
@@ -596,8 +889,10 @@ def main():
         parts["merge"] = bench_merge(job)
     if args.workload in ("all", "strong") or (args.workload == "merge" and world > 1):
         parts["merge_strong"] = bench_merge_strong(job)
+    if args.workload in ("all", "c5"):
+        parts["c5"] = bench_c5(job)
 
-    head = parts.get("intersect") or parts.get("merge") or parts["merge_strong"]
+    head = parts.get("intersect") or parts.get("merge") or parts.get("merge_strong") or parts["c5"]
     result = {
         "metric": METRIC, "value": head["value"], "unit": "postings/s", "n_gpus": world, "steps": args.steps if "intersect" in parts else head.get("steps", args.steps),
         "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
@@ -607,7 +902,10 @@ def main():
     for key in ("roofline", "cpu_baseline", "allgatherv"):
         if key in head:
             result[key] = head[key]
-    for name in ("merge", "merge_strong"):
+    if "intersect" in parts and world > 1:
+        result["scaling_note"] = ("the headline is WEAK scaling (every rank intersects its own %d-doc universe, nothing is exchanged in the "
+                                  "timed region); the strong-scaling figures are merge_strong.value and c5.value" % args.docs)
+    for name in ("merge", "merge_strong", "c5"):
         if name in parts and parts[name] is not head:
             result[name] = parts[name]
     if job.rehearse:

@@ -213,6 +213,22 @@ int ii2_comm_init(ii2_ctx *ctx, int world, int rank, const void *unique_id);
 int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local,
                    uint32_t *d_out, uint64_t cap, uint64_t *counts_host);
 
+/* The same exchange in bytes (any device array): n_bytes / cap_bytes / counts_host are bytes. */
+int ii2_allgatherv_bytes(ii2_ctx *ctx, const void *d_local, uint64_t n_bytes, void *d_out, uint64_t cap_bytes,
+                         uint64_t *counts_host);
+
+/* The exchange of MERGED SEGMENTS (what Shard.Merge writes, shard.go:207): every rank contributes the DV1 segment of its
+ * term range and receives ONE segment holding all ranks' lists in rank order — the terms' global order when the ranks own
+ * contiguous term ranges (shardKey ranges are contiguous, shard.go:362-378).  The postings travel encoded (about one byte
+ * per posting for merged lists instead of four), as three byte-wise all-gathervs (list table, skip table, payload);
+ * block numbers and byte offsets are shifted on arrival.  Every rank takes the same decision: II2_ERANGE on all ranks when
+ * the concatenation exceeds one segment's limits.  With no communicator (one rank) *out is a copy of `local`. */
+int ii2_seg_allgather(ii2_ctx *ctx, const ii2_seg *local, ii2_seg **out);
+/* Its arithmetic, host only: shape[3 r ..] = {n_lists, n_blocks, n_bytes} of rank r; list_off / block_off / byte_off
+ * (world + 1 entries each) = where rank r's lists, blocks and payload bytes start in the concatenated segment.
+ * II2_ERANGE when the totals exceed one segment's limits (2^31 lists or blocks, 4 GiB of payload). */
+int ii2_seg_gather_plan(const uint64_t *shape, int world, uint64_t *list_off, uint64_t *block_off, uint64_t *byte_off);
+
 /* The exchange's arithmetic, host only (no GPU needed): offsets[r] = where rank r's contribution
  * starts in the concatenation (offsets has world + 1 entries, offsets[world] = total).
  * II2_ECAPACITY when the total exceeds cap (offsets are still filled), II2_EINVAL for

@@ -69,6 +69,9 @@ PROTOTYPES = {
     "ii2_comm_unique_id": (C.c_int, [vp]),
     "ii2_comm_init": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "ii2_allgatherv": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
+    "ii2_allgatherv_bytes": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
+    "ii2_seg_allgather": (C.c_int, [vp, vp, vpp]),
+    "ii2_seg_gather_plan": (C.c_int, [u64p, C.c_int, u64p, u64p, u64p]),
     "ii2_gatherv_offsets": (C.c_int, [u64p, C.c_int, C.c_uint64, u64p]),
     "ii2_selftest": (C.c_int, [vp]),
     "ii2_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),

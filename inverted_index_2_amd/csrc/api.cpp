@@ -502,6 +502,39 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
 
 }  // extern "C"
 
+// an empty segment shell with room for the given shape (ii2_seg_allgather fills it): ctx->mu held
+int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, ii2_seg **out) {
+    std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
+    if (!seg) return II2_ENOMEM;
+    seg->device = ctx->device;
+    seg->n_lists = n_lists;
+    seg->n_postings = n_postings;
+    seg->n_blocks = n_blocks;
+    seg->n_bytes = n_bytes;
+    if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&seg->d_skip, (n_blocks + 1) * sizeof(ii2_skip)) != hipSuccess ||
+        hipMalloc((void **)&seg->d_payload, n_bytes + 16) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    *out = seg.release();
+    return II2_OK;
+}
+
+// the parts of a gathered segment (rank r: lists [lo[r], lo[r+1]), blocks [bo[r], bo[r+1]), bytes [qo[r], qo[r+1])) still
+// number their blocks and bytes from 0: shift them, write the closing entries and derive the per-list arrays.  ctx->mu held
+int ii2_seg_rebase_internal(ii2_ctx *ctx, ii2_seg *seg, int world, const uint64_t *lo, const uint64_t *bo, const uint64_t *qo) {
+    hipStream_t st = ctx->stream;
+    for (int r = 0; r < world; r++) {
+        HIP_TRY(ctx, launch_seg_rebase(seg->d_blk_off + lo[r], lo[r + 1] - lo[r], (uint32_t)bo[r], seg->d_skip + bo[r], bo[r + 1] - bo[r], (uint32_t)qo[r], st));
+    }
+    const uint32_t last_blk = (uint32_t)bo[world];
+    const ii2_skip last_skip = {0u, (uint32_t)qo[world]};
+    HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off + lo[world], &last_blk, sizeof last_blk, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(seg->d_skip + bo[world], &last_skip, sizeof last_skip, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + qo[world], 0, 16, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));            // (the two small sources above live on this stack frame)
+    return seg_finish(ctx, seg);
+}
+
 // host mirror of blk_off, fetched on first use (views built on the device do not have one)
 int ii2_seg_host_blk_off(ii2_ctx *ctx, const ii2_seg *seg) {
     std::lock_guard<std::mutex> sg(seg->span_mu);

@@ -182,6 +182,22 @@ hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, c
     return hipGetLastError();
 }
 
+// a gathered segment's part: block numbers of its lists and byte offsets of its blocks move up by what lies before it
+__global__ void k_seg_rebase(uint32_t *__restrict__ blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *__restrict__ skip, uint64_t n_blocks,
+                             uint32_t add_bytes) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_lists) blk_off[i] += add_blocks;
+    if (i < n_blocks) skip[i].byte_off += add_bytes;
+}
+
+hipError_t launch_seg_rebase(uint32_t *blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *skip, uint64_t n_blocks, uint32_t add_bytes,
+                             hipStream_t s) {
+    const uint64_t n = n_lists > n_blocks ? n_lists : n_blocks;
+    if (n == 0 || (add_blocks == 0 && add_bytes == 0)) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blk_off, n_lists, add_blocks, skip, n_blocks, add_bytes);
+    return hipGetLastError();
+}
+
 // structural check of an imported segment: offsets monotone and in range, no block longer than
 // 255 five-byte varints — so that no kernel can be steered outside the payload
 __global__ void k_validate_seg(const uint32_t *__restrict__ blk_off, uint64_t n_lists, const ii2_skip *__restrict__ skip,

@@ -69,24 +69,25 @@ int ii2_gatherv_offsets(const uint64_t *counts, int world, uint64_t cap, uint64_
     return (overflow || offsets[world] > cap) ? II2_ECAPACITY : II2_OK;
 }
 
-int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local, uint32_t *d_out, uint64_t cap,
-                   uint64_t *counts_host) {
-    if (!ctx || !counts_host || (n_local && !d_local)) return II2_EINVAL;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return II2_EHIP; }
+// The exchange itself, in elements of `esz` bytes (4: doc ids, 1: the arrays of an encoded segment).  ctx->mu is held.
+static int gatherv_core(ii2_ctx *ctx, const void *d_local_v, uint64_t n_local, size_t esz, void *d_out_v, uint64_t cap,
+                        uint64_t *counts_host, const char *who) {
+    const uint8_t *d_local = (const uint8_t *)d_local_v;
+    uint8_t *d_out = (uint8_t *)d_out_v;
     const int world = ctx->comm ? ctx->world : 1, rank = ctx->comm ? ctx->rank : 0;
     if (world > (int)II2_MAX_RANKS) { ctx->err = "world size above II2_MAX_RANKS"; return II2_EINVAL; }
     hipStream_t st = ctx->stream;
+    auto say = [&](const char *m) { ctx->err = std::string(who) + ": " + m; };
     if (world == 1) {
         counts_host[0] = n_local;
-        if (n_local > cap) { ctx->err = "ii2_allgatherv: output capacity too small"; return II2_ECAPACITY; }
-        if (n_local && !d_out) { ctx->err = "ii2_allgatherv: output buffer is NULL"; return II2_EINVAL; }
+        if (n_local > cap) { say("output capacity too small"); return II2_ECAPACITY; }
+        if (n_local && !d_out) { say("output buffer is NULL"); return II2_EINVAL; }
         if (n_local && d_out != d_local &&
-            hipMemcpyAsync(d_out, d_local, n_local * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            ctx->err = "ii2_allgatherv: copy failed";
+            hipMemcpyAsync(d_out, d_local, n_local * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            say("copy failed");
             return II2_EHIP;
         }
-        if (hipStreamSynchronize(st) != hipSuccess) { ctx->err = "ii2_allgatherv: sync failed"; return II2_EHIP; }
+        if (hipStreamSynchronize(st) != hipSuccess) { say("sync failed"); return II2_EHIP; }
         return II2_OK;
     }
     ncclComm_t comm = (ncclComm_t)ctx->comm;
@@ -96,13 +97,13 @@ int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local, uint
     h_x[0] = n_local;
     h_x[1] = d_out ? cap : 0;
     if (hipMemcpyAsync(d_x, h_x, 2 * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) {
-        ctx->err = "ii2_allgatherv: count upload failed";
+        say("count upload failed");
         return II2_EHIP;
     }
     NCCL_TRY(ctx, ncclAllGather(d_x, d_x + 2, 2, ncclUint64, comm, st));
     if (hipMemcpyAsync(h_x + 2, d_x + 2, (size_t)world * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess) {
-        ctx->err = "ii2_allgatherv: count download failed";
+        say("count download failed");
         return II2_EHIP;
     }
     std::vector<uint64_t> off(world + 1, 0);
@@ -112,33 +113,111 @@ int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local, uint
         min_cap = std::min(min_cap, h_x[2 + 2 * r + 1]);
     }
     if (ii2_gatherv_offsets(counts_host, world, min_cap, off.data()) != II2_OK) {
-        ctx->err = "ii2_allgatherv: the concatenation does not fit the smallest output buffer of the ranks (no rank exchanged anything)";
+        say("the concatenation does not fit the smallest output buffer of the ranks (no rank exchanged anything)");
         return II2_ECAPACITY;
     }
     // the local contribution may sit in d_out only at its own slot (an in-place gather); anywhere else inside d_out it
     // would be overwritten by incoming data while it is being sent
-    if (n_local && d_local != d_out + off[rank] && d_local + n_local > d_out && d_local < d_out + off[world]) {
-        ctx->err = "ii2_allgatherv: d_local overlaps d_out outside its own slot";
+    if (n_local && d_local != d_out + off[rank] * esz && d_local + n_local * esz > d_out && d_local < d_out + off[world] * esz) {
+        say("d_local overlaps d_out outside its own slot");
         return II2_EINVAL;      // (local decision: the caller's bug on this rank; peers time out in RCCL — documented)
     }
-    // 2. payload: one send + one recv per peer, grouped so they all progress together; the group is always closed
+    // 2. payload: one send + one recv per peer, grouped so they all progress together; the group is always closed.
+    // Bytes travel as ncclUint8 (counts are bytes then); doc ids as ncclUint32.
+    const ncclDataType_t dt = esz == 4 ? ncclUint32 : ncclUint8;
+    const uint64_t unit = esz == 4 ? 1 : esz;           // elements -> items of dt
     ncclResult_t gr = ncclGroupStart();
     for (int r = 0; r < world && gr == ncclSuccess; r++) {
         if (r == rank) continue;
-        if (n_local) gr = ncclSend(d_local, n_local, ncclUint32, r, comm, st);
-        if (gr == ncclSuccess && counts_host[r]) gr = ncclRecv(d_out + off[r], counts_host[r], ncclUint32, r, comm, st);
+        if (n_local) gr = ncclSend(d_local, n_local * unit, dt, r, comm, st);
+        if (gr == ncclSuccess && counts_host[r]) gr = ncclRecv(d_out + off[r] * esz, counts_host[r] * unit, dt, r, comm, st);
     }
     const ncclResult_t ge = ncclGroupEnd();
     if (gr != ncclSuccess || ge != ncclSuccess) {
-        ctx->err = std::string("ii2_allgatherv: grouped send/recv: ") + ncclGetErrorString(gr != ncclSuccess ? gr : ge);
+        ctx->err = std::string(who) + ": grouped send/recv: " + ncclGetErrorString(gr != ncclSuccess ? gr : ge);
         return II2_ECOMM;
     }
-    if (n_local && d_out + off[rank] != d_local &&
-        hipMemcpyAsync(d_out + off[rank], d_local, n_local * sizeof(uint32_t), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-        ctx->err = "ii2_allgatherv: local copy failed";
+    if (n_local && d_out + off[rank] * esz != d_local &&
+        hipMemcpyAsync(d_out + off[rank] * esz, d_local, n_local * esz, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        say("local copy failed");
         return II2_EHIP;
     }
-    if (hipStreamSynchronize(st) != hipSuccess) { ctx->err = "ii2_allgatherv: sync failed"; return II2_EHIP; }
+    if (hipStreamSynchronize(st) != hipSuccess) { say("sync failed"); return II2_EHIP; }
+    return II2_OK;
+}
+
+int ii2_allgatherv(ii2_ctx *ctx, const uint32_t *d_local, uint64_t n_local, uint32_t *d_out, uint64_t cap,
+                   uint64_t *counts_host) {
+    if (!ctx || !counts_host || (n_local && !d_local)) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return II2_EHIP; }
+    return gatherv_core(ctx, d_local, n_local, sizeof(uint32_t), d_out, cap, counts_host, "ii2_allgatherv");
+}
+
+int ii2_allgatherv_bytes(ii2_ctx *ctx, const void *d_local, uint64_t n_bytes, void *d_out, uint64_t cap_bytes,
+                         uint64_t *counts_host) {
+    if (!ctx || !counts_host || (n_bytes && !d_local)) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return II2_EHIP; }
+    return gatherv_core(ctx, d_local, n_bytes, 1, d_out, cap_bytes, counts_host, "ii2_allgatherv_bytes");
+}
+
+// Host arithmetic of the segment exchange (no GPU needed): where every rank's lists, blocks and payload bytes land in
+// the concatenated segment.  shape[3 r .. 3 r + 2] = {n_lists, n_blocks, n_bytes} of rank r; the three outputs have
+// world + 1 entries each.
+int ii2_seg_gather_plan(const uint64_t *shape, int world, uint64_t *list_off, uint64_t *block_off, uint64_t *byte_off) {
+    if (!shape || !list_off || !block_off || !byte_off || world < 1 || world > (int)II2_MAX_RANKS) return II2_EINVAL;
+    list_off[0] = block_off[0] = byte_off[0] = 0;
+    for (int r = 0; r < world; r++) {
+        list_off[r + 1] = list_off[r] + shape[3 * r];
+        block_off[r + 1] = block_off[r] + shape[3 * r + 1];
+        byte_off[r + 1] = byte_off[r] + shape[3 * r + 2];
+    }
+    // the DV1 limits of one segment (include/ii2.h): block numbers and byte offsets are 32 bits
+    if (list_off[world] >= (1ull << 31) || block_off[world] >= (1ull << 31) || byte_off[world] >= 0xFFFFFFF0ull) return II2_ERANGE;
+    return II2_OK;
+}
+
+int ii2_seg_allgather(ii2_ctx *ctx, const ii2_seg *local, ii2_seg **out) {
+    if (!ctx || !local || !out || local->device != ctx->device) return II2_EINVAL;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return II2_EHIP; }
+    const int world = ctx->comm ? ctx->world : 1;
+    hipStream_t st = ctx->stream;
+    // 1. shapes: {lists, blocks, payload bytes, postings} of every rank
+    uint64_t *h_x = ctx->h_mail + II2_MAIL_COMM, *d_x = ctx->d_mail + II2_MAIL_COMM;      // [0..3] mine, [4 .. 4 + 4 world) all
+    static_assert(II2_MAIL_COMM + 4 + 4 * II2_MAX_RANKS <= II2_MAIL_WORDS, "mailbox too small for the segment shapes");
+    h_x[0] = local->n_lists; h_x[1] = local->n_blocks; h_x[2] = local->n_bytes; h_x[3] = local->n_postings;
+    if (world == 1) std::memcpy(h_x + 4, h_x, 4 * sizeof(uint64_t));
+    else {
+        if (hipMemcpyAsync(d_x, h_x, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) { ctx->err = "ii2_seg_allgather: shape upload failed"; return II2_EHIP; }
+        NCCL_TRY(ctx, ncclAllGather(d_x, d_x + 4, 4, ncclUint64, (ncclComm_t)ctx->comm, st));
+        if (hipMemcpyAsync(h_x + 4, d_x + 4, (size_t)world * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) { ctx->err = "ii2_seg_allgather: shape download failed"; return II2_EHIP; }
+    }
+    std::vector<uint64_t> shape(3 * world), lo(world + 1), bo(world + 1), qo(world + 1);
+    uint64_t n_post = 0;
+    for (int r = 0; r < world; r++) {
+        shape[3 * r] = h_x[4 + 4 * r]; shape[3 * r + 1] = h_x[4 + 4 * r + 1]; shape[3 * r + 2] = h_x[4 + 4 * r + 2];
+        n_post += h_x[4 + 4 * r + 3];
+    }
+    // (identical on every rank: either all ranks go on or all of them stop here)
+    if (int rc = ii2_seg_gather_plan(shape.data(), world, lo.data(), bo.data(), qo.data())) {
+        ctx->err = "ii2_seg_allgather: the concatenated segment exceeds the DV1 limits (2^31 lists / blocks, 4 GiB of payload)";
+        return rc;
+    }
+    // 2. the concatenated segment's arrays; every rank's part keeps its own numbering until step 4
+    ii2_seg *seg = nullptr;
+    if (int rc = ii2_seg_alloc_internal(ctx, lo[world], n_post, bo[world], qo[world], &seg)) return rc;
+    std::vector<uint64_t> cnt(world);
+    int rc = gatherv_core(ctx, local->d_blk_off, local->n_lists * sizeof(uint32_t), 1, seg->d_blk_off, lo[world] * sizeof(uint32_t), cnt.data(), "ii2_seg_allgather (lists)");
+    if (!rc) rc = gatherv_core(ctx, local->d_skip, local->n_blocks * sizeof(ii2_skip), 1, seg->d_skip, bo[world] * sizeof(ii2_skip), cnt.data(), "ii2_seg_allgather (skip table)");
+    if (!rc) rc = gatherv_core(ctx, local->d_payload, local->n_bytes, 1, seg->d_payload, qo[world], cnt.data(), "ii2_seg_allgather (payload)");
+    // 3. + 4. block numbers and byte offsets of rank r's part move up by what the ranks before it hold; closing entries
+    if (!rc) rc = ii2_seg_rebase_internal(ctx, seg, world, lo.data(), bo.data(), qo.data());
+    if (rc) { ii2_seg_free(seg); return rc; }
+    *out = seg;
     return II2_OK;
 }
 

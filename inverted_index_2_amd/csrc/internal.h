@@ -12,7 +12,7 @@
 #include "../../include/ii2.h"
 
 // mailbox layout (u64 words; h_mail and d_mail both hold II2_MAIL_WORDS)
-constexpr size_t II2_MAIL_WORDS = 512;
+constexpr size_t II2_MAIL_WORDS = 1024;
 constexpr size_t II2_MAIL_COUNT = 200;     // word of h_mail that receives the result count of ii2_intersect / ii2_union
 constexpr size_t II2_MAIL_COMM = 256;      // all-gatherv: {count, cap} of this rank, then of every rank (2 + 2 * II2_MAX_RANKS words)
 
@@ -102,6 +102,8 @@ struct ii2_tomb {
 };
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
+int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, ii2_seg **out);   // ctx->mu held
+int ii2_seg_rebase_internal(ii2_ctx *ctx, ii2_seg *seg, int world, const uint64_t *lo, const uint64_t *bo, const uint64_t *qo);            // ctx->mu held
 void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes);      // grow-only ctx buffer `slot`, at least `bytes` (nullptr: out of memory); ctx->mu held
 uint64_t *ii2_mapped_mail(ii2_ctx *ctx, uint32_t word);
 int ii2_seg_host_cnt(ii2_ctx *ctx, const ii2_seg *seg);       // fills seg->h_cnt on first use (thread-safe)
@@ -261,6 +263,8 @@ hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_l
                                   uint64_t n_blocks, uint32_t *bad, hipStream_t s);
 hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const ii2_skip *skip, uint64_t n_blocks, uint64_t n_bytes,
                                uint32_t *bad, hipStream_t s);
+hipError_t launch_seg_rebase(uint32_t *blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *skip, uint64_t n_blocks, uint32_t add_bytes,
+                             hipStream_t s);
 hipError_t launch_sum_u32(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
 

@@ -319,6 +319,27 @@ class Context:
         self._ck(self.lib.ii2_allgatherv(self.h, _ptr(local), n_local, _ptr(out), out.count, counts))
         return [int(c) for c in counts]
 
+    def allgatherv_bytes(self, local, n_bytes: int, out: DeviceArray, world: int):
+        """Rank-order concatenation of byte arrays (any device buffers); returns the ranks' byte counts."""
+        counts = (C.c_uint64 * max(world, 1))()
+        self._ck(self.lib.ii2_allgatherv_bytes(self.h, _ptr(local), n_bytes, _ptr(out), out.nbytes, counts))
+        return [int(c) for c in counts]
+
+    def seg_allgather(self, local: "Segment") -> "Segment":
+        """Every rank's merged segment, concatenated in rank order into one segment (the postings travel DV1-encoded)."""
+        h = C.c_void_p()
+        self._ck(self.lib.ii2_seg_allgather(self.h, local.h, C.byref(h)))
+        return Segment(self, h)
+
+
+def seg_gather_plan(shapes):
+    """Host arithmetic of seg_allgather: shapes = [(n_lists, n_blocks, n_bytes)] per rank -> (rc, list_off, block_off, byte_off)."""
+    world = len(shapes)
+    flat = (C.c_uint64 * (3 * max(world, 1)))(*[int(x) for sh in shapes for x in sh])
+    lo, bo, qo = ((C.c_uint64 * (world + 1))() for _ in range(3))
+    rc = _lib.load().ii2_seg_gather_plan(flat, world, lo, bo, qo)
+    return rc, list(lo), list(bo), list(qo)
+
 
 def comm_unique_id() -> bytes:
     buf = C.create_string_buffer(_lib.II2_UNIQUE_ID_BYTES)

@@ -136,3 +136,24 @@ def test_allgatherv_single_rank_is_a_copy(ctx):
     dst = ctx.empty(a.size + 10)
     counts = ctx.allgatherv(src, a.size, dst, 1)
     assert counts == [a.size] and np.array_equal(dst.download(a.size), a)
+
+
+def test_segment_allgather_with_one_rank_is_a_copy(ctx):
+    """ii2_seg_allgather without a communicator: the same shapes / gather / shift / closing-entry steps as the N-rank
+    exchange, with one contribution — the result decodes to the same lists and merges like the original."""
+    rng = np.random.default_rng(21)
+    lists = [sorted_unique(rng, int(n), 5_000_000) for n in (0, 1, 300, 70_000, 0, 257, 5)]
+    seg = ctx.encode_lists(lists)
+    got = ctx.seg_allgather(seg)
+    assert (got.info.n_lists, got.info.n_postings, got.info.n_blocks, got.info.n_bytes) == \
+        (seg.info.n_lists, seg.info.n_postings, seg.info.n_blocks, seg.info.n_bytes)
+    po, v = got.decode()
+    po0, v0 = seg.decode()
+    assert np.array_equal(po, po0) and np.array_equal(v, v0)
+    out_off, out_vals, st = ctx.merge([got, seg])
+    assert st.n_out == sum(l.size for l in lists)
+    # byte-wise all-gatherv, one rank
+    a = ctx.empty(1000, np.uint8).upload(np.arange(1000) % 251)
+    b = ctx.empty(1200, np.uint8)
+    assert ctx.allgatherv_bytes(a, 777, b, 1) == [777]
+    assert np.array_equal(b.download(777), (np.arange(777) % 251).astype(np.uint8))
