@@ -384,6 +384,29 @@ def bench_intersect(job):
     if cold is not None:
         res["roofline"]["cold_frac"] = cold["frac"]
         res["roofline"]["cold"] = cold
+    if tomb is None:
+        # north_star's form of the query: the same passes with the tombstone filter on (1 % of the docs removed, a D/8-byte
+        # bitmap: +12.5 MB algorithmic at 100M docs) - SURVEY §0 D4: off = the reference's Read, on = north_star
+        removed_t = synth.geometric_postings(0.01, D, synth.term_seed(10**6), offset).astype(np.uint32)
+        tomb_t = ctx.tombstones(removed_t)
+        _, n_t = ctx.intersect(lists, tomb=tomb_t, out=out)
+        if not np.array_equal(out.download(n_t), np.setdiff1d(want_np, removed_t, assume_unique=True)):
+            raise SystemExit(f"rank {rank}: GPU intersection with tombstones differs from the numpy cross-check")
+        for i in range(args.warmup):
+            ctx.intersect_async(lists, tomb_t, out, d_count)
+        job.sync_all()
+        ctx.profile_region(True)
+        for i in range(args.steps):
+            ctx.intersect_async(lists, tomb_t, out, d_count)
+        ctx.profile_region(False)
+        job.sync_all()
+        t_s = ctx.profile_region_ms() * 1e-3 / args.steps
+        alg_t = info.n_bytes + 8 * info.n_blocks + 4 * n_t + D // 8
+        res["roofline"]["with_tombstones"] = {"removed_ids": int(removed_t.size), "result_ids": int(n_t), "algorithmic_bytes_per_launch": int(alg_t),
+                                              "kernel_avg_us": t_s * 1e6, "achieved": alg_t / t_s / 1e9, "frac": alg_t / t_s / 1e9 / HBM_PEAK_GBS,
+                                              "value": n_in * world / t_s}
+        tomb_t.free()
+        ctx.intersect(lists, tomb=None, out=out)       # leave the headline result in `out`
 
     # the exchange step, once, after the timed region: rank-order concatenation of the results
     if world > 1:
@@ -498,9 +521,25 @@ def bench_merge(job):
         what = ("the whole workload once (%d postings in, %.1f s)" % (n_in, cdt)) if t_lo == 0 else \
                ("terms [%d, %d) of the workload (%d of its %d postings in, %.1f s; the head terms are checked for order and "
                 "tombstones only)" % (t_lo, T, n_sample, n_in, cdt))
+        # one thread, on a bounded sample: the tail of the term range holding about 20M postings (a few seconds)
+        per_term1 = np.zeros(T, np.int64)
+        for o in offs:
+            per_term1 += np.diff(o.astype(np.int64))
+        t1_lo = int(T - min(int(np.searchsorted(np.cumsum(per_term1[::-1]), 20_000_000)) + 1, T))
+        o1 = [o[t1_lo:] - o[t1_lo] for o in offs]
+        v1 = [v[int(o[t1_lo]):] for o, v in zip(offs, vals)]
+        n1 = int(sum(int(o[-1]) for o in o1))
+        t0 = time.perf_counter()
+        orc.merge_segments(o1, v1, removed, threads=1)
+        c1 = time.perf_counter() - t0
+        del o1, v1
         cpu = {"value": n_sample / cdt, "unit": "postings/s", "cores": avail, "cores_available": avail, "kind": "port",
+               "value_1_thread": n1 / c1,
                "sample": what + ": oracle worker pool over term ranges, pairwise concat+sort+compact fold and binary-search "
-                                "tombstone filter (oracle/ii2_oracle.c); this run is also the correctness check of the GPU result"}
+                                "tombstone filter (oracle/ii2_oracle.c); this run is also the correctness check of the GPU result.  "
+                                "The pool's time is the serial critical path of the largest terms (every fold re-sorts the growing list, "
+                                "file/types.go:14-22; the rank-1 term alone folds 16 lists into ~70M ids on one core), not %d cores of "
+                                "work.  value_1_thread: terms [%d, %d) (%d postings in, %.1f s) on one thread" % (avail, t1_lo, T, n1, c1)}
     host_offs = offs
     del vals
     steps = args.merge_steps or min(args.steps, 10)
@@ -669,14 +708,21 @@ def bench_merge_strong(job):
         for vw in views:
             sg = None
             if vw is not None:
+                tq = time.perf_counter()
                 sg, _ = ctx.merge_to_segment(vw, tomb)
+                if os.environ.get("BENCH_TRACE"):
+                    print("rank %d: merge_to_segment %.2f ms" % (rank, (time.perf_counter() - tq) * 1e3), file=sys.stderr, flush=True)
             merged.append(sg)
             if with_exchange:
                 pending.append(pool.submit(exchange, sg))
+        tq = time.perf_counter()
         got = [f.result() for f in pending]
+        tr = time.perf_counter()
         for sg in merged:
             if sg is not None:
                 sg.free()
+        if os.environ.get("BENCH_TRACE"):
+            print("rank %d: waited %.2f ms for the exchanges, freed in %.2f ms" % (rank, (tr - tq) * 1e3, (time.perf_counter() - tr) * 1e3), file=sys.stderr, flush=True)
         return got
 
     pool = ThreadPoolExecutor(max_workers=1)
@@ -899,9 +945,9 @@ def main():
         "scaling": "weak" if "intersect" in parts else head.get("scaling", "weak"), "vs_baseline": None, "dtype": "u32",
         "data": "synthetic", "config": head["config"],
     }
-    for key in ("roofline", "cpu_baseline", "allgatherv"):
-        if key in head:
-            result[key] = head[key]
+    for key, val in head.items():          # everything else the headline workload reports (roofline, cpu_baseline, ...)
+        if key not in result:
+            result[key] = val
     if "intersect" in parts and world > 1:
         result["scaling_note"] = ("the headline is WEAK scaling (every rank intersects its own %d-doc universe, nothing is exchanged in the "
                                   "timed region); the strong-scaling figures are merge_strong.value and c5.value" % args.docs)

@@ -13,7 +13,12 @@
  *   - plain pointers and sizes only.  `where` says whether a caller buffer lives in host
  *     memory (II2_HOST — what cgo passes) or in this device's HBM (II2_DEVICE).
  *   - inputs are read-only and never retained after return; outputs are written only on
- *     success (all-or-nothing per call).
+ *     success (all-or-nothing per call).  One exception, stated where it applies: an intersect /
+ *     union whose result does not fit `cap` returns II2_ECAPACITY with the buffer's content
+ *     unspecified (the merge entry points write nothing in that case).
+ *   - per-call limits (II2_ERANGE beyond them): a merge takes < 2^32 input postings, < 2^31 input
+ *     blocks and < 2^30 term slots; ii2_align_terms takes < 2^31 terms; one segment holds < 2^31
+ *     lists, < 2^31 blocks and < 4 GiB of payload (split larger inputs into several segments / calls).
  *   - a ctx is bound to one GPU and one HIP stream; calls on one ctx are serialised by an
  *     internal mutex, so a ctx may be shared by goroutines / threads (InvertedIndex.Merge
  *     fans Shard.Merge over `concurrency` goroutines, inverted_index.go:83-103); use one
@@ -42,8 +47,8 @@ enum {
     II2_EINVAL = -1,     /* bad argument (NULL, unsorted sizes, too many lists …) */
     II2_ENOMEM = -2,     /* device or host allocation failed */
     II2_EHIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
-    II2_ECAPACITY = -4,  /* caller's output buffer is too small (buffer content unspecified) */
-    II2_ERANGE = -5,     /* segment too large for the DV1 format (>= 4 GiB of payload) */
+    II2_ECAPACITY = -4,  /* caller's output buffer is too small (merge: nothing written; intersect / union: content unspecified) */
+    II2_ERANGE = -5,     /* beyond a per-call or per-segment limit (see the conventions above) */
     II2_ECOMM = -6,      /* RCCL failure / communicator not initialised */
     II2_ENODEVICE = -7   /* no usable gfx950 GPU — the library has no CPU path */
 };
@@ -157,7 +162,10 @@ void ii2_tomb_free(ii2_tomb *tomb);
  * bytes.Compare term ordering of file/types.go:24-26 stays on the host).
  * Output, device-resident: out_off[n_lists+1] (u64) and out_values (u32, capacity
  * out_cap >= sum of the inputs' n_postings is always enough).  A term whose
- * out_off[t+1]==out_off[t] has no survivors and is dropped by the caller (shard.go:192-194). */
+ * out_off[t+1]==out_off[t] has no survivors and is dropped by the caller (shard.go:192-194).
+ * All-or-nothing: when the merged postings do not fit out_cap the call returns II2_ECAPACITY and
+ * neither out_off nor out_values has been written (the fit is decided on the device before the
+ * packing pass and the offset scan write anything). */
 int ii2_merge_segments(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb,
                        uint64_t *d_out_off, uint32_t *d_out_values, uint64_t out_cap,
                        ii2_merge_stats *stats);
@@ -172,7 +180,9 @@ int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *se
  * d_out: device buffer, capacity cap >= the shortest list is always enough. */
 int ii2_intersect(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
                   const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *count);
-/* Enqueue only: the count lands in the device word d_count; no host synchronisation. */
+/* Enqueue only: the count lands in the device word d_count; no host synchronisation.  (What the path choice needs
+ * to know about a list — its first and last doc — is mirrored on the host when its segment is created, for segments
+ * of up to 65536 lists; a list of a larger segment costs one small fetch + sync the first time it is queried.) */
 int ii2_intersect_async(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx,
                         const ii2_tomb *tomb, uint32_t *d_out, uint64_t cap, uint64_t *d_count);
 
@@ -244,7 +254,8 @@ int ii2_selftest(ii2_ctx *ctx);
  *   union.stream, union.dense, union.sparsity   unions through the streaming kernel / through the OR tiles (the latter up
  *                                           to `sparsity` docs of the lists' common range per posting, default 2048)
  *   setop.small, union.rank                 short-list ANDs / ORs in one launch; ORs of a few medium lists by ranking
- *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms / postings per tile of a large term
+ *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms (1: terms with >= 1 posting per 80 docs; N > 1: per N docs; 0: off)
+ *                                           / input postings a doc-range tile of a large term aims at
  *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below
  * Every combination returns the same results; the tests run the kernels with the alternatives switched on and off. */
 int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);

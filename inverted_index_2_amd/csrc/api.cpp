@@ -250,6 +250,14 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
     seg->h_blk_off.resize(seg->n_lists + 1);
     HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
+    // the lists' spans (what a query's path choice looks at), mirrored now so that no query has to fetch them
+    if (seg->n_lists && seg->n_lists <= ii2_seg::SPAN_MIRROR_MAX) {
+        if (int rcw = ii2_ws_reserve(ctx, align_up(3 * seg->n_lists * sizeof(uint32_t)) + 256)) return rcw;
+        uint32_t *d_sp = ws_take<uint32_t>(ctx, 3 * seg->n_lists);
+        HIP_TRY(ctx, launch_list_spans(seg->d_blk_off, seg->d_skip, seg->d_last_doc, seg->n_lists, d_sp, ctx->stream));
+        seg->h_spans.resize(3 * seg->n_lists);
+        HIP_TRY(ctx, hipMemcpyAsync(seg->h_spans.data(), d_sp, 3 * seg->n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return II2_OK;
 }
@@ -729,6 +737,10 @@ static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, con
 
 // first doc, first doc of the last block and last doc of a non-empty list: fetched once per (segment, list), then cached
 static int list_span(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, const ListView &v, ii2_seg::ListSpan *out) {
+    if (seg->h_spans.size() == 3 * seg->n_lists && idx < seg->n_lists) {      // mirrored when the segment was created: no fetch, no sync
+        *out = ii2_seg::ListSpan{seg->h_spans[3 * idx], seg->h_spans[3 * idx + 1], seg->h_spans[3 * idx + 2]};
+        return II2_OK;
+    }
     {
         std::lock_guard<std::mutex> sg(seg->span_mu);
         auto hit = seg->span_cache.find(idx);

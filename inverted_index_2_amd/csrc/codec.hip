@@ -26,58 +26,93 @@ __device__ __forceinline__ uint64_t owner_list(const uint32_t *__restrict__ blk_
     return lo;
 }
 
-// One wave per block: lane i handles postings 4i..4i+3 of the block.
+// A wave encodes ENC_BPW consecutive blocks, one after the other: lane i handles postings 4i..4i+3 of a block.  The list that
+// owns the wave's first block is found by bisection (some twenty dependent loads in a table of a million lists); the owners
+// of the following blocks by walking on from there (blocks and lists ascend together), so the search is paid once per
+// ENC_BPW blocks.  WRITE: the block's bytes are put together in wave-private LDS and leave as 16-byte stores.
+constexpr uint32_t ENC_BPW = 8;
+constexpr uint32_t ENC_STAGE = 1280 + 32;      // a block's payload (255 gaps of <= 5 bytes) + room to start it at its address mod 16
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_enc_blocks(const uint64_t *__restrict__ post_off, const uint32_t *__restrict__ blk_off,
                                                     uint64_t n_lists, const uint32_t *__restrict__ values, uint64_t n_blocks,
                                                     uint32_t *__restrict__ sizes, const uint64_t *__restrict__ byte_off64,
                                                     ii2_skip *__restrict__ skip, uint8_t *__restrict__ payload, uint64_t n_postings) {
-    const uint64_t b = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    __shared__ __align__(16) uint8_t stage[WRITE ? 4 : 1][WRITE ? ENC_STAGE : 16];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int l = lane_id();
-    if (b > n_blocks) return;
-    if (b == n_blocks) {          // sentinel
-        if (l == 0) {
-            if (!WRITE) sizes[b] = 0;
-            else {
-                skip[b].first_doc = n_postings ? values[n_postings - 1] : 0u;
-                skip[b].byte_off = (uint32_t)byte_off64[b];
+    const uint64_t b_begin = wave * ENC_BPW;
+    if (b_begin > n_blocks) return;
+    uint64_t li = b_begin < n_blocks ? owner_list(blk_off, n_lists, (uint32_t)b_begin) : 0;
+    uint32_t li_end = b_begin < n_blocks ? blk_off[li + 1] : 0u;        // first block past list li
+    for (uint64_t b = b_begin; b < b_begin + ENC_BPW && b <= n_blocks; b++) {
+        if (b == n_blocks) {          // sentinel
+            if (l == 0) {
+                if (!WRITE) sizes[b] = 0;
+                else {
+                    skip[b].first_doc = n_postings ? values[n_postings - 1] : 0u;
+                    skip[b].byte_off = (uint32_t)byte_off64[b];
+                }
+            }
+            break;
+        }
+        while ((uint32_t)b >= li_end) { li++; li_end = blk_off[li + 1]; }   // (empty lists in between own no block)
+        const uint64_t p0 = post_off[li] + (uint64_t)((uint32_t)b - blk_off[li]) * II2_DV1_BLOCK;
+        const uint64_t pe = post_off[li + 1];
+        const uint32_t cnt = (uint32_t)(pe - p0 < II2_DV1_BLOCK ? pe - p0 : II2_DV1_BLOCK);
+        uint32_t d[4];
+        uint32_t len = 0;
+        {   // my four postings and the one before them
+            const uint32_t i0 = 4u * (uint32_t)l;
+            uint32_t v[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const uint32_t i = i0 + (uint32_t)j;
+                v[j] = (i >= 1u && i <= cnt) ? values[p0 + i - 1u] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t i = i0 + (uint32_t)j;
+                d[j] = 0;
+                if (i >= 1u && i < cnt) {
+                    d[j] = v[j + 1] - v[j];
+                    len += varint_len(d[j]);
+                }
             }
         }
-        return;
-    }
-    const uint64_t li = owner_list(blk_off, n_lists, (uint32_t)b);
-    const uint64_t p0 = post_off[li] + (uint64_t)(b - blk_off[li]) * II2_DV1_BLOCK;
-    const uint64_t pe = post_off[li + 1];
-    const uint32_t cnt = (uint32_t)(pe - p0 < II2_DV1_BLOCK ? pe - p0 : II2_DV1_BLOCK);
-    uint32_t d[4];
-    uint32_t len = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = 4u * (uint32_t)l + (uint32_t)j;
-        d[j] = 0;
-        if (i >= 1 && i < cnt) {
-            d[j] = values[p0 + i] - values[p0 + i - 1];
-            len += varint_len(d[j]);
+        const uint32_t incl = wave_incl_scan(len);
+        if (!WRITE) {
+            if (l == 63) sizes[b] = incl;
+            continue;
         }
-    }
-    const uint32_t incl = wave_incl_scan(len);
-    if (!WRITE) {
-        if (l == 63) sizes[b] = incl;
-        return;
-    }
-    const uint64_t base = byte_off64[b];
-    if (l == 0) {
-        skip[b].first_doc = values[p0];
-        skip[b].byte_off = (uint32_t)base;
-    }
-    uint64_t q = base + (incl - len);
+        const uint64_t base = byte_off64[b];
+        const uint32_t total = wave_bcast(incl, 63);
+        if (l == 0) {
+            skip[b].first_doc = values[p0];
+            skip[b].byte_off = (uint32_t)base;
+        }
+        // the block's bytes in LDS, shifted so that LDS offset and global address agree mod 16
+        uint8_t *st = stage[threadIdx.x >> 6];
+        const uint32_t mis = (uint32_t)((uintptr_t)(payload + base) & 15u);
+        uint32_t q = mis + (incl - len);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const uint32_t i = 4u * (uint32_t)l + (uint32_t)j;
-        if (i >= 1 && i < cnt) {
-            uint32_t v = d[j];
-            while (v >= 0x80u) { payload[q++] = (uint8_t)(v | 0x80u); v >>= 7; }
-            payload[q++] = (uint8_t)v;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t i = 4u * (uint32_t)l + (uint32_t)j;
+            if (i >= 1 && i < cnt) {
+                uint32_t v = d[j];
+                while (v >= 0x80u) { st[q++] = (uint8_t)(v | 0x80u); v >>= 7; }
+                st[q++] = (uint8_t)v;
+            }
+        }
+        // (wave-private LDS: program order is enough) whole 16-byte pieces leave as one store each, the ragged ends byte by byte
+        uint8_t *dst = payload + base - mis;                                  // 16-byte aligned
+        const uint32_t end = mis + total;
+        for (uint32_t o = 16u * (uint32_t)l; o < end; o += 1024u) {
+            if (o >= mis && o + 16u <= end) {
+                *reinterpret_cast<uint4 *>(dst + o) = *reinterpret_cast<const uint4 *>(st + o);
+            } else {
+                const uint32_t a0 = o > mis ? o : mis, a1 = o + 16u < end ? o + 16u : end;
+                for (uint32_t x = a0; x < a1; x++) dst[x] = st[x];
+            }
         }
     }
 }
@@ -90,7 +125,7 @@ hipError_t launch_enc_list_blocks(const uint64_t *post_off, uint64_t n_lists, ui
 
 hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
                                   const uint32_t *values, uint64_t n_blocks, uint32_t *sizes, ii2_skip *skip, hipStream_t s) {
-    uint64_t waves = n_blocks + 1;
+    uint64_t waves = (n_blocks + 1 + ENC_BPW - 1) / ENC_BPW;
     hipLaunchKernelGGL(k_enc_blocks<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, post_off, blk_off, n_lists,
                        values, n_blocks, sizes, (const uint64_t *)nullptr, skip, (uint8_t *)nullptr, (uint64_t)0);
     return hipGetLastError();
@@ -99,7 +134,7 @@ hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_
 hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
                             const uint32_t *values, uint64_t n_blocks, const uint64_t *byte_off64,
                             ii2_skip *skip, uint8_t *payload, uint64_t n_postings, hipStream_t s) {
-    uint64_t waves = n_blocks + 1;
+    uint64_t waves = (n_blocks + 1 + ENC_BPW - 1) / ENC_BPW;
     hipLaunchKernelGGL(k_enc_blocks<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, post_off, blk_off, n_lists,
                        values, n_blocks, (uint32_t *)nullptr, byte_off64, skip, payload, n_postings);
     return hipGetLastError();
@@ -179,6 +214,25 @@ hipError_t launch_list_last_doc(const uint32_t *blk_off, const ii2_skip *skip, c
     if (n_lists == 0) return hipSuccess;
     hipLaunchKernelGGL(k_list_last_doc, dim3((unsigned)((n_lists + 3) / 4)), dim3(256), 0, s, blk_off, skip, payload, n_lists, cnt, blk_list,
                        last_doc);
+    return hipGetLastError();
+}
+
+// per list {first doc, first doc of its last block, last doc}: mirrored on the host when a segment is created, so that a
+// query never has to fetch them (ii2_intersect_async stays enqueue-only)
+__global__ void k_list_spans(const uint32_t *__restrict__ blk_off, const ii2_skip *__restrict__ skip, const uint32_t *__restrict__ last_doc,
+                             uint64_t n_lists, uint32_t *__restrict__ spans) {
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lists) return;
+    const uint32_t b0 = blk_off[l], b1 = blk_off[l + 1];
+    const bool any = b1 > b0;
+    spans[3 * l] = any ? skip[b0].first_doc : 0u;
+    spans[3 * l + 1] = any ? skip[b1 - 1u].first_doc : 0u;
+    spans[3 * l + 2] = any ? last_doc[l] : 0u;
+}
+
+hipError_t launch_list_spans(const uint32_t *blk_off, const ii2_skip *skip, const uint32_t *last_doc, uint64_t n_lists, uint32_t *spans, hipStream_t s) {
+    if (n_lists == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_list_spans, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, s, blk_off, skip, last_doc, n_lists, spans);
     return hipGetLastError();
 }
 

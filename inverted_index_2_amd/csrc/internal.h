@@ -92,6 +92,8 @@ struct ii2_seg {
     struct ListSpan { uint32_t first_doc, last_block_first_doc, last_doc; };
     mutable std::mutex span_mu;             // contexts on different threads share the cache
     mutable std::unordered_map<uint64_t, ListSpan> span_cache;
+    std::vector<uint32_t> h_spans;          // {first doc, first doc of the last block, last doc} per list, mirrored at creation (segments of <= SPAN_MIRROR_MAX lists)
+    static constexpr uint64_t SPAN_MIRROR_MAX = 1u << 16;
 };
 
 struct ii2_tomb {
@@ -263,6 +265,7 @@ hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_l
                                   uint64_t n_blocks, uint32_t *bad, hipStream_t s);
 hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const ii2_skip *skip, uint64_t n_blocks, uint64_t n_bytes,
                                uint32_t *bad, hipStream_t s);
+hipError_t launch_list_spans(const uint32_t *blk_off, const ii2_skip *skip, const uint32_t *last_doc, uint64_t n_lists, uint32_t *spans, hipStream_t s);
 hipError_t launch_seg_rebase(uint32_t *blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *skip, uint64_t n_blocks, uint32_t add_bytes,
                              hipStream_t s);
 hipError_t launch_sum_u32(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);

@@ -251,3 +251,22 @@ def test_dense_single_term_tiles_take_the_bitmap_path(ctx, k):
         st = _check_merge(ctx, offs, vals, removed=removed)
         assert st.n_tiles > T
     ctx.set_option("merge.bitmap_tiles", 1)
+
+
+def test_output_too_small_writes_nothing(ctx):
+    """II2_ECAPACITY is all-or-nothing for the merge (include/ii2.h): neither the offsets nor the values are touched."""
+    from inverted_index_2_amd.engine import II2Error
+    rng = np.random.default_rng(8)
+    offs, vals = _rand_segments(rng, 3, 200, 40, 1_000_000)
+    segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+    w_off, w_vals, _ = orc.merge_segments(offs, vals, ())
+    n_out = int(w_off[-1])
+    out_off = ctx.empty(201, np.uint64).upload(np.full(201, 0xABCDEF0123456789, np.uint64))
+    out_vals = ctx.empty(n_out - 1).upload(np.full(n_out - 1, 0xDEADBEEF, np.uint32))
+    with pytest.raises(II2Error) as e:
+        ctx.merge(segs, None, out_off, out_vals)
+    assert e.value.code == -4
+    assert np.all(out_off.download() == np.uint64(0xABCDEF0123456789)) and np.all(out_vals.download() == 0xDEADBEEF)
+    out_vals2 = ctx.empty(n_out)                                  # exactly enough: succeeds
+    g_off, g_vals, st = ctx.merge(segs, None, out_off, out_vals2)
+    assert np.array_equal(g_off.download(), w_off) and np.array_equal(g_vals.download(n_out), w_vals)
