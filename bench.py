@@ -577,13 +577,17 @@ def bench_merge(job):
             po, vv = sg.decode()
             compact.append(ctx.encode(np.concatenate([[0], np.cumsum(np.diff(po.astype(np.int64))[present])]).astype(np.uint64), vv))
             del po, vv
-        blob = np.frombuffer(b"".join(d.tobytes() for d in dict_ids), dtype=np.uint8)
         n_all = sum(d.size for d in dict_ids)
-        toff = (np.arange(n_all + 1, dtype=np.uint64) * np.uint64(8))
-        first = np.concatenate([[0], np.cumsum([d.size for d in dict_ids])]).astype(np.uint64)
+        # every segment's dictionary is made resident once, when the segment is (ii2_dict_create): the alignment reads them in HBM
+        t0 = time.perf_counter()
+        res_dicts = [ctx.dictionary_flat(np.frombuffer(d.tobytes(), np.uint8), np.arange(d.size + 1, dtype=np.uint64) * np.uint64(8)) for d in dict_ids]
+        job.torch.cuda.synchronize()
+        dict_ms = (time.perf_counter() - t0) * 1e3
+        al = ctx.align_dicts(res_dicts)
+        al.free()                                                 # warm-up (workspace growth)
         job.torch.cuda.synchronize()
         t0 = time.perf_counter()
-        al = ctx.align_terms_flat(blob, toff, first)
+        al = ctx.align_dicts(res_dicts)
         t1 = time.perf_counter()
         views = [ctx.select_aligned(c, al, i) for i, c in enumerate(compact)]
         t2 = time.perf_counter()
@@ -594,11 +598,13 @@ def bench_merge(job):
         res["end_to_end_with_device_alignment"] = {
             "dictionary_terms_in": int(n_all), "union_terms": int(al.n_union), "align_ms": (t1 - t0) * 1e3, "select_views_ms": (t2 - t1) * 1e3,
             "merge_ms": (t3 - t2) * 1e3, "total_ms": (t3 - t0) * 1e3, "value": n_in / (t3 - t0), "unit": "postings/s",
-            "note": "align_ms includes the upload of the flat dictionaries (host buffers, PCIe); one run, wall clock",
+            "make_dictionaries_resident_ms": dict_ms,
+            "note": "dictionaries resident in HBM (made once per segment, ii2_dict_create: make_dictionaries_resident_ms, not part of total_ms); "
+                    "align_ms = ii2_align_dicts (ranking kernel + prefix sum + numbering); one run after one warm-up, wall clock",
             "check": "same result as the pre-aligned merge" if ok else "MISMATCH"}
         if not ok:
             job.rc = 5
-        for v in views + compact:
+        for v in views + compact + res_dicts:
             v.free()
         al.free()
     except Exception as e:  # noqa: BLE001 — the timed figures above stand on their own

@@ -128,6 +128,16 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
  * the device: the union dictionary (n_union terms, ascending) and, per dictionary, which of its
  * terms is which union term. */
 typedef struct ii2_align ii2_align;
+/* A segment's term dictionary resident in HBM (sorted, duplicate-free terms: term_off[n_terms + 1] byte offsets into
+ * term_bytes, term_off[0] = 0; `where` says where the two arrays live).  Made once, when the segment is created or
+ * loaded; alignments then read it in place. */
+typedef struct ii2_dict ii2_dict;
+int ii2_dict_create(ii2_ctx *ctx, const uint8_t *term_bytes, const uint64_t *term_off, uint64_t n_terms, int where, ii2_dict **out);
+void ii2_dict_free(ii2_dict *dict);
+/* The alignment of k resident dictionaries: no upload, no host pass over the terms, no sort — every term finds its place
+ * in the k-way merge by bounded bisections in the other dictionaries (align.hip). */
+int ii2_align_dicts(ii2_ctx *ctx, uint32_t k, const ii2_dict *const *dicts, ii2_align **out);
+/* The same from flat host arrays (k temporary dictionaries are made and freed inside the call): */
 int ii2_align_terms(ii2_ctx *ctx, uint32_t k, const uint8_t *term_bytes, const uint64_t *term_off,
                     const uint64_t *seg_first, ii2_align **out);
 int ii2_align_info(const ii2_align *a, uint64_t *n_union, uint32_t *k);

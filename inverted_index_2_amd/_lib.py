@@ -49,6 +49,9 @@ PROTOTYPES = {
     "ii2_seg_decode": (C.c_int, [vp, vp, vp, vp, C.c_int]),
     "ii2_seg_export": (C.c_int, [vp, vp, vp, vp, vp]),
     "ii2_seg_select": (C.c_int, [vp, vp, C.c_uint64, vp, vpp]),
+    "ii2_dict_create": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_int, vpp]),
+    "ii2_dict_free": (None, [vp]),
+    "ii2_align_dicts": (C.c_int, [vp, C.c_uint32, vpp, vpp]),
     "ii2_align_terms": (C.c_int, [vp, C.c_uint32, vp, vp, vp, vpp]),
     "ii2_align_info": (C.c_int, [vp, u64p, C.POINTER(C.c_uint32)]),
     "ii2_align_export": (C.c_int, [vp, vp, vp, vp]),

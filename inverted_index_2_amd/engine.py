@@ -200,6 +200,32 @@ class Context:
         self._ck(self.lib.ii2_align_terms(self.h, first.size - 1, _ptr(blob), _ptr(off), _ptr(first), C.byref(h)))
         return Alignment(self, h, None)
 
+    def dictionary(self, terms) -> "Dictionary":
+        """A segment's sorted, duplicate-free term dictionary (list of bytes), made resident in HBM (ii2_dict_create)."""
+        terms = list(terms)
+        off = np.zeros(len(terms) + 1, np.uint64)
+        if terms:
+            off[1:] = np.cumsum([len(t) for t in terms])
+        blob = np.frombuffer(b"".join(terms) + b"\0", dtype=np.uint8).copy()
+        return self.dictionary_flat(blob, off, terms)
+
+    def dictionary_flat(self, term_bytes, term_off, terms=None) -> "Dictionary":
+        """Same, from flat arrays: u8 bytes and u64 offsets [n + 1] starting at 0."""
+        blob, off = _np(term_bytes, np.uint8), _np(term_off, np.uint64)
+        h = C.c_void_p()
+        self._ck(self.lib.ii2_dict_create(self.h, _ptr(blob), _ptr(off), off.size - 1, II2_HOST, C.byref(h)))
+        return Dictionary(self, h, terms)
+
+    def align_dicts(self, dicts) -> "Alignment":
+        """The union of k resident dictionaries and every dictionary's place in it (ii2_align_dicts): no upload, no sort."""
+        arr = (C.c_void_p * len(dicts))(*[d.h for d in dicts])
+        h = C.c_void_p()
+        self._ck(self.lib.ii2_align_dicts(self.h, len(dicts), arr, C.byref(h)))
+        flat = None
+        if all(d.terms is not None for d in dicts):
+            flat = [t for d in dicts for t in d.terms]
+        return Alignment(self, h, flat)
+
     def select_aligned(self, seg: "Segment", alignment: "Alignment", s: int, first_list: int = 0) -> "Segment":
         out = C.c_void_p()
         self._ck(self.lib.ii2_seg_select_aligned(self.h, seg.h, alignment.h, s, first_list, C.byref(out)))
@@ -395,8 +421,27 @@ class Segment:
             pass
 
 
+class Dictionary:
+    """A term dictionary resident in HBM (ii2_dict)."""
+
+    def __init__(self, ctx: Context, h: C.c_void_p, terms=None):
+        self.ctx, self.h, self.terms = ctx, h, terms
+
+    def free(self) -> None:
+        if self.h:
+            self.ctx.lib.ii2_dict_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            if not sys.is_finalizing():
+                self.free()
+        except Exception:
+            pass
+
+
 class Alignment:
-    """Device-resident result of Context.align_terms (ii2_align)."""
+    """Device-resident result of Context.align_terms / align_dicts (ii2_align)."""
 
     def __init__(self, ctx: Context, h: C.c_void_p, flat_terms):
         self.ctx, self.h, self._flat = ctx, h, flat_terms

@@ -112,3 +112,43 @@ def test_aligned_views_feed_the_merge(ctx):
     terms2, src2 = al2.export()
     want = [lists[0][lo + j] if j >= 0 else np.empty(0, np.uint32) for j in src2[0]]
     assert np.array_equal(v, np.concatenate(want)) and np.array_equal(np.diff(po.astype(np.int64)), [w.size for w in want])
+
+
+@pytest.mark.parametrize("k,n,alphabet,maxlen", [(5, 400, [0x00, 0x01, 0xFF, 0x61], 9), (16, 3000, list(range(256)), 19), (64, 2000, [0x61, 0x7A, 0x41], 12)])
+def test_resident_dictionaries_align_like_the_flat_entry_point(ctx, k, n, alphabet, maxlen):
+    """ii2_dict_create + ii2_align_dicts: the dictionaries live in HBM, the alignment reads them in place."""
+    rng = np.random.default_rng(k * 77 + n)
+    dicts = rand_dicts(rng, k, n, alphabet, maxlen)
+    want_terms, want_src = host_align(dicts)
+    res = [ctx.dictionary(d) for d in dicts]
+    for _ in range(2):                                   # the dictionaries are reusable
+        al = ctx.align_dicts(res)
+        terms, src = al.export()
+        assert al.n_union == len(want_terms) and terms == want_terms and np.array_equal(src, want_src)
+    al2 = ctx.align_dicts(res[::-1])                     # any order of the dictionaries: same union
+    t2, s2 = al2.export()
+    assert t2 == want_terms and np.array_equal(s2, want_src[::-1])
+
+
+def test_sixteen_dictionaries_of_a_million_fixed_width_ids(ctx):
+    """The C3 shape: 16 dictionaries of 8-byte big-endian ids drawn from 1M terms (byte order = numeric order)."""
+    rng = np.random.default_rng(5)
+    T = 1_000_000
+    ids = [np.flatnonzero(rng.random(T) < 0.95).astype(np.uint64) for _ in range(16)]
+    res = [ctx.dictionary_flat(np.frombuffer(a.astype(">u8").tobytes(), np.uint8), np.arange(a.size + 1, dtype=np.uint64) * 8) for a in ids]
+    al = ctx.align_dicts(res)
+    union = np.unique(np.concatenate(ids))
+    assert al.n_union == union.size
+    rep, src = al.export()
+    src = src.reshape(16, union.size)
+    for s in (0, 7, 15):
+        assert np.array_equal(np.flatnonzero(src[s] >= 0), np.searchsorted(union, ids[s]))
+        assert np.array_equal(src[s][src[s] >= 0], np.arange(ids[s].size))
+
+
+def test_malformed_dictionary_is_refused(ctx):
+    from inverted_index_2_amd.engine import II2Error
+    with pytest.raises(II2Error):
+        ctx.dictionary_flat(np.zeros(4, np.uint8), np.array([0, 3, 2, 4], np.uint64))      # offsets not monotone
+    with pytest.raises(II2Error):
+        ctx.dictionary_flat(np.zeros(4, np.uint8), np.array([1, 2, 4], np.uint64))         # does not start at 0
