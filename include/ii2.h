@@ -184,6 +184,23 @@ int ii2_merge_segments(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, con
 int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const ii2_tomb *tomb,
                               ii2_seg **out, ii2_merge_stats *stats);
 
+/* The common Shard.Merge in ONE launch.  Every Shard.Put writes a direct segment with one posting per term (shard.go:33-67)
+ * and Shard.Merge picks the smallest segments first (shard.go:135-146): the usual merge is a handful of tiny segments.  This
+ * entry point does, in one kernel and one host round trip, what otherwise takes ii2_align_terms + k x ii2_seg_select_aligned +
+ * ii2_tomb_create + ii2_merge_segments_to_seg + the empty-term compaction: term alignment of the k dictionaries
+ * (bytes.Compare order), same-term union, tombstone filter, empty-term drop (shard.go:192-194) and the encode step.
+ * Input: k segments, segs[s] holding exactly one list per term of dictionary s, the dictionaries flat in host memory as for
+ * ii2_align_terms, and RemovedLists.Values() (host, any order, duplicates allowed) or NULL.  Output: *out = the merged
+ * segment, one list per SURVIVING term (NULL when none survives, shard.go:219-225); kept[j] (capacity seg_first[k]) = index
+ * into term_off of an input term equal to the term of output list j; *n_kept = number of output lists.
+ * Limits (II2_ERANGE beyond them: use the general entry points): */
+#define II2_SMALL_MERGE_TERMS 512u       /* input terms in all */
+#define II2_SMALL_MERGE_POSTINGS 8192u   /* input postings in all */
+#define II2_SMALL_MERGE_REMOVED 4096u    /* removed ids */
+int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const uint8_t *term_bytes, const uint64_t *term_off,
+                    const uint64_t *seg_first, const uint32_t *removed, uint64_t n_removed, ii2_seg **out, uint64_t *kept,
+                    uint64_t *n_kept, ii2_merge_stats *stats);
+
 /* Multi-term intersection (build-defined operator, absent in the reference — SURVEY §0 D1):
  * ascending ids present in every list segs[i]/list_idx[i], minus the tombstones when
  * tomb != NULL (tomb == NULL is the reference's Read behaviour).

@@ -161,6 +161,10 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     ii2_comm_destroy_internal(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
+    if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
+    if (ctx->d_small_in) (void)hipFree(ctx->d_small_in);
+    if (ctx->d_small_out) (void)hipFree(ctx->d_small_out);
     if (ctx->h_segs) (void)hipHostFree(ctx->h_segs);
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     for (uint8_t *q : ctx->pool) if (q) (void)hipFree(q);
@@ -221,6 +225,7 @@ int ii2_copy_d2h(ii2_ctx *ctx, void *dst, const void *src, size_t bytes) {
 // ---- segments -----------------------------------------------------------------------------
 static void seg_release(ii2_seg *s) {
     if (!s) return;
+    if (s->in_slab) { delete s; return; }       // the store's slab holds every array (ii2_merge_small)
     if (s->d_blk_off) (void)hipFree(s->d_blk_off);
     if (!s->store) {          // not yet handed to a store: still owned directly
         if (s->d_skip) (void)hipFree(s->d_skip);

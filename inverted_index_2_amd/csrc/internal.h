@@ -36,6 +36,7 @@ struct ii2_ctx {
     int64_t opt_merge_bitmap = 1;       // single-term tiles whose doc range fits the LDS bitmap are merged by marking bits
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
     size_t aux_cap = 0;
+    void *h_small_in = nullptr, *h_small_out = nullptr, *d_small_in = nullptr, *d_small_out = nullptr;   // ii2_merge_small: upload / download blocks
     void *h_segs = nullptr;             // pinned staging block of a merge call's segment views ...
     void *d_segs = nullptr;             // ... and its device copy (MergeSegs)
     // grow-only staging buffers of the encode / decode / merge-to-segment paths (no hipMalloc per call)
@@ -68,9 +69,11 @@ struct ii2_ctx {
 struct ii2_seg_store {
     ii2_skip *d_skip = nullptr;
     uint8_t *d_payload = nullptr;
+    void *slab = nullptr;            // one allocation that holds ALL arrays of a small segment (ii2_merge_small): freed as a whole
     ~ii2_seg_store() {
         if (d_skip) (void)hipFree(d_skip);
         if (d_payload) (void)hipFree(d_payload);
+        if (slab) (void)hipFree(slab);
     }
 };
 
@@ -78,6 +81,7 @@ struct ii2_seg_store {
 // read it, from any thread (the reference's readers share segments, segments.go:32-46).
 struct ii2_seg {
     int device = 0;
+    bool in_slab = false;                    // every array below lives in store->slab (nothing to free one by one)
     std::shared_ptr<ii2_seg_store> store;   // owns d_skip / d_payload
     uint64_t n_lists = 0, n_postings = 0, n_blocks = 0, n_bytes = 0;
     uint32_t *d_blk_off = nullptr;   // [n_lists+1]

@@ -291,6 +291,28 @@ class Context:
         return (Segment(self, out) if out.value else None), st
 
     # ---- host-buffer calls (what the cgo binding uses) ---------------------------------------
+    def merge_small(self, segs: Sequence["Segment"], dictionaries, removed=()):
+        """The common Shard.Merge in one launch (ii2_merge_small): k small segments with their term dictionaries (lists of
+        bytes, segs[s] holding one list per term of dictionaries[s]) and RemovedLists.Values().  Returns (merged Segment or
+        None, its terms, MergeStats)."""
+        flat = [t for d in dictionaries for t in d]
+        off = np.zeros(len(flat) + 1, np.uint64)
+        if flat:
+            off[1:] = np.cumsum([len(t) for t in flat])
+        blob = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8).copy()
+        first = np.zeros(len(dictionaries) + 1, np.uint64)
+        first[1:] = np.cumsum([len(d) for d in dictionaries])
+        rem = _np(removed, np.uint32)
+        arr = (C.c_void_p * len(segs))(*[s.h for s in segs])
+        out = C.c_void_p()
+        kept = np.zeros(max(len(flat), 1), np.uint64)
+        n_kept = C.c_uint64()
+        st = MergeStats()
+        self._ck(self.lib.ii2_merge_small(self.h, len(segs), arr, _ptr(blob), _ptr(off), _ptr(first), _ptr(rem) if rem.size else None, rem.size,
+                                          C.byref(out), kept.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(n_kept), C.byref(st)))
+        terms = [flat[int(g)] for g in kept[: n_kept.value]]
+        return (Segment(self, out) if out.value else None), terms, st
+
     def merge_host(self, seg_offs, seg_vals, removed=()):
         k = len(seg_offs)
         offs = [_np(o, np.uint64) for o in seg_offs]

@@ -504,6 +504,46 @@ class Shard {
 
     // Merge into a new device-resident segment; false when no term survives.
     bool merged_segment(ii2_ctx *ctx, const std::vector<const Segment *> &segs, const std::vector<uint32_t> &removed, Segment *out) const {
+        // The common case — a few small segments (every Put writes a direct segment of one posting per term, shard.go:33-67,
+        // and the smallest segments are picked first, shard.go:135-146) — is one launch: alignment, union, removed-list
+        // filter, empty-term drop and encode in ii2_merge_small.  Anything larger takes the general path below.
+        {
+            size_t n_terms = 0, n_bytes = 0;
+            uint64_t n_post = 0;
+            for (auto *sg : segs) {
+                n_terms += sg->terms.size();
+                for (auto &t : sg->terms) n_bytes += t.size();
+                ii2_seg_info inf;
+                if (ii2_seg_get_info(sg->seg->h, &inf) == II2_OK) n_post += inf.n_postings;
+            }
+            if (!segs.empty() && segs.size() <= II2_MAX_LISTS && n_terms <= II2_SMALL_MERGE_TERMS && n_post <= II2_SMALL_MERGE_POSTINGS &&
+                removed.size() <= II2_SMALL_MERGE_REMOVED && n_bytes <= 16384) {
+                std::string bytes;
+                std::vector<uint64_t> off{0}, first{0};
+                std::vector<const ii2_seg *> hs;
+                for (auto *sg : segs) {
+                    for (auto &t : sg->terms) { bytes += t; off.push_back(bytes.size()); }
+                    first.push_back(off.size() - 1);
+                    hs.push_back(sg->seg->h);
+                }
+                std::vector<uint64_t> kept(n_terms + 1);
+                uint64_t n_kept = 0;
+                ii2_seg *m = nullptr;
+                ii2_merge_stats st;
+                std::memset(&st, 0, sizeof st);
+                const int rc = ii2_merge_small(ctx, (uint32_t)hs.size(), hs.data(), (const uint8_t *)bytes.data(), off.data(), first.data(),
+                                               removed.empty() ? nullptr : removed.data(), removed.size(), &m, kept.data(), &n_kept, &st);
+                if (rc == II2_OK) {
+                    if (!m) return false;
+                    out->terms.clear();
+                    for (uint64_t j = 0; j < n_kept; j++) out->terms.emplace_back(bytes.data() + off[kept[j]], off[kept[j] + 1] - off[kept[j]]);
+                    out->seg = std::make_shared<SegHandle>(m);
+                    out->key = now_ns();
+                    return true;
+                }
+                if (rc != II2_ERANGE) ck(ctx, rc, "s: merge");      // (a view's posting count is an upper bound: the kernel may still refuse)
+            }
+        }
         Aligned a = align(ctx, segs, nullptr, nullptr);
         if (a.views.empty()) return false;
         fold_to_limit(ctx, a.views);
