@@ -150,6 +150,85 @@ func (c *Ctx) SelectAligned(seg *Segment, a *Alignment, s int, firstList uint64)
 
 func (a *Alignment) Free() { C.ii2_align_free(a.h); a.h = nil }
 
+// Dictionary is a segment's sorted, duplicate-free term dictionary resident in HBM (ii2_dict): made once, when the
+// segment is written or loaded, so that alignments read it in place (no upload per merge).
+type Dictionary struct{ h *C.ii2_dict }
+
+// NewDictionary uploads a dictionary given flat (termBytes, termOff[n+1], termOff[0] == 0).
+func (c *Ctx) NewDictionary(termBytes []byte, termOff []uint64) (*Dictionary, error) {
+	var tb *C.uint8_t
+	if len(termBytes) > 0 {
+		tb = (*C.uint8_t)(unsafe.Pointer(&termBytes[0]))
+	}
+	var d *C.ii2_dict
+	if rc := C.ii2_dict_create(c.h, tb, u64ptr(termOff), C.uint64_t(len(termOff)-1), C.II2_HOST, &d); rc != 0 {
+		return nil, c.err("dictionary", rc)
+	}
+	return &Dictionary{d}, nil
+}
+
+func (d *Dictionary) Free() { C.ii2_dict_free(d.h); d.h = nil }
+
+// AlignDicts is AlignTerms on resident dictionaries (ii2_align_dicts): nothing is uploaded, nothing is sorted.
+func (c *Ctx) AlignDicts(dicts []*Dictionary) (*Alignment, error) {
+	hs := make([]*C.ii2_dict, len(dicts))
+	for i, d := range dicts {
+		hs[i] = d.h
+	}
+	var a *C.ii2_align
+	if rc := C.ii2_align_dicts(c.h, C.uint32_t(len(hs)), (**C.ii2_dict)(unsafe.Pointer(&hs[0])), &a); rc != 0 {
+		return nil, c.err("align", rc)
+	}
+	var n C.uint64_t
+	var k C.uint32_t
+	C.ii2_align_info(a, &n, &k)
+	return &Alignment{h: a, NUnion: uint64(n), K: int(k)}, nil
+}
+
+// MergeSmall is the common Shard.Merge in one launch (ii2_merge_small): a few small resident segments (what Shard.Put
+// writes, shard.go:33-67), their dictionaries flat as for AlignTerms, RemovedLists.Values().  It returns the merged
+// segment (nil when no term survives, shard.go:219-225) and, per output list, the index into termOff of an input term
+// equal to its term.  ErrTooLarge (II2_ERANGE) means: take AlignTerms + MergeSegmentsToSeg instead.
+func (c *Ctx) MergeSmall(segs []*Segment, termBytes []byte, termOff, segFirst []uint64, removed []uint32) (*Segment, []uint64, error) {
+	hs := make([]*C.ii2_seg, len(segs))
+	for i, s := range segs {
+		hs[i] = s.h
+	}
+	var tb *C.uint8_t
+	if len(termBytes) > 0 {
+		tb = (*C.uint8_t)(unsafe.Pointer(&termBytes[0]))
+	}
+	kept := make([]uint64, len(termOff))
+	var nKept C.uint64_t
+	var out *C.ii2_seg
+	var st C.ii2_merge_stats
+	rc := C.ii2_merge_small(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), tb, u64ptr(termOff), u64ptr(segFirst),
+		u32ptr(removed), C.uint64_t(len(removed)), &out, u64ptr(kept), &nKept, &st)
+	if rc == C.II2_ERANGE {
+		return nil, nil, ErrTooLarge
+	}
+	if rc != 0 {
+		return nil, nil, c.err("merge", rc)
+	}
+	if out == nil {
+		return nil, nil, nil
+	}
+	return &Segment{out}, kept[:nKept], nil
+}
+
+// ErrTooLarge: the inputs exceed the one-launch merge's limits (II2_SMALL_MERGE_*).
+var ErrTooLarge = fmt.Errorf("gpu: too large for the one-launch merge")
+
+// SegAllGather concatenates every rank's merged segment in rank order into one segment on every rank; the postings
+// travel DV1-encoded (ii2_seg_allgather; one process per GPU, the communicator set up with ii2_comm_init).
+func (c *Ctx) SegAllGather(local *Segment) (*Segment, error) {
+	var out *C.ii2_seg
+	if rc := C.ii2_seg_allgather(c.h, local.h, &out); rc != 0 {
+		return nil, c.err("segment all-gather", rc)
+	}
+	return &Segment{out}, nil
+}
+
 // Union replaces PrefixSearch's append + slices.Sort + slices.Compact (inverted_index.go:274-292).
 func (c *Ctx) Union(listOff []uint64, values, removed []uint32) ([]uint32, error) {
 	return c.lists(true, listOff, values, removed)

@@ -1154,6 +1154,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "merge.large_tile") ctx->opt_merge_large_tile = value;
     else if (k == "merge.bitmap_tiles") ctx->opt_merge_bitmap = value;
     else if (k == "debug.merge_skip") ctx->opt_merge_skip = value;
+    else if (k == "merge.direct") ctx->opt_merge_direct = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;

@@ -32,6 +32,7 @@ struct ii2_ctx {
     int64_t opt_intersect_g = 0;        // 0 = auto
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
+    int64_t opt_merge_direct = 1;       // tiles place their survivors themselves when the output buffer surely fits (0: always park + pack)
     int64_t opt_merge_skip = 0;         // timing experiments: phases of the merge tile kernel left out (results wrong)
     int64_t opt_merge_bitmap = 1;       // single-term tiles whose doc range fits the LDS bitmap are merged by marking bits
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
@@ -295,6 +296,9 @@ struct MergeSegs {
 };
 static_assert(sizeof(MergeSegs) <= 4096, "MergeSegs travels through one pinned 4 KB block");
 
+// direct placement of the merged postings (merge.hip): tile tickets, an error flag for bounded waits
+struct MergeSync { uint32_t ticket, error, pad0, pad1; };
+
 struct MergeParams {
     uint32_t k;
     uint32_t n_tiles_ub;          // host-side upper bound of the tile count (sizes grids and per-tile arrays)
@@ -309,6 +313,9 @@ struct MergeParams {
     uint32_t bitmap_tiles;        // 1: dense terms are cut into bitmap tiles
     uint32_t bitmap_sparsity;     // ... when they hold at least one posting per this many docs
     uint32_t pad0;
+    uint32_t direct;              // 1: tiles go to their final place from inside the tile kernel (ticket order + scanner); 0: parking + packing pass
+    MergeSync *sync;              // (zeroed by the host)
+    uint64_t *tile_off;           // [n_tiles_ub + 1] output offset of every tile: written by the scanner (direct) or by the scan before the packing pass
     // per term (plan)
     uint32_t *tn;                 // [T+1] input postings
     uint32_t *tmin, *tmax;        // [T+1] smallest / largest doc id over the k lists

@@ -37,6 +37,8 @@ constexpr uint32_t EPT = MCAP / MT;               // elements per thread in the 
 constexpr uint32_t PCAP = 1536;                   // 16-byte payload pieces decoded per chunk of blocks
 constexpr uint32_t BKT_LIMIT = 15;                // fullest bucket the bucket sort accepts (slot numbers are 4 bits)
 constexpr uint32_t BMW = MERGE_BM_WORDS;
+constexpr uint32_t MERGE_PQ = 16;                  // parked tiles a workgroup may have waiting for their output offset
+constexpr uint32_t SPIN_LIMIT = 4000000;          // bounded waits (each ~1.5 us: seconds in all): a bug must not hang the GPU
 static_assert(MCAP % MT == 0 && EPT * 4u <= 64u && (MCAP / 2u) % MT == 0, "sort passes: EPT elements and EPT / 2 counter words per thread");
 
 // ---- plan ----------------------------------------------------------------------------------
@@ -246,6 +248,11 @@ struct __align__(16) MergeSmem {
     uint32_t ovf;                           // a bucket overflowed
     uint32_t tp;                            // pieces of the chunk
     uint32_t ab;                            // allocation inside the term's parking region
+    uint32_t tk;                            // the tile this workgroup works on next (ticket)
+    uint32_t pq_n;                          // parked tiles that still wait for their place in the output
+    uint32_t pq_tile[MERGE_PQ], pq_cnt[MERGE_PQ];
+    unsigned long long pq_slot[MERGE_PQ];
+    unsigned long long pq_off;              // output offset of the queue's first tile
     uint32_t stk[72][2];                    // bisection stack of doc ranges
 };
 
@@ -325,22 +332,139 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
     uint16_t *C16 = reinterpret_cast<uint16_t *>(sm.u.s.C32);
 
     const uint32_t n_tiles = *p.n_tiles_dev;       // computed by the plan kernels; the host only knows an upper bound
-    // what a tile needs from global memory before it can start is fetched one tile ahead: its descriptor, its runs and
-    // (one step later, when the descriptor is there) its terms' plan entries
-    uint4 td_nx = blockIdx.x < n_tiles ? p.desc[blockIdx.x] : make_uint4(0, 0, 1, 0);
-    uint2 rn_nx = (blockIdx.x < n_tiles && (uint32_t)tid < k) ? p.runs[(uint64_t)blockIdx.x * k + (uint32_t)tid] : make_uint2(0, 0);
+    MergeSync *sy = p.sync;
+    // ---- direct placement (p.direct): the FIRST workgroup of the grid is the scanner (workgroups are dispatched in ascending
+    // order: whenever a worker of this launch runs, its scanner runs too).  Tiles are claimed in ticket order and publish their
+    // survivor counts (count + 1; 0 = not yet); the scanner's one wave turns the counts into output offsets as far as the
+    // counts are contiguous (tile_off starts as all-ones: an entry is its own "ready" flag).  A tile workgroup parks its
+    // survivors as always, goes on with its next tile and moves a parked tile to its final place once its offset is there -
+    // normally one tile later, when everything that was in flight beside it has counted too.  No packing pass, no scan launch.
+    // Only those two scalars cross workgroups (relaxed device-scope accesses, no fences: the L2s of the eight XCDs are not
+    // coherent with each other, and a release would write a whole L2 back); the parked ids stay inside their workgroup's CU.
+    // Every wait is bounded.
+    if (p.direct && blockIdx.x == 0u) {
+        // all eight waves: 512 tiles per step (one wave alone - 64 device-scope loads and as many write-through stores per
+        // step - tops out below the rate at which a full machine counts tiles, and the workers then queue up behind it)
+        uint32_t base = 0, spins = 0;
+        unsigned long long run = 0;
+        unsigned long long it_all = 0, it_zero = 0, t_start = __builtin_amdgcn_s_memtime();
+        uint32_t *sk = sm.RR0, *ss = sm.RR1;          // per wave: counted tiles in a row from the wave's first, their survivors
+        while (base < n_tiles) {
+            const uint32_t i = base + (uint32_t)tid;
+            const uint32_t c1 = i < n_tiles ? __hip_atomic_load(&p.tile_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
+            const unsigned long long m = __ballot(c1 != 0u);
+            const uint32_t kk = m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1u;
+            const uint32_t cnt = (uint32_t)l < kk && i < n_tiles ? c1 - 1u : 0u;
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (l == 0) { sk[wv] = kk; ss[wv] = kk ? wave_bcast(incl, 0) : 0u; }
+            const uint32_t wsum = kk ? (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)kk - 1) : 0u;
+            if (l == 0) ss[wv] = wsum;
+            lds_barrier();
+            bool mine = true;                         // the waves before mine are complete: my counted tiles extend the row
+            uint32_t pre = 0, K = 0, R = 0;
+            bool open = true;
+            for (uint32_t w = 0; w < MW; w++) {
+                if (w < (uint32_t)wv) { mine = mine && sk[w] == 64u; pre += ss[w]; }
+                if (open) { K += sk[w]; R += ss[w]; open = sk[w] == 64u; }
+            }
+            if (mine && (uint32_t)l < kk && i < n_tiles)
+                __hip_atomic_store(&p.tile_off[i], (uint64_t)(run + pre + incl - cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            run += R;
+            base += K;
+            it_all++;
+            if (K == 0u) it_zero++;
+            lds_barrier();
+            if (K == 0u) {
+                if (++spins > SPIN_LIMIT || __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    if (tid == 0) __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(10);
+            } else spins = 0;
+        }
+        if (tid == 0) { p.tile_off[n_tiles] = run; *p.d_total = run; }
+        if (stamps && tid == 0) { p.debug[0] = it_all; p.debug[1] = it_zero; p.debug[2] = __builtin_amdgcn_s_memtime() - t_start; p.debug[3] = n_tiles; }
+        return;
+    }
+    // moves parked tiles whose output offset is known to their final place; block: wait (bounded) until none is left waiting
+    // probe: thread 0's early look at the first queued tile's offset (taken mid-tile, so that its latency is hidden); used once
+    auto drain = [&](bool block, unsigned long long probe, uint32_t probe_tile) {
+        uint32_t spins = 0;
+        while (true) {
+            lds_barrier();
+            const uint32_t nq = sm.pq_n;
+            if (nq == 0u) return;
+            if (tid == 0) {
+                if (probe != ~0ull && probe_tile == sm.pq_tile[0]) sm.pq_off = probe;
+                else sm.pq_off = __hip_atomic_load(&p.tile_off[sm.pq_tile[0]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                probe = ~0ull;
+            }
+            __syncthreads();          // (also: the parked ids were stored by all waves of this workgroup - their stores have landed)
+            if (sm.pq_off != ~0ull) {
+                const uint32_t c = sm.pq_cnt[0];
+                const uint32_t *src = p.tmp + sm.pq_slot[0];
+                uint32_t *dstp = p.out_values + sm.pq_off;
+                // 16 bytes per thread and step, four steps in flight (a plain element loop is one dependent load -> store per
+                // thread at a time: latency-bound)
+                for (uint32_t q0 = 0; q0 < c; q0 += 16u * MT) {
+                    uint4 v4[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        const uint32_t q = q0 + 4u * ((uint32_t)tid + j * MT);
+                        v4[j] = make_uint4(0, 0, 0, 0);
+                        if (q + 4u <= c) __builtin_memcpy(&v4[j], src + q, 16);
+                        else if (q < c) { v4[j].x = src[q]; if (q + 1u < c) v4[j].y = src[q + 1u]; if (q + 2u < c) v4[j].z = src[q + 2u]; }
+                    }
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++) {
+                        const uint32_t q = q0 + 4u * ((uint32_t)tid + j * MT);
+                        if (q + 4u <= c) __builtin_memcpy(dstp + q, &v4[j], 16);
+                        else if (q < c) { dstp[q] = v4[j].x; if (q + 1u < c) dstp[q + 1u] = v4[j].y; if (q + 2u < c) dstp[q + 2u] = v4[j].z; }
+                    }
+                }
+                lds_barrier();
+                if (tid == 0) {
+                    for (uint32_t z = 1; z < nq; z++) { sm.pq_tile[z - 1u] = sm.pq_tile[z]; sm.pq_cnt[z - 1u] = sm.pq_cnt[z]; sm.pq_slot[z - 1u] = sm.pq_slot[z]; }
+                    sm.pq_n = nq - 1u;
+                }
+                spins = 0;
+                continue;
+            }
+            if (!block) return;
+            if (++spins > SPIN_LIMIT) { if (tid == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sm.pq_n = 0u; } continue; }
+            __builtin_amdgcn_s_sleep(20);
+        }
+    };
+    if (tid == 0) { sm.pq_n = 0u; sm.tk = p.direct ? atomicAdd(&sy->ticket, 1u) : blockIdx.x; }
+    lds_barrier();
+    const uint32_t n_workers = p.direct ? gridDim.x - 1u : gridDim.x;
+    uint32_t tk_next = 0;                           // thread 0: the ticket after this one (claimed early: its latency hides behind the tile)
+    // what a tile needs from global memory before it can start is fetched ahead: its descriptor, its runs and (one step later,
+    // when the descriptor is there) its terms' plan entries
+    uint32_t tile_nx = sm.tk;
+    uint4 td_nx = tile_nx < n_tiles ? p.desc[tile_nx] : make_uint4(0, 0, 1, 0);
+    uint2 rn_nx = (tile_nx < n_tiles && (uint32_t)tid < k) ? p.runs[(uint64_t)tile_nx * k + (uint32_t)tid] : make_uint2(0, 0);
     uint2 bo_nx = make_uint2(0, 0);                // the same for a tile that takes whole lists: blk_off[t0], blk_off[t1]
-    if (blockIdx.x < n_tiles && (uint32_t)tid < k) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    if (tile_nx < n_tiles && (uint32_t)tid < k) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
+    for (uint32_t tile = tile_nx; tile < n_tiles; tile = tile_nx) {
         const uint4 td = td_nx;
         const uint2 rn = rn_nx, bo = bo_nx;
-        {
-            const uint32_t nx = tile + gridDim.x;
-            if (nx < n_tiles) {
-                td_nx = p.desc[nx];
-                if ((uint32_t)tid < k) rn_nx = p.runs[(uint64_t)nx * k + (uint32_t)tid];
+        bool nx_known = false;                      // tile_nx / td_nx / rn_nx hold the next tile
+        if (!p.direct) {                            // static order: the next tile is known now
+            tile_nx = tile + n_workers;
+            nx_known = true;
+            if (tile_nx < n_tiles) {
+                td_nx = p.desc[tile_nx];
+                if ((uint32_t)tid < k) rn_nx = p.runs[(uint64_t)tile_nx * k + (uint32_t)tid];
             }
         }
+        // The next ticket is claimed now (its latency hides behind this tile) only while few parked tiles wait: a workgroup
+        // that may have to wait for room in its queue must not own a tile it has not started - the scanner's frontier
+        // would stand still at that tile, and every other queue would fill behind it.
+        const bool claim_early = p.direct && sm.pq_n <= 2u;
+        unsigned long long probe = ~0ull;           // thread 0: the first queued tile's offset as seen mid-tile
+        uint32_t probe_tile = 0xFFFFFFFFu;
+        if (claim_early && tid == 0) tk_next = atomicAdd(&sy->ticket, 1u);
         const uint32_t t0 = td.x, t1 = td.y & 0x3FFFFFFFu;
         // plan entries of the tile's terms (a batch: one term per thread), in flight while the tile is decoded
         const uint32_t my_t = t0 + ((uint32_t)tid < t1 - t0 ? (uint32_t)tid : 0u);
@@ -379,6 +503,20 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             return dst + acc;
         };
 
+        // Direct placement, at the tile's end: its count is published, the older parked tiles whose offsets have arrived move to
+        // their final place, and the tile joins the queue.  (Tried: doing this the moment the count is known, before the
+        // tile's own survivors are stored - the scanner sees counts earlier and the barrier in drain() has nothing recent to wait
+        // for, but the tile's stores then start later: 12.7 -> 13.7 ms on C3.)
+        bool published = false;
+        auto publish = [&](uint32_t cnt) {
+            lds_barrier();
+            if (tid == 0) __hip_atomic_store(&p.tile_count[tile], cnt + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counted: the scanner may pass this tile
+            drain(sm.pq_n >= MERGE_PQ, probe, probe_tile);     // what is ready moves now; a full queue waits for its oldest entry
+            probe = ~0ull;
+            lds_barrier();
+            if (tid == 0 && cnt) { const uint32_t z = sm.pq_n; sm.pq_tile[z] = tile; sm.pq_cnt[z] = cnt; sm.pq_slot[z] = slot; sm.pq_n = z + 1u; }
+            published = true;
+        };
         while (true) {
             if (sp == 0u) {
                 if (fb_active) {                       // a term of a batch that is redone term by term is complete
@@ -593,7 +731,23 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             }
             lds_barrier();
             II2_STAMP(BM ? 5 : (cur_batch ? 1 : 3))
-            if (was_root && (uint32_t)tid < k && tile + gridDim.x < n_tiles) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
+            if (was_root) {
+                if (p.direct && tid == 0 && probe_tile == 0xFFFFFFFFu && sm.pq_n) {
+                    probe_tile = sm.pq_tile[0];
+                    probe = __hip_atomic_load(&p.tile_off[probe_tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!nx_known && claim_early) {    // the next ticket has arrived by now: hand it round and fetch that tile's descriptor and runs
+                    if (tid == 0) sm.tk = tk_next;
+                    lds_barrier();
+                    tile_nx = sm.tk;
+                    nx_known = true;
+                    if (tile_nx < n_tiles) {
+                        td_nx = p.desc[tile_nx];
+                        if ((uint32_t)tid < k) rn_nx = p.runs[(uint64_t)tile_nx * k + (uint32_t)tid];
+                    }
+                }
+                if ((uint32_t)tid < k && tile_nx < n_tiles) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
+            }
 
             if (BM) {
                 // ---- bitmap: the union, the dedupe and the order came with the representation; clear the tombstoned docs
@@ -847,9 +1001,32 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             sp += 2u;
             II2_STAMP(7)
         }
-        if (tid == 0) { p.tile_count[tile] = acc; p.tile_slot[tile] = slot; }
+        auto take_next = [&]() {                    // the next ticket goes round; that tile's descriptor and runs are fetched
+            lds_barrier();
+            tile_nx = sm.tk;
+            nx_known = true;
+            if (tile_nx < n_tiles) {
+                td_nx = p.desc[tile_nx];
+                if ((uint32_t)tid < k) { rn_nx = p.runs[(uint64_t)tile_nx * k + (uint32_t)tid]; bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]); }
+            }
+        };
+        if (!nx_known && claim_early) {             // (a tile without a root range to decode: the early ticket was not handed round yet)
+            if (tid == 0) sm.tk = tk_next;
+            take_next();
+        }
+        if (!p.direct) {
+            if (tid == 0) { p.tile_count[tile] = acc; p.tile_slot[tile] = slot; }
+        } else {
+            if (!published) publish(acc);
+            lds_barrier();
+            if (!nx_known) {                        // no early claim: the next tile is claimed only now, with room in the queue
+                if (tid == 0) sm.tk = atomicAdd(&sy->ticket, 1u);
+                take_next();
+            }
+        }
         II2_STAMP(7)
     }
+    if (p.direct) drain(true, ~0ull, 0xFFFFFFFFu);
     if (stamps && tid == 0)
         for (int i = 0; i < 8; i++) p.debug[(uint64_t)blockIdx.x * 8u + i] = tacc[i];
 #undef II2_STAMP

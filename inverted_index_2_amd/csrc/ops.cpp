@@ -128,11 +128,12 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     // aux: per-tile arrays, the large terms' bump allocators and the parking array
     const size_t nt1 = (size_t)p.n_tiles_ub + 1;
     const size_t scan_t = scan_temp_bytes(nt1);
-    const size_t aux_need = align_up(nt1 * sizeof(uint32_t)) + align_up(n1 * sizeof(uint32_t)) + align_up(nt1 * 16) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
+    const size_t aux_need = 256 + align_up(nt1 * sizeof(uint32_t)) + align_up(n1 * sizeof(uint32_t)) + align_up(nt1 * 16) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
                             align_up(nt1 * k * sizeof(uint2)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
     if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
-    p.tile_count = carve<uint32_t>(ac, nt1);               // (first in the allocation: zeroed together with term_alloc by one memset)
+    p.sync = (MergeSync *)carve<uint8_t>(ac, sizeof(MergeSync));      // (first in the allocation: zeroed together with the two arrays after it by one memset)
+    p.tile_count = carve<uint32_t>(ac, nt1);
     p.term_alloc = carve<uint32_t>(ac, n1);
     const size_t zero_bytes = (size_t)(ac - ctx->aux);
     p.tile_slot = (unsigned long long *)carve<uint64_t>(ac, nt1);
@@ -169,12 +170,22 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
     HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(p.tile_count, 0, zero_bytes, st));      // tiles past the real count contribute 0 to the scan
-    // 2 workgroups of ~75 KB LDS per CU; each walks tiles w, w+grid, ...
+    HIP_TRY(ctx, hipMemsetAsync(ctx->aux, 0, zero_bytes, st));         // tickets / frontier, tile counts (tiles past the real count contribute 0), bump allocators
+    // 2 workgroups of ~75 KB LDS per CU.  When the caller's buffer is known to hold any result (out_cap >= all input postings)
+    // the tiles put their survivors in place themselves (ticket order, one scanner workgroup: merge.hip) - every posting
+    // crosses HBM once on its way in and once on its way out.  Otherwise (the fit is only known at the end, and the call is
+    // all-or-nothing) the tiles park and a packing pass follows the scan of their counts.
+    p.tile_off = d_tile_off;
+    p.direct = (postings_ub <= out_cap && ctx->opt_merge_direct) ? 1u : 0u;
+    if (p.direct) HIP_TRY(ctx, hipMemsetAsync(d_tile_off, 0xFF, nt1 * sizeof(uint64_t), st));      // all-ones: "offset not known yet"
     HIP_TRY(ctx, launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * 2u, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
+    if (!p.direct) {
+        HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
+        HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mail + 3, &p.sync->error, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));      // -> h_mail[3]
+    }
     HIP_TRY(ctx, launch_merge_large_counts(p, d_tile_off, st));
-    HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
     HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
     // all-or-nothing: like the packing pass, the offsets are only written when the result fits the caller's buffer
     if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64_guarded(d_scan, scan_b, d_cnt, d_out_off, n1, ctx->d_mail, out_cap, st));
@@ -184,6 +195,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint32_t n_tiles = (uint32_t)(ctx->h_mail[4] & 0xFFFFFFFFull);
     if (n_tiles > p.n_tiles_ub) return fail(ctx, II2_EHIP, "merge: internal error (tile bound exceeded)");
+    if (p.direct && (ctx->h_mail[3] & 0xFFFFFFFFull)) return fail(ctx, II2_EHIP, "merge: internal error (a bounded wait of the direct placement ran out)");
     if (n_tiles == 0) ctx->h_mail[0] = 0;
     if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small; nothing was written");
     if (stats) {

@@ -31,6 +31,8 @@ buf = (C.c_uint64 * (nwg * 8))()
 ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, nwg * 8))
 arr = np.frombuffer(buf, dtype=np.uint64).reshape(-1, 8).astype(np.float64)
 names = ["setup", "batch decode", "batch sort+write", "range decode", "range sort+write", "bitmap decode+mark", "bitmap tomb+extract", "tail"]
+print("scanner (direct placement): iterations %d, empty %d, cycles %d, tiles %d" % tuple(int(x) for x in arr[0, :4]))
+arr = arr[1:]
 tot = arr.sum(axis=1)
 print(f"cycles per WG: mean {tot.mean():.0f} max {tot.max():.0f} min {tot.min():.0f}")
 for i, nm in enumerate(names):
