@@ -462,8 +462,15 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
         // that may have to wait for room in its queue must not own a tile it has not started - the scanner's frontier
         // would stand still at that tile, and every other queue would fill behind it.
         const bool claim_early = p.direct && sm.pq_n <= 2u;
-        unsigned long long probe = ~0ull;           // thread 0: the first queued tile's offset as seen mid-tile
+        // thread 0 looks up the first queued tile's offset now; mid-tile - when the stores that parked it have long landed and
+        // this tile's decode has hidden the look-up's latency - the queued tiles whose offsets are there move to their place
+        unsigned long long probe = ~0ull;
         uint32_t probe_tile = 0xFFFFFFFFu;
+        if (p.direct && tid == 0 && sm.pq_n) {
+            probe_tile = sm.pq_tile[0];
+            probe = __hip_atomic_load(&p.tile_off[probe_tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool drained_mid = false;
         if (claim_early && tid == 0) tk_next = atomicAdd(&sy->ticket, 1u);
         const uint32_t t0 = td.x, t1 = td.y & 0x3FFFFFFFu;
         // plan entries of the tile's terms (a batch: one term per thread), in flight while the tile is decoded
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
         auto publish = [&](uint32_t cnt) {
             lds_barrier();
             if (tid == 0) __hip_atomic_store(&p.tile_count[tile], cnt + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // counted: the scanner may pass this tile
-            drain(sm.pq_n >= MERGE_PQ, probe, probe_tile);     // what is ready moves now; a full queue waits for its oldest entry
+            if (sm.pq_n >= MERGE_PQ || !drained_mid) drain(sm.pq_n >= MERGE_PQ, probe, probe_tile);     // (normally done mid-tile; a full queue waits for its oldest entry)
             probe = ~0ull;
             lds_barrier();
             if (tid == 0 && cnt) { const uint32_t z = sm.pq_n; sm.pq_tile[z] = tile; sm.pq_cnt[z] = cnt; sm.pq_slot[z] = slot; sm.pq_n = z + 1u; }
@@ -732,10 +739,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             lds_barrier();
             II2_STAMP(BM ? 5 : (cur_batch ? 1 : 3))
             if (was_root) {
-                if (p.direct && tid == 0 && probe_tile == 0xFFFFFFFFu && sm.pq_n) {
-                    probe_tile = sm.pq_tile[0];
-                    probe = __hip_atomic_load(&p.tile_off[probe_tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                if (p.direct && !drained_mid) { drain(false, probe, probe_tile); probe = ~0ull; drained_mid = true; }
                 if (!nx_known && claim_early) {    // the next ticket has arrived by now: hand it round and fetch that tile's descriptor and runs
                     if (tid == 0) sm.tk = tk_next;
                     lds_barrier();
