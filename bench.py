@@ -116,7 +116,7 @@ def cores_available():
 def pmc_traffic(name):
     """HBM bytes per pass from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the same
     workload, scripts/pmc_run.sh) — a recorded figure, not a counter of this run; the JSON says so (`traffic_source`)."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_%s.json" % name)
+    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % name)
     try:
         with open(path) as f:
             return json.load(f)["hbm_bytes_per_pass_corrected"], os.path.relpath(path, ROOT)
