@@ -282,9 +282,9 @@ constexpr uint32_t ISECT_SMAX = 16384;      // doc span a tile's LDS byte map ca
 hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 // merge / union (merge.hip)
-constexpr uint32_t MERGE_THREADS = 512;     // threads per workgroup of the tile kernel
-constexpr uint32_t MERGE_CAP = 7168;        // postings a tile sorts in LDS (14 per thread)
-constexpr uint32_t MERGE_NT_MAX = 512;      // terms per batch tile (one thread per term)
+constexpr uint32_t MERGE_THREADS = 256;     // threads per workgroup of the tile kernel
+constexpr uint32_t MERGE_CAP = 3584;        // postings a tile sorts in LDS (14 per thread)
+constexpr uint32_t MERGE_NT_MAX = 256;      // terms per batch tile (one thread per term)
 constexpr uint32_t MERGE_BM_WORDS = 2 * MERGE_CAP;          // LDS bitmap of a bitmap tile: the sort arrays' 56 KB
 constexpr uint32_t MERGE_BM_DOCS = MERGE_BM_WORDS * 32u;    // docs a bitmap tile covers (458752)
 // the k term-aligned inputs, by value in the kernel arguments

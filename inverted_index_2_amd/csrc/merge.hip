@@ -34,10 +34,10 @@ constexpr uint32_t MCAP = MERGE_CAP;
 constexpr uint32_t MT = MERGE_THREADS;
 constexpr uint32_t MW = MT / 64u;                 // waves per workgroup
 constexpr uint32_t EPT = MCAP / MT;               // elements per thread in the sort passes (14)
-constexpr uint32_t PCAP = 1536;                   // 16-byte payload pieces decoded per chunk of blocks
+constexpr uint32_t PCAP = 768;                   // 16-byte payload pieces decoded per chunk of blocks
 constexpr uint32_t BKT_LIMIT = 15;                // fullest bucket the bucket sort accepts (slot numbers are 4 bits)
 constexpr uint32_t BMW = MERGE_BM_WORDS;
-constexpr uint32_t MERGE_PQ = 16;                  // parked tiles a workgroup may have waiting for their output offset
+constexpr uint32_t MERGE_PQ = 8;                  // parked tiles a workgroup may have waiting for their output offset
 constexpr uint32_t SPIN_LIMIT = 4000000;          // bounded waits (each ~1.5 us: seconds in all): a bug must not hang the GPU
 static_assert(MCAP % MT == 0 && EPT * 4u <= 64u && (MCAP / 2u) % MT == 0, "sort passes: EPT elements and EPT / 2 counter words per thread");
 
@@ -211,6 +211,7 @@ __global__ void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams 
 // ---- the tile kernel ----------------------------------------------------------------------
 constexpr uint32_t PSLOT = PCAP / MT;             // piece slots per thread when the piece -> block map is built
 static_assert(PCAP % MT == 0, "piece map: PSLOT slots per thread");
+static_assert(MERGE_NT_MAX <= 1024u && PCAP < 2048u, "BI packs term slot (10 bits), payload bytes (11 bits) and first piece (11 bits)");
 
 struct __align__(16) MergeSmem {
     union {
@@ -226,8 +227,7 @@ struct __align__(16) MergeSmem {
             uint32_t PX[PCAP];              // exclusive prefix of the pieces' gap sums
             uint16_t PJ[PCAP];              // block (thread of the chunk) that owns each piece
             const uint8_t *BP[MT];          // per block: its payload
-            uint32_t BF[MT], BI[MT];        // per block: first doc; term slot | payload bytes << 16
-            uint16_t PB[MT + 2u];           // per block: its first piece
+            uint32_t BF[MT], BI[MT];        // per block: first doc; term slot | payload bytes << 10 | first piece << 21
         } d;
         struct {                            // while a decoded tile is sorted
             uint2 TT[MERGE_NT_MAX];         // per term of a batch: {smallest doc, float bits of buckets per doc}
@@ -253,7 +253,7 @@ struct __align__(16) MergeSmem {
     uint32_t pq_tile[MERGE_PQ], pq_cnt[MERGE_PQ];
     unsigned long long pq_slot[MERGE_PQ];
     unsigned long long pq_off;              // output offset of the queue's first tile
-    uint32_t stk[72][2];                    // bisection stack of doc ranges
+    uint32_t stk[36][2];                    // bisection stack of doc ranges (<= 32 levels, two pushes per pop)
 };
 
 // block-wide exclusive scan of one value per thread (MT threads); returns exclusive prefix, total in *tot
@@ -615,8 +615,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                 if (ok) {
                     sm.x.d.BF[tid] = first;
                     sm.x.d.BP[tid] = bp;
-                    sm.x.d.BI[tid] = ti | (len << 16);
-                    sm.x.d.PB[tid] = (uint16_t)pex;
+                    sm.x.d.BI[tid] = ti | (len << 10) | (pex << 21);
                     if (np) sm.x.d.PJ[pex] = (uint16_t)(tid + 1);     // marks the block's first piece
                     if ((uint32_t)tid == nchunk - 1u) sm.tp = pex + np;
                 }
@@ -661,8 +660,8 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     if (pv) {
                         jb = (uint32_t)sm.x.d.PJ[pc] - 1u;
                         bi = sm.x.d.BI[jb];
-                        const uint32_t off = 16u * (pc - (uint32_t)sm.x.d.PB[jb]);
-                        const uint32_t rem = (bi >> 16) - off;                 // payload bytes from my first one on (>= 1)
+                        const uint32_t off = 16u * (pc - (bi >> 21));
+                        const uint32_t rem = ((bi >> 10) & 0x7FFu) - off;                 // payload bytes from my first one on (>= 1)
                         const uint8_t *pp = sm.x.d.BP[jb] + off;
                         const uint4 w4 = gload16(pp);                          // (segments carry 16 bytes of padding)
                         const uint32_t prev = off ? gload4(pp - 4) : 0u;
@@ -694,7 +693,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     carry += tots;
                     if (pv) sm.x.d.PX[pc] = pex2;
                     lds_barrier();
-                    const uint32_t base = pv ? sm.x.d.BF[jb] + pex2 - sm.x.d.PX[sm.x.d.PB[jb]] : 0u;
+                    const uint32_t base = pv ? sm.x.d.BF[jb] + pex2 - sm.x.d.PX[bi >> 21] : 0u;
                     if (BM) {
                         if (pv) {
                             const uint32_t rb = base - lo32, span = hi - lo32;
@@ -721,7 +720,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                             wb = wave_bcast(wb, 0);
                             uint32_t pos = wb + incl - c;
                             if (wb + wtot <= MCAP) {
-                                const uint16_t tg = (uint16_t)(bi & 0xFFFFu);
+                                const uint16_t tg = (uint16_t)(bi & 0x3FFu);
 #pragma unroll
                                 for (int i = 0; i < 16; i++) {
                                     if ((tmask >> i) & 1u) {

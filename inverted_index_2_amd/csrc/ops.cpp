@@ -178,7 +178,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.tile_off = d_tile_off;
     p.direct = (postings_ub <= out_cap && ctx->opt_merge_direct) ? 1u : 0u;
     if (p.direct) HIP_TRY(ctx, hipMemsetAsync(d_tile_off, 0xFF, nt1 * sizeof(uint64_t), st));      // all-ones: "offset not known yet"
-    HIP_TRY(ctx, launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * 2u, st));
+    HIP_TRY(ctx, launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * (1024u / MERGE_THREADS), st));
     if (!p.direct) {
         HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
         HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
