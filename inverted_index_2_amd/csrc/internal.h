@@ -327,7 +327,8 @@ struct MergeParams {
     const uint32_t *n_tiles_dev;  // = term_tile + T
     // per tile
     uint4 *desc;                  // {t0, t1 | flags, dlo, dhi}
-    uint2 *runs;                  // [n_tiles * k] block range of list (s, t0) that overlaps the tile's doc range
+    uint4 *cut0;                  // [n_tiles * k] where list s's part of the tile begins: {block | inside, payload byte, doc before, -} (merge.hip: cut_for)
+    uint2 *cut1;                  // [n_tiles * k] ... and where it ends: {block | inside, payload byte}
     uint32_t *term_alloc;         // [T] bump allocator inside a large term's parking region (zeroed by the host)
     uint32_t *tmp;                // parked survivors
     uint32_t *tile_count;         // [n_tiles_ub+1] survivors per tile (zeroed by the host)

@@ -41,6 +41,15 @@ constexpr uint32_t MERGE_PQ = 8;                  // parked tiles a workgroup ma
 constexpr uint32_t SPIN_LIMIT = 4000000;          // bounded waits (each ~1.5 us: seconds in all): a bug must not hang the GPU
 static_assert(MCAP % MT == 0 && EPT * 4u <= 64u && (MCAP / 2u) % MT == 0, "sort passes: EPT elements and EPT / 2 counter words per thread");
 
+// payload bytes live in global memory: say so (a pointer that went through LDS would be loaded with flat instructions)
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ uint4 gload16(const uint8_t *p) {
+    const u32x4_unaligned v = *(const __attribute__((address_space(1))) u32x4_unaligned *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t gload4(const uint8_t *p) { return *(const __attribute__((address_space(1))) u32_unaligned *)p; }
+
 // ---- plan ----------------------------------------------------------------------------------
 // per term: input postings, doc range, longest list, and how it will be merged
 __global__ __launch_bounds__(256) void k_mp_terms(const MergeSegs *__restrict__ ms, MergeParams p) {
@@ -197,15 +206,164 @@ __device__ __forceinline__ uint2 blocks_of_range(const ii2_skip *__restrict__ sk
     return make_uint2(a > b_lo ? a - 1u : b_lo, b1);
 }
 
-// runs[tile * k + s]: the blocks of list (s, t0) a range tile has to decode (tiles that take whole lists read blk_off)
-__global__ void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams p) {
+// Where a doc range begins inside a list: the CUT before the first posting >= x of the list that owns the segment's blocks
+// [b_lo, b_hi).  {block | CUT_INSIDE, payload byte, doc before}: without CUT_INSIDE the cut is in front of that block (or at the
+// list's end, block == b_hi); with it the cut is inside the block, in front of the gap at `payload byte` (absolute offset in
+// the segment's payload), and `doc before` is the posting that gap is added to.  Found in the skip table and then by walking
+// the one block that straddles x - once, here, so that the tiles on both sides of x decode only their own part of it (a
+// range tile holds less than one block per list: decoding the straddling blocks whole was more than half of its decode work).
+constexpr uint32_t CUT_INSIDE = 1u << 31;
+
+// cut0[tile * k + s] / cut1[tile * k + s]: where list s's part of the tile begins and ends (tiles that take whole lists: the
+// lists' first block and the block after their last).  A tile's end is the next tile's beginning, so the cut at a tile's lower
+// bound is computed once and handed to the tile(s) before it as their end.  A thread per (tile, list) finds the block that
+// straddles the bound in the skip table; the walks through those blocks are then done by the wave together, two at a time:
+// 32 lanes per block, 16 payload bytes per lane, all pieces of a block in one round of loads (a thread walking its block
+// alone is a chain of dependent loads: ~1 ms on C3 against 0.1 ms for everything else the plan does).
+__global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams p) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)*p.n_tiles_dev * p.k) return;
-    const uint32_t tile = (uint32_t)(i / p.k), s = (uint32_t)(i % p.k);
-    const uint4 td = p.desc[tile];
-    if (td.z == 0u && td.w == 0xFFFFFFFFu) return;            // whole lists: nothing to search
+    const int l = lane_id();
+    const uint32_t hl = (uint32_t)l & 31u, half = (uint32_t)l >> 5;
+    const uint64_t n_pairs = (uint64_t)*p.n_tiles_dev * p.k;
+    const bool live = i < n_pairs;                              // (no early exit: the wave works together below)
+    const uint32_t tile = live ? (uint32_t)(i / p.k) : 0u, s = live ? (uint32_t)(i % p.k) : 0u;
+    const uint4 td = live ? p.desc[tile] : make_uint4(0u, 0u, 1u, 0u);
+    const bool nonempty = live && td.z <= td.w;                 // (an empty range: the tile decodes nothing)
     const SegView &sv = ms->segs[s];
-    p.runs[i] = blocks_of_range(sv.skip, sv.blk_off[td.x], sv.blk_off[td.x + 1u], td.z, td.w);
+    const uint32_t b_lo = live ? sv.blk_off[td.x] : 0u, b_hi = live ? sv.blk_off[td.y & 0x3FFFFFFFu] : 0u;
+    const uint32_t x = td.z;
+    uint4 c0 = make_uint4(b_lo, 0u, 0u, 0u);
+    // ---- the block that straddles x (if any): the last one that starts below x
+    bool walk = false;
+    uint32_t a = b_lo, start = 0, len = 0, first = 0;
+    if (nonempty && x != 0u && b_hi > b_lo && !(p.pad0 & 32u)) {
+        const ii2_skip *__restrict__ skip = sv.skip;
+        const uint32_t f0 = skip[b_lo].first_doc;
+        if (x > f0) {
+            auto get = [&](uint32_t j) { return skip[j].first_doc; };
+            a = upper_bound_guess(get, b_lo, b_hi, x - 1u, f0, skip[b_hi - 1u].first_doc);      // first block that starts at or after x (> b_lo)
+            const ii2_skip e0 = skip[a - 1u];
+            start = e0.byte_off;
+            len = skip[a].byte_off - start;
+            if (len > 1280u) len = 1280u;                       // (a block holds <= 256 postings of <= 5 bytes; imported segments are validated)
+            first = e0.first_doc;
+            c0 = make_uint4(a, 0u, 0u, 0u);                      // unless the walk finds x inside the block
+            walk = len != 0u && !(p.pad0 & 16u);
+        }
+    }
+    const unsigned long long pay64 = (unsigned long long)(uintptr_t)sv.payload;
+    // every lane asks for its own block's cache lines now: the shared walks below then find them in the L2 (one round of
+    // memory latency for the whole wave instead of one per pair of blocks)
+    if (walk) {
+        uint32_t touch = 0;
+        for (uint32_t o = 0; o < len; o += 128u) touch |= gload4(sv.payload + start + o);
+        asm volatile("" ::"v"(touch));
+    }
+    for (unsigned long long need = __ballot(walk); need != 0ull;) {
+        // the two lowest lanes that need a walk: the lower half of the wave takes the first, the upper half the second
+        const int s0 = __ffsll((long long)need) - 1;
+        need &= need - 1ull;
+        const bool two = need != 0ull;
+        const int s1 = two ? __ffsll((long long)need) - 1 : s0;
+        if (two) need &= need - 1ull;
+        const int src = half ? s1 : s0;
+        const bool mine = half == 0u || two;                    // my half has a block to walk
+        const uint32_t w_start = (uint32_t)__shfl((int)start, src, 64), w_len = (uint32_t)__shfl((int)len, src, 64);
+        const uint32_t w_first = (uint32_t)__shfl((int)first, src, 64), w_x = (uint32_t)__shfl((int)x, src, 64), w_a = (uint32_t)__shfl((int)a, src, 64);
+        const uint8_t *w_pay = (const uint8_t *)(uintptr_t)(unsigned long long)__shfl((long long)pay64, src, 64);
+        const uint32_t np = mine ? (w_len + 15u) >> 4 : 0u;
+        uint32_t docbase = w_first;                             // sum of all gap bits before the step's first piece
+        bool open = mine;
+        uint4 res = make_uint4(w_a, 0u, 0u, 0u);
+        for (uint32_t pb = 0; __ballot(open && pb < np) != 0ull; pb += 32u) {       // (wave-uniform: a half that is done idles)
+            const uint32_t pc = pb + hl;
+            const bool pv = open && pc < np;
+            uint32_t val[16], tmask = 0, w[4] = {0, 0, 0, 0}, prev = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) val[q] = 0;
+            const uint32_t off = 16u * pc;
+            if (pv) {
+                const uint32_t rem = w_len - off;
+                const uint8_t *pp = w_pay + w_start + off;
+                const uint4 w4 = gload16(pp);                    // (segments carry 16 bytes of padding)
+                prev = off ? gload4(pp - 4) : 0u;
+                w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+                if (rem < 16u) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t nj = rem > 4u * j ? (rem - 4u * j < 4u ? rem - 4u * j : 4u) : 0u;
+                        w[j] &= nj >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nj)) - 1u);
+                    }
+                }
+                uint32_t sh = 7u * ((uint32_t)__clz((int)~(prev | 0x7F7F7F7Fu)) >> 3);      // continuation bytes pending before my first byte
+                uint32_t sum = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t c7 = __builtin_amdgcn_ubfe(w[q >> 2], 8 * (q & 3), 7);
+                    const uint32_t cm = (uint32_t)__builtin_amdgcn_sbfe((int)w[q >> 2], 8 * (q & 3) + 7, 1);
+                    sum += c7 << (sh & 31u);
+                    sh = (sh + 7u) & cm;
+                    tmask |= ~cm & (1u << q);
+                    val[q] = sum;
+                }
+                if (rem < 16u) tmask &= (1u << rem) - 1u;
+            }
+            uint32_t incl = val[15];
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 32); if (hl >= (uint32_t)d) incl += y; }
+            const uint32_t base = docbase + incl - val[15];
+            uint32_t cm = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) cm |= (base + val[q] >= w_x) ? 1u << q : 0u;
+            cm &= tmask;
+            const uint32_t hits = (uint32_t)(__ballot(pv && cm != 0u) >> (32u * half));
+            uint4 r = make_uint4(0, 0, 0, 0);
+            if (pv && cm != 0u) {
+                // the first posting >= x ends at byte q of my piece: its varint back to front (the byte before its first one ends
+                // the posting before, or is the 0 in front of the block's first byte), most significant group first
+                const int q = __ffs((int)cm) - 1;
+                uint32_t gap = 0, nbytes = 0;
+                for (int j = q; j > q - 5; j--) {
+                    const uint32_t wj = j < 0 ? prev : j < 4 ? w[0] : j < 8 ? w[1] : j < 12 ? w[2] : w[3];
+                    const uint32_t c = (wj >> (8u * ((uint32_t)j & 3u))) & 0xFFu;
+                    if (j != q && !(c & 0x80u)) break;
+                    gap = (gap << 7) | (c & 0x7Fu);
+                    nbytes++;
+                }
+                uint32_t vq = val[0];
+#pragma unroll
+                for (int t = 1; t < 16; t++) vq = t == q ? val[t] : vq;
+                r = make_uint4((w_a - 1u) | CUT_INSIDE, w_start + off + (uint32_t)q + 1u - nbytes, base + vq - gap, 0u);
+            }
+            if (hits != 0u) {                                    // (uniform in the half)
+                const int hsrc = __ffs((int)hits) - 1;
+                res = make_uint4((uint32_t)__shfl((int)r.x, hsrc, 32), (uint32_t)__shfl((int)r.y, hsrc, 32), (uint32_t)__shfl((int)r.z, hsrc, 32), 0u);
+                open = false;
+            }
+            docbase += (uint32_t)__shfl((int)incl, 31, 32);
+        }
+        // the halves' results go to the lanes whose blocks they walked
+        const uint32_t r0x = (uint32_t)__shfl((int)res.x, 0, 64), r0y = (uint32_t)__shfl((int)res.y, 0, 64), r0z = (uint32_t)__shfl((int)res.z, 0, 64);
+        const uint32_t r1x = (uint32_t)__shfl((int)res.x, 32, 64), r1y = (uint32_t)__shfl((int)res.y, 32, 64), r1z = (uint32_t)__shfl((int)res.z, 32, 64);
+        if (l == s0) c0 = make_uint4(r0x, r0y, r0z, 0u);
+        if (two && l == s1) c0 = make_uint4(r1x, r1y, r1z, 0u);
+    }
+    if (!nonempty) return;
+    if (x != 0u) {
+        // the tiles of the same term right before this one: the empty ones in between and the one that ends where I begin
+        for (uint32_t j = tile; j-- > 0u;) {
+            const uint4 pd = p.desc[j];
+            if (pd.x != td.x || !(pd.y & MERGE_DESC_LARGE)) break;
+            if (pd.z > pd.w) continue;
+            p.cut1[(uint64_t)j * p.k + s] = make_uint2(c0.x, c0.y);
+            break;
+        }
+    }
+    p.cut0[i] = c0;
+    // the last tile of its term(s) ends where the lists end (a bitmap term's last window stops short of 2^32, and nothing follows it)
+    bool last = tile + 1u == *p.n_tiles_dev;
+    if (!last) { const uint4 nd = p.desc[tile + 1u]; last = nd.x != td.x || !(nd.y & MERGE_DESC_LARGE) || !(td.y & MERGE_DESC_LARGE); }
+    if (last) p.cut1[i] = make_uint2(b_hi, 0u);
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------
@@ -292,15 +450,6 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t x) {
     y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = y > x ? y : x;
     return x;
 }
-
-// payload bytes live in global memory: say so (a pointer that went through LDS would be loaded with flat instructions)
-typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
-typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-__device__ __forceinline__ uint4 gload16(const uint8_t *p) {
-    const u32x4_unaligned v = *(const __attribute__((address_space(1))) u32x4_unaligned *)p;
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ uint32_t gload4(const uint8_t *p) { return *(const __attribute__((address_space(1))) u32_unaligned *)p; }
 
 __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSegs *__restrict__ ms, MergeParams p) {
     __shared__ MergeSmem sm;
@@ -443,20 +592,22 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
     // when the descriptor is there) its terms' plan entries
     uint32_t tile_nx = sm.tk;
     uint4 td_nx = tile_nx < n_tiles ? p.desc[tile_nx] : make_uint4(0, 0, 1, 0);
-    uint2 rn_nx = (tile_nx < n_tiles && (uint32_t)tid < k) ? p.runs[(uint64_t)tile_nx * k + (uint32_t)tid] : make_uint2(0, 0);
-    uint2 bo_nx = make_uint2(0, 0);                // the same for a tile that takes whole lists: blk_off[t0], blk_off[t1]
-    if (tile_nx < n_tiles && (uint32_t)tid < k) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
+    uint4 c0_nx = make_uint4(0, 0, 0, 0);          // threads 0 .. k-1: where my list's part of the tile begins ...
+    uint2 c1_nx = make_uint2(0, 0);                // ... and ends (plan: k_merge_tile_runs)
+    auto fetch_cuts = [&]() {
+        if (tile_nx < n_tiles && (uint32_t)tid < k) { c0_nx = p.cut0[(uint64_t)tile_nx * k + (uint32_t)tid]; c1_nx = p.cut1[(uint64_t)tile_nx * k + (uint32_t)tid]; }
+    };
+    fetch_cuts();
     for (uint32_t tile = tile_nx; tile < n_tiles; tile = tile_nx) {
         const uint4 td = td_nx;
-        const uint2 rn = rn_nx, bo = bo_nx;
-        bool nx_known = false;                      // tile_nx / td_nx / rn_nx hold the next tile
+        const uint4 c0 = c0_nx;
+        const uint2 c1 = c1_nx;
+        bool nx_known = false;                      // tile_nx / td_nx / c0_nx / c1_nx hold the next tile
         if (!p.direct) {                            // static order: the next tile is known now
             tile_nx = tile + n_workers;
             nx_known = true;
-            if (tile_nx < n_tiles) {
-                td_nx = p.desc[tile_nx];
-                if ((uint32_t)tid < k) rn_nx = p.runs[(uint64_t)tile_nx * k + (uint32_t)tid];
-            }
+            if (tile_nx < n_tiles) td_nx = p.desc[tile_nx];
+            fetch_cuts();
         }
         // The next ticket is claimed now (its latency hides behind this tile) only while few parked tiles wait: a workgroup
         // that may have to wait for room in its queue must not own a tile it has not started - the scanner's frontier
@@ -478,7 +629,6 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
         const uint32_t pf_tn = p.tn[my_t], pf_mn = p.tmin[my_t], pf_mx = p.tmax[my_t];
         const uint32_t pf_mn0 = p.tmin[t0], pf_mx0 = p.tmax[t0];
         const bool large = (td.y & MERGE_DESC_LARGE) != 0u, bm_tile = (td.y & MERGE_DESC_BITMAP) != 0u;
-        const bool whole = td.z == 0u && td.w == 0xFFFFFFFFu;
         // Work list of the tile: doc ranges of cur_t0 .. cur_t0 + cur_nt, handled one after the other in doc order, their
         // survivors appended at dst + acc.  Normally one range (the tile's).  A range that does not fit LDS or whose ids are
         // clustered is bisected until its pieces fit the bitmap (exact for any input); a batch whose sort fails is redone
@@ -489,7 +639,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
         uint32_t acc = 0;
         uint32_t cur_t0 = t0, cur_nt = t1 - t0;
         bool cur_batch = !large;
-        uint32_t root_mode = large ? (whole ? 0u : 1u) : 0u;      // how the runs of a root range are found (see below)
+        uint32_t root_mode = 1u;                   // how the runs of a root range are found (see below)
         bool root = true;
         uint32_t fb_next = 0, fb_end = 0, fb_acc0 = 0;
         bool fb_active = false;
@@ -545,16 +695,20 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             lds_barrier();
             const uint32_t lo = sm.stk[sp - 1u][0], hi = sm.stk[sp - 1u][1];
             sp--;
-            // ---- the runs of [lo, hi]: which blocks of every list have to be decoded.  mode 0: the whole lists of the
-            // terms; 1: the tile's range, searched by the plan; 2: a sub-range of the root (searched here)
+            // ---- the runs of [lo, hi]: which blocks of every list have to be decoded.  mode 1: the tile's own range, between
+            // the cuts the plan made (the first and the last block of a run may be partial); 0: the whole lists of a term (a
+            // batch redone term by term); 2: a sub-range of the root (searched here: whole blocks, ids outside are dropped)
+            const bool cutmode = root && root_mode == 1u;
             {
                 const uint32_t mode = root ? root_mode : 2u;
                 lds_barrier();
                 if ((uint32_t)tid < k) {
                     uint2 r;
-                    if (mode == 0u) r = (cur_t0 == t0 && cur_nt == t1 - t0) ? bo : make_uint2(my_bo[cur_t0], my_bo[cur_t0 + cur_nt]);
-                    else if (mode == 1u) r = rn;
-                    else r = blocks_of_range(sm.skp[tid], sm.RR0[tid], sm.RR1[tid], lo, hi);
+                    if (mode == 0u) r = make_uint2(my_bo[cur_t0], my_bo[cur_t0 + cur_nt]);
+                    else if (mode == 1u) {
+                        const uint32_t bs = c0.x & ~CUT_INSIDE, be = (c1.x & ~CUT_INSIDE) + (c1.x >> 31);
+                        r = make_uint2(bs, be > bs ? be : bs);
+                    } else r = blocks_of_range(sm.skp[tid], sm.RR0[tid], sm.RR1[tid], lo, hi);
                     if (mode != 2u) { sm.RR0[tid] = r.x; sm.RR1[tid] = r.y; }
                     sm.R0[tid] = r.x;
                     sm.RB[tid] = r.y - r.x;            // (count; scanned below)
@@ -575,7 +729,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             if (NB == 0u || (xskip & 8u)) continue;
             const bool BM = (was_root && bm_tile) || (!was_root && hi - (lo & ~31u) < BMW * 32u);
             const uint32_t lo32 = lo & ~31u;
-            const bool filter = !(lo == 0u && hi == 0xFFFFFFFFu);
+            const bool filter = !cutmode && !(lo == 0u && hi == 0xFFFFFFFFu);       // (between cuts every decoded id is the tile's)
             const uint32_t bm_nw = BM ? ((hi - lo32) >> 5) + 1u : 0u;                      // <= BMW
             if (BM) {
                 for (uint32_t i = 4u * (uint32_t)tid; i < bm_nw; i += 4u * MT) *reinterpret_cast<uint4 *>(&sm.u.bm[i]) = make_uint4(0, 0, 0, 0);
@@ -592,6 +746,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                 const uint32_t g = g0 + (uint32_t)tid;
                 const bool valid = g < NB;
                 uint32_t np = 0, first = 0, ti = 0, len = 0;
+                bool has_first = true;                // the block's first posting (the one in its skip entry) is the tile's
                 const uint8_t *bp = nullptr;
                 if (valid) {
                     uint32_t a = 0, e = k;            // RB[a] <= g < RB[e]
@@ -599,11 +754,22 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     const uint32_t b = sm.R0[a] + (g - sm.RB[a]);
                     const ii2_skip *sk = sm.skp[a];
                     const ii2_skip e0 = sk[b];
+                    uint32_t from = e0.byte_off, to = sk[b + 1u].byte_off;
                     first = e0.first_doc;
-                    len = sk[b + 1u].byte_off - e0.byte_off;
+                    if (cutmode) {                    // the run's first / last block may be cut (all four loads are in flight together)
+                        if (g == sm.RB[a]) {
+                            const uint4 cs = p.cut0[(uint64_t)tile * k + a];
+                            if (cs.x & CUT_INSIDE) { from = cs.y; first = cs.z; has_first = false; }
+                        }
+                        if (g + 1u == sm.RB[a + 1u]) {
+                            const uint2 ce = p.cut1[(uint64_t)tile * k + a];
+                            if (ce.x & CUT_INSIDE) to = ce.y;
+                        }
+                    }
+                    len = to > from ? to - from : 0u;
                     if (len > 1280u) len = 1280u;     // (a block holds <= 256 postings of <= 5 bytes; imported segments are validated)
                     np = (len + 15u) >> 4;
-                    bp = sm.pay[a] + e0.byte_off;
+                    bp = sm.pay[a] + from;
                     if (cur_batch) { ti = sm.bls[a][b] - sm.lbase[a] - cur_t0; ti = ti < cur_nt ? ti : cur_nt - 1u; }
                 }
 #pragma unroll
@@ -620,7 +786,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     if ((uint32_t)tid == nchunk - 1u) sm.tp = pex + np;
                 }
                 {   // the blocks' first postings (their ids are in the skip entries)
-                    const bool in = ok && first >= lo && first <= hi;
+                    const bool in = ok && has_first && first >= lo && first <= hi;
                     if (BM) {
                         if (in) atomicOr(&sm.u.bm[(first - lo32) >> 5], 1u << (first & 31u));
                     } else {
@@ -744,12 +910,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     lds_barrier();
                     tile_nx = sm.tk;
                     nx_known = true;
-                    if (tile_nx < n_tiles) {
-                        td_nx = p.desc[tile_nx];
-                        if ((uint32_t)tid < k) rn_nx = p.runs[(uint64_t)tile_nx * k + (uint32_t)tid];
-                    }
+                    if (tile_nx < n_tiles) td_nx = p.desc[tile_nx];
+                    fetch_cuts();
                 }
-                if ((uint32_t)tid < k && tile_nx < n_tiles) bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]);
             }
 
             if (BM) {
@@ -1008,10 +1171,8 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             lds_barrier();
             tile_nx = sm.tk;
             nx_known = true;
-            if (tile_nx < n_tiles) {
-                td_nx = p.desc[tile_nx];
-                if ((uint32_t)tid < k) { rn_nx = p.runs[(uint64_t)tile_nx * k + (uint32_t)tid]; bo_nx = make_uint2(my_bo[td_nx.x], my_bo[td_nx.y & 0x3FFFFFFFu]); }
-            }
+            if (tile_nx < n_tiles) td_nx = p.desc[tile_nx];
+            fetch_cuts();
         };
         if (!nx_known && claim_early) {             // (a tile without a root range to decode: the early ticket was not handed round yet)
             if (tid == 0) sm.tk = tk_next;

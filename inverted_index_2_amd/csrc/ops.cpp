@@ -78,7 +78,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.small_max = (cap * 5u) / 14u;         // 2560
     p.batch_q = cap - p.small_max;          // 4608
     p.wmin = (cap + MERGE_NT_MAX - 1u) / MERGE_NT_MAX;
-    p.range_target = ctx->opt_merge_large_tile > 0 ? std::min<uint32_t>((uint32_t)ctx->opt_merge_large_tile, cap) : (cap / 7u) * 6u;
+    p.range_target = ctx->opt_merge_large_tile > 0 ? std::min<uint32_t>((uint32_t)ctx->opt_merge_large_tile, cap) : (cap / 20u) * 19u;
     p.bitmap_tiles = ctx->opt_merge_bitmap ? 1u : 0u;
     p.bitmap_sparsity = ctx->opt_merge_bitmap > 1 ? (uint32_t)std::min<int64_t>(ctx->opt_merge_bitmap, 4096) : 80u;
     // upper bound of the tile count (the exact one is computed on the device and stays there): a large term has more than
@@ -129,7 +129,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const size_t nt1 = (size_t)p.n_tiles_ub + 1;
     const size_t scan_t = scan_temp_bytes(nt1);
     const size_t aux_need = 256 + align_up(nt1 * sizeof(uint32_t)) + align_up(n1 * sizeof(uint32_t)) + align_up(nt1 * 16) + 2 * align_up(nt1 * sizeof(uint64_t)) + scan_t +
-                            align_up(nt1 * k * sizeof(uint2)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
+                            align_up(nt1 * k * 16) + align_up(nt1 * k * sizeof(uint2)) + align_up((postings_ub + 64) * sizeof(uint32_t)) + 4096;
     if (!grow(ctx->aux, ctx->aux_cap, aux_need)) return fail(ctx, II2_ENOMEM, "merge scratch allocation failed");
     uint8_t *ac = ctx->aux;
     p.sync = (MergeSync *)carve<uint8_t>(ac, sizeof(MergeSync));      // (first in the allocation: zeroed together with the two arrays after it by one memset)
@@ -140,7 +140,8 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     uint64_t *d_tile_off = carve<uint64_t>(ac, nt1);
     void *d_scan_t = carve<uint8_t>(ac, scan_t);
     p.desc = (uint4 *)carve<uint8_t>(ac, nt1 * 16);
-    p.runs = carve<uint2>(ac, nt1 * k);
+    p.cut0 = (uint4 *)carve<uint8_t>(ac, nt1 * k * 16);
+    p.cut1 = carve<uint2>(ac, nt1 * k);
     p.tmp = carve<uint32_t>(ac, postings_ub + 64);
 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_segs, hs, sizeof(MergeSegs), hipMemcpyHostToDevice, st));
@@ -155,6 +156,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.term_tile = d_tt;
     p.n_tiles_dev = d_tt + T;                   // term_tile[T] = number of tiles
     p.npre = d_npre;
+    p.pad0 = (uint32_t)ctx->opt_merge_skip;
     HIP_TRY(ctx, launch_merge_tile_desc(d_ms, p, st));
     HIP_TRY(ctx, launch_merge_tile_runs(d_ms, p, st));
     p.out_counts = d_cnt;
@@ -162,7 +164,6 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.out_cap = out_cap;
     p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
     p.debug = nullptr;
-    p.pad0 = (uint32_t)ctx->opt_merge_skip;
     if (ctx->opt_debug_stamps) {
         if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
