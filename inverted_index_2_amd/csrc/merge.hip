@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
 
 // ---- the tile kernel ----------------------------------------------------------------------
 constexpr uint32_t PSLOT = PCAP / MT;             // piece slots per thread when the piece -> block map is built
-static_assert(PCAP % MT == 0, "piece map: PSLOT slots per thread");
+static_assert(PCAP % MT == 0 && BMW % (2u * MT) == 0, "piece map: PSLOT slots per thread; bitmap tiles: BMW / MT words per thread");
 static_assert(MERGE_NT_MAX <= 1024u && PCAP < 2048u, "BI packs term slot (10 bits), payload bytes (11 bits) and first piece (11 bits)");
 
 struct __align__(16) MergeSmem {
@@ -924,38 +924,47 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     if ((hi & 31u) != 31u) bm[bm_nw - 1u] &= (2u << (hi & 31u)) - 1u;
                 }
                 if (p.tomb) {
+                    // all of a thread's tombstone words are requested before the first is used (one round of memory latency per tile)
+                    constexpr uint32_t TW = BMW / MT / 2u;      // (two rounds: all at once would spill registers)
                     const uint32_t twb = lo32 >> 5;
-                    for (uint32_t i0 = (uint32_t)tid; i0 < bm_nw; i0 += 4u * MT) {
-                        uint32_t t4[4];
+#pragma unroll 1
+                    for (uint32_t h = 0; h < 2u; h++) {
+                        uint32_t tw[TW];
 #pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++) {
-                            const uint32_t i = i0 + j * MT;
-                            t4[j] = (i < bm_nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
+                        for (uint32_t j = 0; j < TW; j++) {
+                            const uint32_t i = (uint32_t)tid + (h * TW + j) * MT;
+                            tw[j] = (i < bm_nw && twb + i < p.tomb_nwords) ? p.tomb[twb + i] : 0u;
                         }
 #pragma unroll
-                        for (uint32_t j = 0; j < 4u; j++)
-                            if (t4[j]) bm[i0 + j * MT] &= ~t4[j];
+                        for (uint32_t j = 0; j < TW; j++)
+                            if (tw[j]) bm[(uint32_t)tid + (h * TW + j) * MT] &= ~tw[j];
                     }
                 }
                 lds_barrier();
-                // consecutive words per thread, as few as cover the range
-                const uint32_t wpt = (bm_nw + MT - 1u) / MT;
-                const uint32_t w0 = wpt * (uint32_t)tid;
-                const uint32_t w1 = w0 + wpt < bm_nw ? w0 + wpt : bm_nw;
+                // a wave takes a stretch of consecutive words and goes through it 64 words at a time, a word per lane: lanes
+                // next to each other write ids next to each other (a thread that extracts a stretch of its own writes 4 bytes
+                // per lane to 64 different cache lines with every store)
+                const uint32_t wpw = ((bm_nw + 64u * MW - 1u) / (64u * MW)) * 64u;      // words per wave (a multiple of 64)
+                const uint32_t ww0 = wpw * (uint32_t)wv < bm_nw ? wpw * (uint32_t)wv : bm_nw;
+                const uint32_t ww1 = ww0 + wpw < bm_nw ? ww0 + wpw : bm_nw;
                 uint32_t cnt = 0;
-#pragma unroll 1
-                for (uint32_t w = w0; w < w1; w++) cnt += (uint32_t)__popc(bm[w]);
+                for (uint32_t w = ww0 + (uint32_t)l; w < ww1; w += 64u) cnt += (uint32_t)__popc(bm[w]);
                 uint32_t tot;
-                uint32_t pos = block_excl_scan(cnt, sm.wsum, &tot);
+                const uint32_t tpos = block_excl_scan(cnt, sm.wsum, &tot);
+                uint32_t off = wave_bcast(tpos, 0);               // ids before my wave's stretch
                 uint32_t *out = alloc(tot);
-#pragma unroll 1
-                for (uint32_t w = w0; w < w1; w++) {
-                    uint32_t x = bm[w];
+                for (uint32_t r = ww0; r < ww1; r += 64u) {
+                    const uint32_t w = r + (uint32_t)l;
+                    uint32_t x = w < ww1 ? bm[w] : 0u;
+                    const uint32_t c = (uint32_t)__popc(x);
+                    const uint32_t incl = wave_incl_scan(c);
+                    uint32_t q = off + incl - c;
                     const uint32_t base = lo32 + 32u * w;
                     while (x) {
-                        out[pos++] = base + (uint32_t)__ffs((int)x) - 1u;
+                        out[q++] = base + (uint32_t)__ffs((int)x) - 1u;
                         x &= x - 1u;
                     }
+                    off += wave_bcast(incl, 63);
                 }
                 acc += tot;
                 II2_STAMP(6)
