@@ -37,7 +37,7 @@ constexpr uint32_t EPT = MCAP / MT;               // elements per thread in the 
 constexpr uint32_t PCAP = 768;                   // 16-byte payload pieces decoded per chunk of blocks
 constexpr uint32_t BKT_LIMIT = 15;                // fullest bucket the bucket sort accepts (slot numbers are 4 bits)
 constexpr uint32_t BMW = MERGE_BM_WORDS;
-constexpr uint32_t MERGE_PQ = 8;                  // parked tiles a workgroup may have waiting for their output offset
+constexpr uint32_t MERGE_PQ = 16;                 // parked tiles a workgroup may have waiting for their output offset
 constexpr uint32_t SPIN_LIMIT = 4000000;          // bounded waits (each ~1.5 us: seconds in all): a bug must not hang the GPU
 static_assert(MCAP % MT == 0 && EPT * 4u <= 64u && (MCAP / 2u) % MT == 0, "sort passes: EPT elements and EPT / 2 counter words per thread");
 

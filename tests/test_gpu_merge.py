@@ -270,3 +270,35 @@ def test_output_too_small_writes_nothing(ctx):
     out_vals2 = ctx.empty(n_out)                                  # exactly enough: succeeds
     g_off, g_vals, st = ctx.merge(segs, None, out_off, out_vals2)
     assert np.array_equal(g_off.download(), w_off) and np.array_equal(g_vals.download(n_out), w_vals)
+
+
+@pytest.mark.parametrize("k,tile", [(3, 300), (16, 700), (64, 3000)])
+def test_range_tiles_cut_blocks_at_any_byte(ctx, k, tile):
+    """Round 3: a range tile decodes only its own part of a block that straddles its doc bounds (merge.hip: cuts).  Small
+    tiles put a cut into nearly every block; the lists mix 1- to 5-byte gaps, repeat ids inside a list (gap 0) and
+    share ids across lists, so cuts fall before, inside and after multi-byte varints and runs of equal ids."""
+    rng = np.random.default_rng(900 + k)
+    ctx.set_option("merge.large_tile", tile)
+    ctx.set_option("merge.bitmap_tiles", 0)
+    try:
+        offs, vals = [], []
+        shared = np.sort(rng.integers(0, 1 << 31, 4000).astype(np.uint32))
+        for s in range(k):
+            lists = []
+            for t in range(3):
+                n = [20_000, 0, 6_000][t] // (1 + s % 3)
+                widths = rng.choice([7, 14, 21, 28], n, p=[0.5, 0.3, 0.15, 0.05])
+                gaps = (rng.integers(0, 1 << 30, n) % (1 << widths)).astype(np.uint64)
+                gaps[rng.random(n) < 0.05] = 0                                  # the same id twice in one list
+                ids = np.cumsum(gaps)
+                ids = ids[ids < (1 << 32) - 1].astype(np.uint32)
+                if t == 0: ids = np.sort(np.concatenate([ids, shared[rng.random(shared.size) < 0.5]]))
+                lists.append(ids)
+            offs.append(np.concatenate([[0], np.cumsum([x.size for x in lists])]).astype(np.uint64))
+            vals.append(np.concatenate(lists).astype(np.uint32))
+        removed = np.unique(np.concatenate([shared[::7], rng.integers(0, 1 << 31, 5000).astype(np.uint32)]))
+        st = _check_merge(ctx, offs, vals, removed=removed)
+        assert st.n_tiles > 20
+    finally:
+        ctx.set_option("merge.large_tile", 0)
+        ctx.set_option("merge.bitmap_tiles", 1)
