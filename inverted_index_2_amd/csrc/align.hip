@@ -470,12 +470,12 @@ int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a,
     void *d_tmp = cur;
     // one allocation for the view's four arrays
     uint32_t *d_blk_off = nullptr, *d_cnt = nullptr, *d_last = nullptr, *d_blk_list = nullptr;
-    if (hipMalloc((void **)&d_blk_off, (nu + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&d_cnt, (nu + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&d_last, (nu + 1) * sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&d_blk_list, (src->n_blocks + 1) * sizeof(uint32_t)) != hipSuccess) {
-        if (d_blk_off) (void)hipFree(d_blk_off);
-        if (d_cnt) (void)hipFree(d_cnt);
-        if (d_last) (void)hipFree(d_last);
-        if (d_blk_list) (void)hipFree(d_blk_list);
+    if (dm_alloc((void **)&d_blk_off, (nu + 1) * sizeof(uint32_t)) != hipSuccess || dm_alloc((void **)&d_cnt, (nu + 1) * sizeof(uint32_t)) != hipSuccess ||
+        dm_alloc((void **)&d_last, (nu + 1) * sizeof(uint32_t)) != hipSuccess || dm_alloc((void **)&d_blk_list, (src->n_blocks + 1) * sizeof(uint32_t)) != hipSuccess) {
+        dm_free(d_blk_off);
+        dm_free(d_cnt);
+        dm_free(d_last);
+        dm_free(d_blk_list);
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     }
     const int32_t *sel_row = a->d_sel + (size_t)s * nu;
@@ -491,7 +491,7 @@ int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a,
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
-        (void)hipFree(d_blk_off); (void)hipFree(d_cnt); (void)hipFree(d_last); (void)hipFree(d_blk_list);
+        dm_free(d_blk_off); dm_free(d_cnt); dm_free(d_last); dm_free(d_blk_list);
         ctx->err = std::string("ii2_seg_select_aligned: ") + hipGetErrorString(e);
         return II2_EHIP;
     }

@@ -143,6 +143,7 @@ int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
     if (!ctx) return II2_ENOMEM;
     ctx->device = device;
     ctx->cu_count = prop.multiProcessorCount;
+    dm_user(+1);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess) {
@@ -176,6 +177,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     for (auto *v : {&ctx->prof_events, &ctx->prof_pool})
         for (auto &pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    dm_user(-1);                 // the last context gives the cached segment arrays back (devmem.cpp)
     delete ctx;
 }
 
@@ -226,14 +228,15 @@ int ii2_copy_d2h(ii2_ctx *ctx, void *dst, const void *src, size_t bytes) {
 static void seg_release(ii2_seg *s) {
     if (!s) return;
     if (s->in_slab) { delete s; return; }       // the store's slab holds every array (ii2_merge_small)
-    if (s->d_blk_off) (void)hipFree(s->d_blk_off);
+    // (devmem.cpp: the arrays go back to the size-class cache; no driver call, no device-wide wait)
+    dm_free(s->d_blk_off);
     if (!s->store) {          // not yet handed to a store: still owned directly
-        if (s->d_skip) (void)hipFree(s->d_skip);
-        if (s->d_payload) (void)hipFree(s->d_payload);
+        dm_free(s->d_skip);
+        dm_free(s->d_payload);
     }
-    if (s->d_last_doc) (void)hipFree(s->d_last_doc);
-    if (s->d_cnt) (void)hipFree(s->d_cnt);
-    if (s->d_blk_list) (void)hipFree(s->d_blk_list);
+    dm_free(s->d_last_doc);
+    dm_free(s->d_cnt);
+    dm_free(s->d_blk_list);
     delete s;
 }
 
@@ -244,10 +247,10 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
         seg->store->d_skip = seg->d_skip;
         seg->store->d_payload = seg->d_payload;
     }
-    if (hipMalloc((void **)&seg->d_last_doc, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
+    if (dm_alloc((void **)&seg->d_last_doc, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
-    if (hipMalloc((void **)&seg->d_cnt, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&seg->d_blk_list, (seg->n_blocks + 1) * sizeof(uint32_t)) != hipSuccess)
+    if (dm_alloc((void **)&seg->d_cnt, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_blk_list, (seg->n_blocks + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemsetAsync(seg->d_blk_list, 0xFF, (seg->n_blocks + 1) * sizeof(uint32_t), ctx->stream));
     HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_cnt, seg->d_blk_list, seg->d_last_doc,
@@ -278,7 +281,7 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     seg->n_postings = n_postings;
     const uint64_t nb_bound = n_postings / II2_DV1_BLOCK + n_lists + 1;
     if (nb_bound >= (1ull << 31)) return fail(ctx, II2_ERANGE, "too many DV1 blocks for one segment");
-    if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
+    if (dm_alloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     // scratch comes out of the context's grow-only workspace (sized by the upper bound of the block count)
     const size_t tmpb = scan_temp_bytes((size_t)std::max<uint64_t>(n_lists + 1, nb_bound + 1));
@@ -296,7 +299,7 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint64_t nb = nb32;
     seg->n_blocks = nb;
-    if (hipMalloc((void **)&seg->d_skip, (nb + 1) * sizeof(ii2_skip)) != hipSuccess)
+    if (dm_alloc((void **)&seg->d_skip, (nb + 1) * sizeof(ii2_skip)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, launch_enc_block_sizes(d_post_off, seg->d_blk_off, n_lists, d_values, nb, d_sizes, seg->d_skip, st));
     HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_tmp, tmpb, d_sizes, d_boff, nb + 1, st));
@@ -305,7 +308,7 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (nbytes >= 0xFFFFFFF0ull) return fail(ctx, II2_ERANGE, "segment payload exceeds the 4 GiB DV1 limit; split the segment");
     seg->n_bytes = nbytes;
-    if (hipMalloc((void **)&seg->d_payload, nbytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    if (dm_alloc((void **)&seg->d_payload, nbytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + nbytes, 0, 16, st));
     HIP_TRY(ctx, launch_enc_write(d_post_off, seg->d_blk_off, n_lists, d_values, nb, d_boff, seg->d_skip,
                                   seg->d_payload, n_postings, st));
@@ -386,9 +389,9 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t
     seg->n_blocks = nb;
     seg->n_bytes = last.byte_off;
     if (seg->n_bytes && !payload) return fail(ctx, II2_EINVAL, "ii2_seg_import: payload is NULL");
-    if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&seg->d_skip, ((uint64_t)nb + 1) * sizeof(ii2_skip)) != hipSuccess ||
-        hipMalloc((void **)&seg->d_payload, seg->n_bytes + 16) != hipSuccess)
+    if (dm_alloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_skip, ((uint64_t)nb + 1) * sizeof(ii2_skip)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_payload, seg->n_bytes + 16) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off, blk_off, (n_lists + 1) * sizeof(uint32_t), kind, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(seg->d_skip, skip, ((uint64_t)nb + 1) * sizeof(ii2_skip), kind, ctx->stream));
@@ -504,7 +507,7 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     seg->n_blocks = src->n_blocks;
     seg->n_bytes = src->n_bytes;
     seg->n_postings = src->n_postings;      // upper bound: postings of unselected window lists are still counted
-    if (hipMalloc((void **)&seg->d_blk_off, (n_out + 1) * sizeof(uint32_t)) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    if (dm_alloc((void **)&seg->d_blk_off, (n_out + 1) * sizeof(uint32_t)) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off, blk.data(), (n_out + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     int rc = seg_finish(ctx, seg.get());
@@ -524,9 +527,9 @@ int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, 
     seg->n_postings = n_postings;
     seg->n_blocks = n_blocks;
     seg->n_bytes = n_bytes;
-    if (hipMalloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&seg->d_skip, (n_blocks + 1) * sizeof(ii2_skip)) != hipSuccess ||
-        hipMalloc((void **)&seg->d_payload, n_bytes + 16) != hipSuccess)
+    if (dm_alloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_skip, (n_blocks + 1) * sizeof(ii2_skip)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_payload, n_bytes + 16) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     *out = seg.release();
     return II2_OK;
@@ -576,7 +579,7 @@ int ii2_seg_adopt_view(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, uint32_
                        uint32_t *d_blk_list, ii2_seg **out) {
     ii2_seg *seg = new (std::nothrow) ii2_seg();
     if (!seg) {
-        (void)hipFree(d_blk_off); (void)hipFree(d_cnt); (void)hipFree(d_last_doc); (void)hipFree(d_blk_list);
+        dm_free(d_blk_off); dm_free(d_cnt); dm_free(d_last_doc); dm_free(d_blk_list);
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     }
     seg->device = ctx->device;

@@ -67,14 +67,22 @@ struct ii2_ctx {
 };
 
 // skip table + payload of one encoded segment; shared by the views made with ii2_seg_select
+namespace ii2 {
+// device memory of segments: a size-class cache in front of hipMalloc / hipFree (devmem.cpp)
+hipError_t dm_alloc(void **p, size_t bytes);
+void dm_free(void *p);
+void dm_trim(size_t keep_bytes);
+void dm_user(int delta);
+}  // namespace ii2
+
 struct ii2_seg_store {
     ii2_skip *d_skip = nullptr;
     uint8_t *d_payload = nullptr;
     void *slab = nullptr;            // one allocation that holds ALL arrays of a small segment (ii2_merge_small): freed as a whole
     ~ii2_seg_store() {
-        if (d_skip) (void)hipFree(d_skip);
-        if (d_payload) (void)hipFree(d_payload);
-        if (slab) (void)hipFree(slab);
+        ii2::dm_free(d_skip);
+        ii2::dm_free(d_payload);
+        ii2::dm_free(slab);
     }
 };
 

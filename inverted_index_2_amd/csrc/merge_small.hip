@@ -406,7 +406,7 @@ extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *s
                  o_cnt = o_pay + up256((size_t)SM_P * 5 + 16), o_last = o_cnt + up256((SM_T + 1) * sizeof(uint32_t)), o_bl = o_last + up256((SM_T + 1) * sizeof(uint32_t)),
                  slab_bytes = o_bl + up256((SM_NB + 1) * sizeof(uint32_t));
     uint8_t *slab = nullptr;
-    if (hipMalloc((void **)&slab, slab_bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "ii2_merge_small: segment allocation failed");
+    if (dm_alloc((void **)&slab, slab_bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "ii2_merge_small: segment allocation failed");
     SmallParams p;
     std::memset(&p, 0, sizeof p);
     for (uint32_t s = 0; s < k; s++) p.seg[s] = SmallSeg{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt};
@@ -421,14 +421,14 @@ extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *s
     // sizes first (they say how much of the rest matters) would be a second round trip: the whole block is 12 KB, take it in one
     if (e == hipSuccess) e = hipMemcpyAsync(ho, ctx->d_small_out, sizeof(SmallOut), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(slab); ctx->err = std::string("ii2_merge_small: ") + hipGetErrorString(e); return II2_EHIP; }
-    if (ho->error) { (void)hipFree(slab); return fail(ctx, II2_ERANGE, "ii2_merge_small: the lists hold more postings than the one-launch merge takes"); }
+    if (e != hipSuccess) { dm_free(slab); ctx->err = std::string("ii2_merge_small: ") + hipGetErrorString(e); return II2_EHIP; }
+    if (ho->error) { dm_free(slab); return fail(ctx, II2_ERANGE, "ii2_merge_small: the lists hold more postings than the one-launch merge takes"); }
     if (stats) { stats->n_in = ho->n_in; stats->n_out = ho->n_out; stats->n_terms_out = ho->n_terms_out; stats->n_tiles = 1; }
     *n_kept = ho->n_terms_out;
     for (uint64_t j = 0; j < ho->n_terms_out; j++) kept[j] = ho->kept[j];
-    if (ho->n_terms_out == 0) { (void)hipFree(slab); return II2_OK; }        // shard.go:219-225: nothing survives, no segment is written
+    if (ho->n_terms_out == 0) { dm_free(slab); return II2_OK; }        // shard.go:219-225: nothing survives, no segment is written
     ii2_seg *seg = new (std::nothrow) ii2_seg();
-    if (!seg) { (void)hipFree(slab); return II2_ENOMEM; }
+    if (!seg) { dm_free(slab); return II2_ENOMEM; }
     seg->device = ctx->device;
     seg->store = std::make_shared<ii2_seg_store>();
     seg->store->slab = slab;                     // owns every array of this segment
