@@ -241,20 +241,29 @@ static void seg_release(ii2_seg *s) {
 }
 
 // reads back the driver-choice statistics of single-list segments and the host blk_off mirror
-static int seg_finish(ii2_ctx *ctx, ii2_seg *seg) {
-    if (!seg->store) {
-        seg->store = std::make_shared<ii2_seg_store>();
-        seg->store->d_skip = seg->d_skip;
-        seg->store->d_payload = seg->d_payload;
-    }
+// the three per-list / per-block arrays every segment carries next to its DV1 arrays
+static int seg_alloc_meta(ii2_ctx *ctx, ii2_seg *seg) {
     if (dm_alloc((void **)&seg->d_last_doc, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     if (dm_alloc((void **)&seg->d_cnt, (seg->n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
         dm_alloc((void **)&seg->d_blk_list, (seg->n_blocks + 1) * sizeof(uint32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
-    HIP_TRY(ctx, hipMemsetAsync(seg->d_blk_list, 0xFF, (seg->n_blocks + 1) * sizeof(uint32_t), ctx->stream));
-    HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_cnt, seg->d_blk_list, seg->d_last_doc,
-                                      ctx->stream));
+    return II2_OK;
+}
+
+// have_meta: the encoder filled d_cnt / d_last_doc / d_blk_list from the CSR it encoded (no list has to be decoded for them)
+static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
+    if (!seg->store) {
+        seg->store = std::make_shared<ii2_seg_store>();
+        seg->store->d_skip = seg->d_skip;
+        seg->store->d_payload = seg->d_payload;
+    }
+    if (!have_meta) {
+        if (int rcm = seg_alloc_meta(ctx, seg)) return rcm;
+        HIP_TRY(ctx, hipMemsetAsync(seg->d_blk_list, 0xFF, (seg->n_blocks + 1) * sizeof(uint32_t), ctx->stream));
+        HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_cnt, seg->d_blk_list, seg->d_last_doc,
+                                          ctx->stream));
+    }
     seg->h_blk_off.resize(seg->n_lists + 1);
     HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -310,9 +319,12 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     seg->n_bytes = nbytes;
     if (dm_alloc((void **)&seg->d_payload, nbytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + nbytes, 0, 16, st));
+    if (int rcm = seg_alloc_meta(ctx, seg.get())) return rcm;
+    HIP_TRY(ctx, hipMemsetAsync(seg->d_blk_list + nb, 0xFF, sizeof(uint32_t), st));         // (the entry past the last block, as k_list_last_doc leaves it)
     HIP_TRY(ctx, launch_enc_write(d_post_off, seg->d_blk_off, n_lists, d_values, nb, d_boff, seg->d_skip,
-                                  seg->d_payload, n_postings, st));
-    int rc = seg_finish(ctx, seg.get());
+                                  seg->d_payload, n_postings, seg->d_blk_list, st));
+    HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
+    int rc = seg_finish(ctx, seg.get(), true);
     if (rc) return rc;
     *out = seg.release();
     return II2_OK;

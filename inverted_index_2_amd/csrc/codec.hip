@@ -36,7 +36,8 @@ template <bool WRITE>
 __global__ __launch_bounds__(256) void k_enc_blocks(const uint64_t *__restrict__ post_off, const uint32_t *__restrict__ blk_off,
                                                     uint64_t n_lists, const uint32_t *__restrict__ values, uint64_t n_blocks,
                                                     uint32_t *__restrict__ sizes, const uint64_t *__restrict__ byte_off64,
-                                                    ii2_skip *__restrict__ skip, uint8_t *__restrict__ payload, uint64_t n_postings) {
+                                                    ii2_skip *__restrict__ skip, uint8_t *__restrict__ payload, uint64_t n_postings,
+                                                    uint32_t *__restrict__ blk_list) {
     __shared__ __align__(16) uint8_t stage[WRITE ? 4 : 1][WRITE ? ENC_STAGE : 16];
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int l = lane_id();
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void k_enc_blocks(const uint64_t *__restrict__
         if (l == 0) {
             skip[b].first_doc = values[p0];
             skip[b].byte_off = (uint32_t)base;
+            if (blk_list) blk_list[b] = (uint32_t)li;         // the block's owner (what k_list_last_doc derives for imported segments)
         }
         // the block's bytes in LDS, shifted so that LDS offset and global address agree mod 16
         uint8_t *st = stage[threadIdx.x >> 6];
@@ -127,16 +129,32 @@ hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_
                                   const uint32_t *values, uint64_t n_blocks, uint32_t *sizes, ii2_skip *skip, hipStream_t s) {
     uint64_t waves = (n_blocks + 1 + ENC_BPW - 1) / ENC_BPW;
     hipLaunchKernelGGL(k_enc_blocks<false>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, post_off, blk_off, n_lists,
-                       values, n_blocks, sizes, (const uint64_t *)nullptr, skip, (uint8_t *)nullptr, (uint64_t)0);
+                       values, n_blocks, sizes, (const uint64_t *)nullptr, skip, (uint8_t *)nullptr, (uint64_t)0, (uint32_t *)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
                             const uint32_t *values, uint64_t n_blocks, const uint64_t *byte_off64,
-                            ii2_skip *skip, uint8_t *payload, uint64_t n_postings, hipStream_t s) {
+                            ii2_skip *skip, uint8_t *payload, uint64_t n_postings, uint32_t *blk_list, hipStream_t s) {
     uint64_t waves = (n_blocks + 1 + ENC_BPW - 1) / ENC_BPW;
     hipLaunchKernelGGL(k_enc_blocks<true>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, post_off, blk_off, n_lists,
-                       values, n_blocks, (uint32_t *)nullptr, byte_off64, skip, payload, n_postings);
+                       values, n_blocks, (uint32_t *)nullptr, byte_off64, skip, payload, n_postings, blk_list);
+    return hipGetLastError();
+}
+
+// per list: posting count and last doc id, straight from the CSR that is being encoded (an imported segment has to decode every
+// list's last block for them: k_list_last_doc)
+__global__ void k_enc_list_meta(const uint64_t *__restrict__ post_off, const uint32_t *__restrict__ values, uint64_t n_lists,
+                                uint32_t *__restrict__ cnt, uint32_t *__restrict__ last_doc) {
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lists) return;
+    const uint64_t p0 = post_off[l], p1 = post_off[l + 1];
+    cnt[l] = (uint32_t)(p1 - p0);
+    last_doc[l] = p1 > p0 ? values[p1 - 1] : 0u;
+}
+hipError_t launch_enc_list_meta(const uint64_t *post_off, const uint32_t *values, uint64_t n_lists, uint32_t *cnt, uint32_t *last_doc, hipStream_t s) {
+    if (n_lists == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_enc_list_meta, dim3((unsigned)((n_lists + 255) / 256)), dim3(256), 0, s, post_off, values, n_lists, cnt, last_doc);
     return hipGetLastError();
 }
 

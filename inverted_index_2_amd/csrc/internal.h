@@ -266,7 +266,8 @@ hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_
                                   const uint32_t *values, uint64_t n_blocks, uint32_t *sizes, ii2_skip *skip, hipStream_t s);
 hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
                             const uint32_t *values, uint64_t n_blocks, const uint64_t *byte_off64,
-                            ii2_skip *skip, uint8_t *payload, uint64_t n_postings, hipStream_t s);
+                            ii2_skip *skip, uint8_t *payload, uint64_t n_postings, uint32_t *blk_list, hipStream_t s);
+hipError_t launch_enc_list_meta(const uint64_t *post_off, const uint32_t *values, uint64_t n_lists, uint32_t *cnt, uint32_t *last_doc, hipStream_t s);
 hipError_t launch_dec_block_counts(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, uint32_t *counts, hipStream_t s);
 hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, const uint64_t *bpo,
                             uint32_t *values, hipStream_t s);
