@@ -374,7 +374,7 @@ static_assert(MERGE_NT_MAX <= 1024u && PCAP < 2048u, "BI packs term slot (10 bit
 struct __align__(16) MergeSmem {
     union {
         struct {
-            uint32_t V[MCAP];               // the tile's postings: arrival order, then bucket order
+            uint32_t V[MCAP + 4u];          // the tile's postings: arrival order, then bucket order (+ 4: the ranking reads four entries from any bucket's base)
             uint16_t TG[MCAP];              // per posting: term slot (while decoding), then its bucket
             uint32_t C32[MCAP / 2u + 4u];   // bucket counters, then exclusive bucket bases: two 16-bit values per word
         } s;
@@ -1011,17 +1011,21 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     u_scale = (float)MCAP / ((float)((mxr > u_mn ? mxr : u_mn) - u_mn) + 1.0f);
                 }
                 lds_barrier();
-                // ---- bucket of every posting, slot inside the bucket
+                // ---- bucket of every posting, slot inside the bucket.  No per-lane branches: a lane past the tile's last
+                // posting works on a dummy (term slot 0, counts nothing, its bucket id lands in an unused TG entry) - the
+                // exec-mask bookkeeping of a predicated body was a quarter of this pass's issue slots
                 bool over = false;
 #pragma unroll
                 for (uint32_t j = 0; j < EPT; j++) {
                     const uint32_t i = (uint32_t)tid + j * MT;
-                    if (j < nj && i < n) {
+                    if (j < nj) {
+                        const bool valid = i < n;
                         const uint32_t v = sm.u.s.V[i];
                         uint32_t mn = u_mn, nbm1 = u_nbm1, tb = 0;
                         float sc = u_scale;
                         if (cur_batch) {
-                            const uint32_t ti = sm.u.s.TG[i];
+                            const uint32_t tg0 = sm.u.s.TG[i];
+                            const uint32_t ti = valid ? tg0 : 0u;
                             const uint2 te = sm.x.f.TT[ti];
                             tb = sm.x.f.TB[ti];
                             nbm1 = (uint32_t)sm.x.f.TB[ti + 1u] - tb - 1u;
@@ -1032,8 +1036,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                         const uint32_t b = tb + (bq < nbm1 ? bq : nbm1);
                         sm.u.s.TG[i] = (uint16_t)b;
                         const uint32_t sh = 16u * (b & 1u);
-                        uint32_t slot_ = (atomicAdd(&C32[b >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                        if (slot_ > BKT_LIMIT) { over = true; slot_ = BKT_LIMIT; }
+                        uint32_t slot_ = (atomicAdd(&C32[b >> 1], valid ? 1u << sh : 0u) >> sh) & 0xFFFFu;
+                        over = over || (valid && slot_ > BKT_LIMIT);
+                        slot_ = slot_ < BKT_LIMIT ? slot_ : BKT_LIMIT;
                         slots |= (unsigned long long)slot_ << (4u * j);
                     }
                 }
@@ -1072,10 +1077,13 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     for (uint32_t j = 0; j < EPT; j++) {
                         const uint32_t i = (uint32_t)tid + j * MT;
                         v[j] = 0; pk[j] = 0; ts[j] = 0;
-                        if (j < nj && i < n) {
+                        if (j < nj) {           // (no per-lane branch: a lane past the last posting moves its unused entry onto itself)
+                            const bool valid = i < n;
                             v[j] = sm.u.s.V[i];
-                            const uint32_t b = sm.u.s.TG[i];
-                            pk[j] = ((uint32_t)C16[b] + (uint32_t)((slots >> (4u * j)) & 15ull)) | (b << 16);
+                            const uint32_t b0 = sm.u.s.TG[i];
+                            const uint32_t b = valid ? b0 : 0u;
+                            const uint32_t to = (uint32_t)C16[b] + (uint32_t)((slots >> (4u * j)) & 15ull);
+                            pk[j] = (valid ? to : i) | (b << 16);
                             // tombstones: most tests stop at the summary (1 bit per 16 docs, L2-resident)
                             if (p.tomb && (v[j] >> 5) < p.tomb_nwords) ts[j] = p.tomb_summary[v[j] >> 9];
                         }
@@ -1083,8 +1091,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     lds_barrier();
 #pragma unroll
                     for (uint32_t j = 0; j < EPT; j++) {
-                        const uint32_t i = (uint32_t)tid + j * MT;
-                        if (j < nj && i < n) {
+                        if (j < nj) {
                             uint32_t tag = pk[j] >> 16;
                             if ((ts[j] >> ((v[j] >> 4) & 31u)) & 1u) tag |= ((p.tomb[v[j] >> 5] >> (v[j] & 31u)) & 1u) << 15;     // rarely: the bitmap itself
                             sm.u.s.V[pk[j] & 0xFFFFu] = v[j];
@@ -1100,9 +1107,11 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                 for (uint32_t j = 0; j < EPT; j++) {
                     const uint32_t q = (uint32_t)tid + j * MT;
                     fv[j] = 0; fp[j] = 0x80000000u;
-                    if (j < nj && q < n) {
+                    if (j < nj) {               // (no per-lane branch: a lane past the last posting ranks a dummy in bucket 0 and drops it)
+                        const bool valid = q < n;
                         const uint32_t v = sm.u.s.V[q];
-                        const uint32_t tg = sm.u.s.TG[q];                         // bucket | tombstoned << 15
+                        const uint32_t tg0 = sm.u.s.TG[q];
+                        const uint32_t tg = valid ? tg0 : 0u;                     // bucket | tombstoned << 15
                         const uint32_t b = tg & 0x7FFFu;
                         const uint32_t blo = C16[b], nb = (uint32_t)C16[b + 1u] - blo;
                         const uint32_t qi = q - blo;                              // my place in the bucket
@@ -1110,7 +1119,10 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                         // the whole wave wait for the fullest bucket among its 64).  A place past the bucket counts as my own id
                         // at a later place: neither smaller nor an earlier copy.
                         const uint32_t *B4 = &sm.u.s.V[blo];
-                        const uint32_t u0 = B4[0], u1 = nb > 1u ? B4[1] : v, u2 = nb > 2u ? B4[2] : v, u3 = nb > 3u ? B4[3] : v;
+                        // (all four are read whatever the bucket holds and the ones past the bucket are replaced afterwards: selects
+                        // instead of predicated loads)
+                        const uint32_t r0 = B4[0], r1 = B4[1], r2 = B4[2], r3 = B4[3];
+                        const uint32_t u0 = r0, u1 = nb > 1u ? r1 : v, u2 = nb > 2u ? r2 : v, u3 = nb > 3u ? r3 : v;
                         const uint32_t e0 = (u0 == v && 0u < qi) ? 1u : 0u, e1 = (u1 == v && 1u < qi) ? 1u : 0u;
                         const uint32_t e2 = (u2 == v && 2u < qi) ? 1u : 0u, e3 = (u3 == v && 3u < qi) ? 1u : 0u;
                         uint32_t r = (u0 < v ? 1u : 0u) + (u1 < v ? 1u : 0u) + (u2 < v ? 1u : 0u) + (u3 < v ? 1u : 0u) + e0 + e1 + e2 + e3;
@@ -1123,9 +1135,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                             dead |= eq;
                         }
                         const uint32_t P = blo + r;
-                        if (dead) atomicOr(&sm.x.f.DB[P >> 5], 1u << (P & 31u));
+                        if (dead && valid) atomicOr(&sm.x.f.DB[P >> 5], 1u << (P & 31u));
                         fv[j] = v;
-                        fp[j] = P | (dead << 31);
+                        fp[j] = valid ? P | (dead << 31) : 0x80000000u;
                     }
                 }
                 lds_barrier();
