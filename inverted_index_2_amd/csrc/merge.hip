@@ -217,13 +217,13 @@ constexpr uint32_t CUT_INSIDE = 1u << 31;
 // cut0[tile * k + s] / cut1[tile * k + s]: where list s's part of the tile begins and ends (tiles that take whole lists: the
 // lists' first block and the block after their last).  A tile's end is the next tile's beginning, so the cut at a tile's lower
 // bound is computed once and handed to the tile(s) before it as their end.  A thread per (tile, list) finds the block that
-// straddles the bound in the skip table; the walks through those blocks are then done by the wave together, two at a time:
-// 32 lanes per block, 16 payload bytes per lane, all pieces of a block in one round of loads (a thread walking its block
+// straddles the bound in the skip table; the walks through those blocks are then done by the wave together, four at a time:
+// 16 lanes per block, 16 payload bytes per lane, 256 bytes of a block in one round of loads (a thread walking its block
 // alone is a chain of dependent loads: ~1 ms on C3 against 0.1 ms for everything else the plan does).
 __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams p) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = lane_id();
-    const uint32_t hl = (uint32_t)l & 31u, half = (uint32_t)l >> 5;
+    const uint32_t hl = (uint32_t)l & 15u, grp = (uint32_t)l >> 4;
     const uint64_t n_pairs = (uint64_t)*p.n_tiles_dev * p.k;
     const bool live = i < n_pairs;                              // (no early exit: the wave works together below)
     const uint32_t tile = live ? (uint32_t)(i / p.k) : 0u, s = live ? (uint32_t)(i % p.k) : 0u;
@@ -260,14 +260,17 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
         asm volatile("" ::"v"(touch));
     }
     for (unsigned long long need = __ballot(walk); need != 0ull;) {
-        // the two lowest lanes that need a walk: the lower half of the wave takes the first, the upper half the second
-        const int s0 = __ffsll((long long)need) - 1;
-        need &= need - 1ull;
-        const bool two = need != 0ull;
-        const int s1 = two ? __ffsll((long long)need) - 1 : s0;
-        if (two) need &= need - 1ull;
-        const int src = half ? s1 : s0;
-        const bool mine = half == 0u || two;                    // my half has a block to walk
+        // the four lowest lanes that need a walk: one per group of 16 lanes (a block is walked 16 pieces = 256 bytes at a time,
+        // and most walks end in their first or second step: the crossing is half a block in on average)
+        int sl[4];
+        uint32_t ng = 0;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            sl[g] = need ? __ffsll((long long)need) - 1 : 0;
+            if (need) { need &= need - 1ull; ng++; }
+        }
+        const int src = grp == 0u ? sl[0] : grp == 1u ? sl[1] : grp == 2u ? sl[2] : sl[3];
+        const bool mine = grp < ng;                             // my group has a block to walk
         const uint32_t w_start = (uint32_t)__shfl((int)start, src, 64), w_len = (uint32_t)__shfl((int)len, src, 64);
         const uint32_t w_first = (uint32_t)__shfl((int)first, src, 64), w_x = (uint32_t)__shfl((int)x, src, 64), w_a = (uint32_t)__shfl((int)a, src, 64);
         const uint8_t *w_pay = (const uint8_t *)(uintptr_t)(unsigned long long)__shfl((long long)pay64, src, 64);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
         uint32_t docbase = w_first;                             // sum of all gap bits before the step's first piece
         bool open = mine;
         uint4 res = make_uint4(w_a, 0u, 0u, 0u);
-        for (uint32_t pb = 0; __ballot(open && pb < np) != 0ull; pb += 32u) {       // (wave-uniform: a half that is done idles)
+        for (uint32_t pb = 0; __ballot(open && pb < np) != 0ull; pb += 16u) {       // (wave-uniform: a group that is done idles)
             const uint32_t pc = pb + hl;
             const bool pv = open && pc < np;
             uint32_t val[16], tmask = 0, w[4] = {0, 0, 0, 0}, prev = 0;
@@ -310,13 +313,13 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
             }
             uint32_t incl = val[15];
 #pragma unroll
-            for (int d = 1; d < 32; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 32); if (hl >= (uint32_t)d) incl += y; }
+            for (int d = 1; d < 16; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 16); if (hl >= (uint32_t)d) incl += y; }
             const uint32_t base = docbase + incl - val[15];
             uint32_t cm = 0;
 #pragma unroll
             for (int q = 0; q < 16; q++) cm |= (base + val[q] >= w_x) ? 1u << q : 0u;
             cm &= tmask;
-            const uint32_t hits = (uint32_t)(__ballot(pv && cm != 0u) >> (32u * half));
+            const uint32_t hits = (uint32_t)(__ballot(pv && cm != 0u) >> (16u * grp)) & 0xFFFFu;
             uint4 r = make_uint4(0, 0, 0, 0);
             if (pv && cm != 0u) {
                 // the first posting >= x ends at byte q of my piece: its varint back to front (the byte before its first one ends
@@ -335,18 +338,19 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
                 for (int t = 1; t < 16; t++) vq = t == q ? val[t] : vq;
                 r = make_uint4((w_a - 1u) | CUT_INSIDE, w_start + off + (uint32_t)q + 1u - nbytes, base + vq - gap, 0u);
             }
-            if (hits != 0u) {                                    // (uniform in the half)
+            if (hits != 0u) {                                    // (uniform in the group)
                 const int hsrc = __ffs((int)hits) - 1;
-                res = make_uint4((uint32_t)__shfl((int)r.x, hsrc, 32), (uint32_t)__shfl((int)r.y, hsrc, 32), (uint32_t)__shfl((int)r.z, hsrc, 32), 0u);
+                res = make_uint4((uint32_t)__shfl((int)r.x, hsrc, 16), (uint32_t)__shfl((int)r.y, hsrc, 16), (uint32_t)__shfl((int)r.z, hsrc, 16), 0u);
                 open = false;
             }
-            docbase += (uint32_t)__shfl((int)incl, 31, 32);
+            docbase += (uint32_t)__shfl((int)incl, 15, 16);
         }
-        // the halves' results go to the lanes whose blocks they walked
-        const uint32_t r0x = (uint32_t)__shfl((int)res.x, 0, 64), r0y = (uint32_t)__shfl((int)res.y, 0, 64), r0z = (uint32_t)__shfl((int)res.z, 0, 64);
-        const uint32_t r1x = (uint32_t)__shfl((int)res.x, 32, 64), r1y = (uint32_t)__shfl((int)res.y, 32, 64), r1z = (uint32_t)__shfl((int)res.z, 32, 64);
-        if (l == s0) c0 = make_uint4(r0x, r0y, r0z, 0u);
-        if (two && l == s1) c0 = make_uint4(r1x, r1y, r1z, 0u);
+        // the groups' results go to the lanes whose blocks they walked
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t rx = (uint32_t)__shfl((int)res.x, 16 * g, 64), ry = (uint32_t)__shfl((int)res.y, 16 * g, 64), rz = (uint32_t)__shfl((int)res.z, 16 * g, 64);
+            if ((uint32_t)g < ng && l == sl[g]) c0 = make_uint4(rx, ry, rz, 0u);
+        }
     }
     if (!nonempty) return;
     if (x != 0u) {
