@@ -645,9 +645,9 @@ int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where
     if (!t) return II2_ENOMEM;
     t->device = ctx->device;
     t->n_words = n ? (uint64_t)(mx >> 5) + 1 : 0;
-    // bitmap, then its summary (1 bit per 16 docs = per half bitmap word) in the same allocation
+    // bitmap, then its summary (1 bit per (1 << TOMB_SUM_SHIFT) docs) in the same allocation
     const uint64_t words_padded = (t->n_words + 4 + 3) & ~3ull;
-    const uint64_t n_sum = (t->n_words + 15) / 16 + 1;
+    const uint64_t n_sum = (t->n_words >> TOMB_SUM_SHIFT) + 2;
     if (hipMalloc((void **)&t->d_words, (words_padded + n_sum) * sizeof(uint32_t)) != hipSuccess) {
         delete t;
         return fail(ctx, II2_ENOMEM, "tombstone bitmap allocation failed");

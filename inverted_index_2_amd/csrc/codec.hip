@@ -312,7 +312,7 @@ hipError_t launch_validate_counts(const uint32_t *blk_off, const uint32_t *blk_l
 
 // ---- tombstones -----------------------------------------------------------------------
 // RemovedLists.Values() (removed_list.go:44-54) as a dense bitmap: bit v set <=> v removed.
-// plus a summary with one bit per 16 docs (random bit tests of a 12 MB bitmap miss L2; the summary does not)
+// plus a summary with one bit per (1 << TOMB_SUM_SHIFT) docs (random bit tests of a 12 MB bitmap miss L2; the summary mostly does not)
 __global__ void k_tomb_build(const uint32_t *__restrict__ removed, uint64_t n, uint32_t *__restrict__ words, uint64_t n_words,
                              uint32_t *__restrict__ summary) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -320,7 +320,7 @@ __global__ void k_tomb_build(const uint32_t *__restrict__ removed, uint64_t n, u
         uint64_t w = v >> 5;
         if (w < n_words) {
             atomicOr(&words[w], 1u << (v & 31u));
-            atomicOr(&summary[v >> 9], 1u << ((v >> 4) & 31u));
+            atomicOr(&summary[v >> (5u + TOMB_SUM_SHIFT)], 1u << ((v >> TOMB_SUM_SHIFT) & 31u));
         }
     }
 }

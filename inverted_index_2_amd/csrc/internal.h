@@ -109,10 +109,12 @@ struct ii2_seg {
     static constexpr uint64_t SPAN_MIRROR_MAX = 1u << 16;
 };
 
+namespace ii2 { constexpr uint32_t TOMB_SUM_SHIFT = 4; }    // docs per bit of a tombstone bitmap's summary: 1 << TOMB_SUM_SHIFT
+
 struct ii2_tomb {
     int device = 0;
     uint32_t *d_words = nullptr;
-    uint32_t *d_summary = nullptr;   // bit g set <=> some doc of [16g, 16g+16) is removed (same allocation as d_words)
+    uint32_t *d_summary = nullptr;   // bit g set <=> some doc of [g << TOMB_SUM_SHIFT, (g + 1) << TOMB_SUM_SHIFT) is removed (same allocation as d_words)
     uint64_t n_words = 0;   // bitmap covers doc ids [0, 32*n_words)
 };
 
@@ -313,7 +315,7 @@ struct MergeParams {
     uint32_t n_tiles_ub;          // host-side upper bound of the tile count (sizes grids and per-tile arrays)
     uint64_t n_terms;
     const uint32_t *tomb;
-    const uint32_t *tomb_summary;  // 1 bit per 16 docs: most bit tests stop at this small, L2-resident array
+    const uint32_t *tomb_summary;  // 1 bit per (1 << TOMB_SUM_SHIFT) docs: most bit tests stop at this small, L2-resident array
     uint32_t tomb_nwords;
     uint32_t small_max;           // terms with more input postings get their own tiles (doc ranges)
     uint32_t range_target;        // input postings a range tile of a large term aims at

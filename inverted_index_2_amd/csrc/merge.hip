@@ -1088,8 +1088,8 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                             const uint32_t b = valid ? b0 : 0u;
                             const uint32_t to = (uint32_t)C16[b] + (uint32_t)((slots >> (4u * j)) & 15ull);
                             pk[j] = (valid ? to : i) | (b << 16);
-                            // tombstones: most tests stop at the summary (1 bit per 16 docs, L2-resident)
-                            if (p.tomb && (v[j] >> 5) < p.tomb_nwords) ts[j] = p.tomb_summary[v[j] >> 9];
+                            // tombstones: most tests stop at the summary (1 bit per 1 << TOMB_SUM_SHIFT docs, mostly L2-resident)
+                            if (p.tomb && (v[j] >> 5) < p.tomb_nwords) ts[j] = p.tomb_summary[v[j] >> (5u + TOMB_SUM_SHIFT)];
                         }
                     }
                     lds_barrier();
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     for (uint32_t j = 0; j < EPT; j++) {
                         if (j < nj) {
                             uint32_t tag = pk[j] >> 16;
-                            if ((ts[j] >> ((v[j] >> 4) & 31u)) & 1u) tag |= ((p.tomb[v[j] >> 5] >> (v[j] & 31u)) & 1u) << 15;     // rarely: the bitmap itself
+                            if ((ts[j] >> ((v[j] >> TOMB_SUM_SHIFT) & 31u)) & 1u) tag |= ((p.tomb[v[j] >> 5] >> (v[j] & 31u)) & 1u) << 15;     // rarely: the bitmap itself
                             sm.u.s.V[pk[j] & 0xFFFFu] = v[j];
                             sm.u.s.TG[pk[j] & 0xFFFFu] = (uint16_t)tag;
                         }
