@@ -338,8 +338,9 @@ struct MergeParams {
     const uint32_t *n_tiles_dev;  // = term_tile + T
     // per tile
     uint4 *desc;                  // {t0, t1 | flags, dlo, dhi}
-    uint4 *cut0;                  // [n_tiles * k] where list s's part of the tile begins: {block | inside, payload byte, doc before, -} (merge.hip: cut_for)
-    uint2 *cut1;                  // [n_tiles * k] ... and where it ends: {block | inside, payload byte}
+    uint4 *cut0;                  // [k * n_tiles_ub] where list s's part of the tile begins: {block | inside, payload byte, doc before, -} (merge.hip: cut_for)
+    uint2 *cut1;                  // [k * n_tiles_ub] ... and where it ends: {block | inside, payload byte}
+    uint32_t cut_ss, cut_st;      // entry of (list s, tile): s * cut_ss + tile * cut_st ([tile][s] for few lists, [s][tile] for many: the plan kernel's lanes then run along the tiles)
     uint32_t *term_alloc;         // [T] bump allocator inside a large term's parking region (zeroed by the host)
     uint32_t *tmp;                // parked survivors
     uint32_t *tile_count;         // [n_tiles_ub+1] survivors per tile (zeroed by the host)

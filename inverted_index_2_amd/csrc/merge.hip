@@ -214,7 +214,175 @@ __device__ __forceinline__ uint2 blocks_of_range(const ii2_skip *__restrict__ sk
 // range tile holds less than one block per list: decoding the straddling blocks whole was more than half of its decode work).
 constexpr uint32_t CUT_INSIDE = 1u << 31;
 
-// cut0[tile * k + s] / cut1[tile * k + s]: where list s's part of the tile begins and ends (tiles that take whole lists: the
+// cut0[s * n_tiles_ub + tile] / cut1[...]: where list s's part of the tile begins and ends (tiles that take whole lists: the
+// lists' first block and the block after their last).  A tile's end is the next tile's beginning, so the cut at a tile's lower
+// bound is computed once and handed to the tile(s) before it as their end.  A thread per (list, tile) - neighbouring lanes hold
+// neighbouring tiles of ONE list - finds the block that straddles its bound in the skip table.  The walks through those blocks
+// are then done by the wave together: 16 lanes per block, 16 payload bytes per lane, 256 bytes of a block in one round of
+// loads, four blocks at a time, and a block is walked ONCE for all the bounds that fall into it (with 64 lists a tile takes a
+// fifth of a block from each: five bounds per block).  A thread walking its block alone is a chain of dependent loads
+// (~1 ms on C3 against 0.1 ms for everything else the plan does); one shared walk per bound was 3.3 ms of C4's 14.7.
+__global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs *__restrict__ ms, MergeParams p) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = lane_id();
+    const uint32_t hl = (uint32_t)l & 15u, grp = (uint32_t)l >> 4;
+    const uint32_t n_tiles = *p.n_tiles_dev;
+    const uint64_t n_pairs = (uint64_t)n_tiles * p.k;
+    const bool live = i < n_pairs;                              // (no early exit: the wave works together below)
+    const uint32_t s = live ? (uint32_t)(i / n_tiles) : 0u, tile = live ? (uint32_t)(i % n_tiles) : 0u;
+    const uint4 td = live ? p.desc[tile] : make_uint4(0u, 0u, 1u, 0u);
+    const bool nonempty = live && td.z <= td.w;                 // (an empty range: the tile decodes nothing)
+    const SegView &sv = ms->segs[s];
+    const uint32_t b_lo = live ? sv.blk_off[td.x] : 0u, b_hi = live ? sv.blk_off[td.y & 0x3FFFFFFFu] : 0u;
+    const uint32_t x = td.z;
+    uint4 c0 = make_uint4(b_lo, 0u, 0u, 0u);
+    // ---- the block that straddles x (if any): the last one that starts below x
+    bool walk = false;
+    uint32_t a = b_lo, start = 0, len = 0, first = 0;
+    if (nonempty && x != 0u && b_hi > b_lo && !(p.pad0 & 32u)) {
+        const ii2_skip *__restrict__ skip = sv.skip;
+        const uint32_t f0 = skip[b_lo].first_doc;
+        if (x > f0) {
+            auto get = [&](uint32_t j) { return skip[j].first_doc; };
+            a = upper_bound_guess(get, b_lo, b_hi, x - 1u, f0, skip[b_hi - 1u].first_doc);      // first block that starts at or after x (> b_lo)
+            const ii2_skip e0 = skip[a - 1u];
+            start = e0.byte_off;
+            len = skip[a].byte_off - start;
+            if (len > 1280u) len = 1280u;                       // (a block holds <= 256 postings of <= 5 bytes; imported segments are validated)
+            first = e0.first_doc;
+            c0 = make_uint4(a, 0u, 0u, 0u);                      // unless the walk finds x inside the block
+            walk = len != 0u && !(p.pad0 & 16u);
+        }
+    }
+    // (block a of segment s: two lanes share a walk when both agree; lanes of a wave may belong to two lists)
+    const unsigned long long blk_id = ((unsigned long long)s << 32) | a;
+    for (unsigned long long need = __ballot(walk); need != 0ull;) {
+        // up to four different blocks, one per group of 16 lanes, each with the lanes whose bounds fall into it (they are
+        // neighbours: ascending tiles, ascending bounds)
+        unsigned long long bm[4] = {0ull, 0ull, 0ull, 0ull};
+        int lead[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            if (need) {
+                lead[g] = __ffsll((long long)need) - 1;
+                const unsigned long long id = (unsigned long long)__shfl((long long)blk_id, lead[g], 64);
+                bm[g] = __ballot(walk && blk_id == id) & need;
+                need &= ~bm[g];
+            } else (void)__shfl((long long)blk_id, 0, 64);       // (every lane takes part in every shuffle)
+        }
+        const int src = grp == 0u ? lead[0] : grp == 1u ? lead[1] : grp == 2u ? lead[2] : lead[3];
+        unsigned long long pend = grp == 0u ? bm[0] : grp == 1u ? bm[1] : grp == 2u ? bm[2] : bm[3];      // my group's bounds still to be found
+        const uint32_t w_start = (uint32_t)__shfl((int)start, src, 64), w_len = (uint32_t)__shfl((int)len, src, 64);
+        const uint32_t w_first = (uint32_t)__shfl((int)first, src, 64), w_a = (uint32_t)__shfl((int)a, src, 64);
+        const uint8_t *w_pay = ms->segs[(uint32_t)__shfl((int)s, src, 64)].payload;
+        const uint32_t np = pend ? (w_len + 15u) >> 4 : 0u;
+        uint32_t docbase = w_first;                             // sum of all gap bits before the step's first piece
+        for (uint32_t pb = 0; __ballot(pend != 0ull && pb < np) != 0ull; pb += 16u) {       // (wave-uniform: a group that is done idles)
+            const uint32_t pc = pb + hl;
+            const bool pv = pend != 0ull && pc < np;
+            uint32_t val[16], tmask = 0, w[4] = {0, 0, 0, 0}, prev = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) val[q] = 0;
+            const uint32_t off = 16u * pc;
+            if (pv) {
+                const uint32_t rem = w_len - off;
+                const uint8_t *pp = w_pay + w_start + off;
+                const uint4 w4 = gload16(pp);                    // (segments carry 16 bytes of padding)
+                prev = off ? gload4(pp - 4) : 0u;
+                w[0] = w4.x; w[1] = w4.y; w[2] = w4.z; w[3] = w4.w;
+                if (rem < 16u) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t nj = rem > 4u * j ? (rem - 4u * j < 4u ? rem - 4u * j : 4u) : 0u;
+                        w[j] &= nj >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nj)) - 1u);
+                    }
+                }
+                uint32_t sh = 7u * ((uint32_t)__clz((int)~(prev | 0x7F7F7F7Fu)) >> 3);      // continuation bytes pending before my first byte
+                uint32_t sum = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const uint32_t c7 = __builtin_amdgcn_ubfe(w[q >> 2], 8 * (q & 3), 7);
+                    const uint32_t cm = (uint32_t)__builtin_amdgcn_sbfe((int)w[q >> 2], 8 * (q & 3) + 7, 1);
+                    sum += c7 << (sh & 31u);
+                    sh = (sh + 7u) & cm;
+                    tmask |= ~cm & (1u << q);
+                    val[q] = sum;
+                }
+                if (rem < 16u) tmask &= (1u << rem) - 1u;
+            }
+            uint32_t incl = val[15];
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 16); if (hl >= (uint32_t)d) incl += y; }
+            const uint32_t base = docbase + incl - val[15];
+            // the group's bounds, in ascending order, against this step's 16 pieces: a bound that is not found here waits for
+            // the next step (and so do the bounds above it)
+            bool more = pend != 0ull;
+            while (__ballot(more) != 0ull) {                     // (wave-uniform)
+                const int bl = more ? __ffsll((long long)pend) - 1 : 0;
+                const uint32_t xb = (uint32_t)__shfl((int)x, bl, 64);
+                uint32_t cm = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) cm |= (base + val[q] >= xb) ? 1u << q : 0u;
+                cm &= tmask;
+                const bool hit = more && pv && cm != 0u;
+                const uint32_t hits = (uint32_t)(__ballot(hit) >> (16u * grp)) & 0xFFFFu;
+                uint4 r = make_uint4(0, 0, 0, 0);
+                if (hit) {
+                    // the first posting >= x ends at byte q of my piece: its varint back to front (the byte before its first one
+                    // ends the posting before, or is the 0 in front of the block's first byte), most significant group first
+                    const int q = __ffs((int)cm) - 1;
+                    uint32_t gap = 0, nbytes = 0;
+                    for (int j = q; j > q - 5; j--) {
+                        const uint32_t wj = j < 0 ? prev : j < 4 ? w[0] : j < 8 ? w[1] : j < 12 ? w[2] : w[3];
+                        const uint32_t c = (wj >> (8u * ((uint32_t)j & 3u))) & 0xFFu;
+                        if (j != q && !(c & 0x80u)) break;
+                        gap = (gap << 7) | (c & 0x7Fu);
+                        nbytes++;
+                    }
+                    uint32_t vq = val[0];
+#pragma unroll
+                    for (int t = 1; t < 16; t++) vq = t == q ? val[t] : vq;
+                    r = make_uint4((w_a - 1u) | CUT_INSIDE, w_start + off + (uint32_t)q + 1u - nbytes, base + vq - gap, 0u);
+                }
+                const int hsrc = hits ? __ffs((int)hits) - 1 : 0;
+                const uint4 res = make_uint4((uint32_t)__shfl((int)r.x, hsrc, 16), (uint32_t)__shfl((int)r.y, hsrc, 16), (uint32_t)__shfl((int)r.z, hsrc, 16), 0u);
+                // the groups' answers go to the lanes that asked
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t rx = (uint32_t)__shfl((int)res.x, 16 * g, 64), ry = (uint32_t)__shfl((int)res.y, 16 * g, 64), rz = (uint32_t)__shfl((int)res.z, 16 * g, 64);
+                    const bool found = (uint32_t)__shfl((int)(more && hits != 0u ? 1 : 0), 16 * g, 64) != 0u;
+                    const int who = __shfl(bl, 16 * g, 64);
+                    if (found && l == who) c0 = make_uint4(rx, ry, rz, 0u);
+                }
+                if (more && hits != 0u) pend &= pend - 1ull;     // found: on to the group's next bound, in this same step
+                else more = false;
+                more = more && pend != 0ull;
+            }
+            docbase += (uint32_t)__shfl((int)incl, 15, 16);
+        }
+        // (bounds still pending: the block lies wholly below them - their cut stays in front of the next block)
+    }
+    if (!nonempty) return;
+    if (x != 0u) {
+        // the tiles of the same term right before this one: the empty ones in between and the one that ends where I begin
+        for (uint32_t j = tile; j-- > 0u;) {
+            const uint4 pd = p.desc[j];
+            if (pd.x != td.x || !(pd.y & MERGE_DESC_LARGE)) break;
+            if (pd.z > pd.w) continue;
+            p.cut1[(uint64_t)s * p.cut_ss + (uint64_t)j * p.cut_st] = make_uint2(c0.x, c0.y);
+            break;
+        }
+    }
+    p.cut0[(uint64_t)s * p.cut_ss + (uint64_t)tile * p.cut_st] = c0;
+    // the last tile of its term(s) ends where the lists end (a bitmap term's last window stops short of 2^32, and nothing follows it)
+    bool last = tile + 1u == *p.n_tiles_dev;
+    if (!last) { const uint4 nd = p.desc[tile + 1u]; last = nd.x != td.x || !(nd.y & MERGE_DESC_LARGE) || !(td.y & MERGE_DESC_LARGE); }
+    if (last) p.cut1[(uint64_t)s * p.cut_ss + (uint64_t)tile * p.cut_st] = make_uint2(b_hi, 0u);
+}
+
+// Few lists (k < 32): a bound rarely shares its block with another one - a thread per (tile, list), neighbouring lanes hold the
+// lists of one tile (cut0[tile * k + s]), every bound walks its block.
+// cut0 / cut1: where list s's part of the tile begins and ends (tiles that take whole lists: the
 // lists' first block and the block after their last).  A tile's end is the next tile's beginning, so the cut at a tile's lower
 // bound is computed once and handed to the tile(s) before it as their end.  A thread per (tile, list) finds the block that
 // straddles the bound in the skip table; the walks through those blocks are then done by the wave together, four at a time:
@@ -359,15 +527,15 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
             const uint4 pd = p.desc[j];
             if (pd.x != td.x || !(pd.y & MERGE_DESC_LARGE)) break;
             if (pd.z > pd.w) continue;
-            p.cut1[(uint64_t)j * p.k + s] = make_uint2(c0.x, c0.y);
+            p.cut1[(uint64_t)s * p.cut_ss + (uint64_t)j * p.cut_st] = make_uint2(c0.x, c0.y);
             break;
         }
     }
-    p.cut0[i] = c0;
+    p.cut0[(uint64_t)s * p.cut_ss + (uint64_t)tile * p.cut_st] = c0;
     // the last tile of its term(s) ends where the lists end (a bitmap term's last window stops short of 2^32, and nothing follows it)
     bool last = tile + 1u == *p.n_tiles_dev;
     if (!last) { const uint4 nd = p.desc[tile + 1u]; last = nd.x != td.x || !(nd.y & MERGE_DESC_LARGE) || !(td.y & MERGE_DESC_LARGE); }
-    if (last) p.cut1[i] = make_uint2(b_hi, 0u);
+    if (last) p.cut1[(uint64_t)s * p.cut_ss + (uint64_t)tile * p.cut_st] = make_uint2(b_hi, 0u);
 }
 
 // ---- the tile kernel ----------------------------------------------------------------------
@@ -599,7 +767,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
     uint4 c0_nx = make_uint4(0, 0, 0, 0);          // threads 0 .. k-1: where my list's part of the tile begins ...
     uint2 c1_nx = make_uint2(0, 0);                // ... and ends (plan: k_merge_tile_runs)
     auto fetch_cuts = [&]() {
-        if (tile_nx < n_tiles && (uint32_t)tid < k) { c0_nx = p.cut0[(uint64_t)tile_nx * k + (uint32_t)tid]; c1_nx = p.cut1[(uint64_t)tile_nx * k + (uint32_t)tid]; }
+        if (tile_nx < n_tiles && (uint32_t)tid < k) { c0_nx = p.cut0[(uint64_t)tid * p.cut_ss + (uint64_t)tile_nx * p.cut_st]; c1_nx = p.cut1[(uint64_t)tid * p.cut_ss + (uint64_t)tile_nx * p.cut_st]; }
     };
     fetch_cuts();
     for (uint32_t tile = tile_nx; tile < n_tiles; tile = tile_nx) {
@@ -762,11 +930,11 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                     first = e0.first_doc;
                     if (cutmode) {                    // the run's first / last block may be cut (all four loads are in flight together)
                         if (g == sm.RB[a]) {
-                            const uint4 cs = p.cut0[(uint64_t)tile * k + a];
+                            const uint4 cs = p.cut0[(uint64_t)a * p.cut_ss + (uint64_t)tile * p.cut_st];
                             if (cs.x & CUT_INSIDE) { from = cs.y; first = cs.z; has_first = false; }
                         }
                         if (g + 1u == sm.RB[a + 1u]) {
-                            const uint2 ce = p.cut1[(uint64_t)tile * k + a];
+                            const uint2 ce = p.cut1[(uint64_t)a * p.cut_ss + (uint64_t)tile * p.cut_st];
                             if (ce.x & CUT_INSIDE) to = ce.y;
                         }
                     }
@@ -1282,7 +1450,8 @@ hipError_t launch_merge_tile_desc(const MergeSegs *ms, const MergeParams &p, hip
 }
 hipError_t launch_merge_tile_runs(const MergeSegs *ms, const MergeParams &p, hipStream_t s) {
     if (p.n_tiles_ub == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_merge_tile_runs, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
+    if (p.cut_st == 1u) hipLaunchKernelGGL(k_merge_tile_runs_shared, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
+    else hipLaunchKernelGGL(k_merge_tile_runs, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
     return hipGetLastError();
 }
 hipError_t launch_merge_tiles(const MergeSegs *ms, const MergeParams &p, uint32_t grid, hipStream_t s) {

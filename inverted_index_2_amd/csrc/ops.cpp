@@ -142,6 +142,8 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.desc = (uint4 *)carve<uint8_t>(ac, nt1 * 16);
     p.cut0 = (uint4 *)carve<uint8_t>(ac, nt1 * k * 16);
     p.cut1 = carve<uint2>(ac, nt1 * k);
+    if (k >= 32u) { p.cut_ss = p.n_tiles_ub; p.cut_st = 1u; }      // many lists: bounds share blocks, the plan walks a block once for all of them (merge.hip)
+    else { p.cut_ss = 1u; p.cut_st = k; }
     p.tmp = carve<uint32_t>(ac, postings_ub + 64);
 
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_segs, hs, sizeof(MergeSegs), hipMemcpyHostToDevice, st));
