@@ -18,7 +18,8 @@ ls = [(seg, 0), (seg, 1)]
 out = ctx.empty(b.size + 512)
 cnt = ctx.empty(8, np.uint64)
 _, n = ctx.intersect(ls, out=out)
-assert np.array_equal(out.download(n), np.intersect1d(a, b, assume_unique=True))
+import os
+if not os.environ.get("C2_NOCHECK"): assert np.array_equal(out.download(n), np.intersect1d(a, b, assume_unique=True))
 ctx.sync()
 ctx.profile_region(True)
 for _ in range(steps):
