@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--merge-steps", type=int, default=0, help="timed merges (0: min(steps, 10))")
     ap.add_argument("--cold-pairs", type=int, default=4)
     ap.add_argument("--strong-chunks", type=int, default=4, help="merge_strong: chunks a rank's term range is merged and exchanged in")
+    ap.add_argument("--strong-workers", type=int, default=2,
+                    help="merge_strong: chunks merged side by side, one context (stream + scratch) each - the reference's "
+                         "InvertedIndex.Merge(…, concurrency) fan-out (inverted_index.go:62-109) on one GPU")
     ap.add_argument("--c5-docs", type=int, default=1_000_000_000, help="c5: doc-id universe of the whole index (config 5: 1B)")
     ap.add_argument("--c5-steps", type=int, default=0, help="c5: timed queries (0: min(steps, 20))")
     ap.add_argument("--dry-run", action="store_true",
@@ -624,8 +627,12 @@ def bench_merge_strong(job):
     from concurrent.futures import ThreadPoolExecutor
     from inverted_index_2_amd import sharding, synth
     T, k = args.merge_terms, args.strong_segments
-    ranges = sharding.balanced_term_ranges(T, args.merge_mean, args.docs, world)
+    ranges = sharding.balanced_term_ranges(T, args.merge_mean, args.docs, world, by="cost+encode")      # (merge -> DV1 segment)
     t0, t1 = ranges[rank]
+    pretend = os.environ.get("BENCH_PRETEND")          # "r/N" on one GPU: rank r's share of an N-rank run, without the peers
+    if pretend and world == 1:                          # (what one rank of the N-GPU job computes; scripts/README.md)
+        pr, pn = (int(x) for x in pretend.split("/"))
+        t0, t1 = sharding.balanced_term_ranges(T, args.merge_mean, args.docs, pn, by="cost+encode")[pr]
     offs, vals, removed = synth.merge_workload_big(T, k, args.merge_mean, args.docs, threads=min(cores_available(), 32),
                                                    term_range=(t0, t1))
     n_in_local = int(sum(int(o[-1]) for o in offs))
@@ -658,7 +665,7 @@ def bench_merge_strong(job):
         per_term += np.diff(o.astype(np.int64))
     del offs
     n_chunks = max(1, min(args.strong_chunks, t1 - t0))
-    cum = np.concatenate([[0.0], np.cumsum(sharding.merge_cost_weights(per_term))])
+    cum = np.concatenate([[0.0], np.cumsum(sharding.merge_cost_weights(per_term, encode=True))])
     cuts = [0] + [int(np.searchsorted(cum, cum[-1] * c / n_chunks)) for c in range(1, n_chunks)] + [t1 - t0]
     cuts = [max(a, b) for a, b in zip(cuts, np.maximum.accumulate(cuts))]
     views = []
@@ -708,16 +715,28 @@ def bench_merge_strong(job):
 
     empty_seg = ctx.encode_lists([np.empty(0, np.uint32)]) if world > 1 else None
 
+    # the chunks are merged by `strong-workers` threads side by side, one context each (the segments and the tombstones belong
+    # to the device, not to a context): one chunk's host round trips (sizes of the new segment, its mirrors) hide behind
+    # another chunk's kernels.  Chunks still reach the exchange in term order.
+    n_workers = max(1, min(args.strong_workers, n_chunks))
+    wctx = [ctx] + [Context(ctx.device) for _ in range(n_workers - 1)]
+    wpool = ThreadPoolExecutor(max_workers=n_workers)
+
+    def merge_chunk(ci, vw):
+        if vw is None:
+            return None
+        tq = time.perf_counter()
+        sg, _ = wctx[ci % n_workers].merge_to_segment(vw, tomb)
+        if os.environ.get("BENCH_TRACE"):
+            print("rank %d: merge_to_segment %.2f ms (worker %d)" % (rank, (time.perf_counter() - tq) * 1e3, ci % n_workers), file=sys.stderr, flush=True)
+        return sg
+
     def one_pass(with_exchange):
-        """All chunks of this rank: merge to a segment, hand it to the exchange thread, merge the next."""
+        """All chunks of this rank: merged to segments by the workers, handed to the exchange thread in term order."""
         pending, merged = [], []
-        for vw in views:
-            sg = None
-            if vw is not None:
-                tq = time.perf_counter()
-                sg, _ = ctx.merge_to_segment(vw, tomb)
-                if os.environ.get("BENCH_TRACE"):
-                    print("rank %d: merge_to_segment %.2f ms" % (rank, (time.perf_counter() - tq) * 1e3), file=sys.stderr, flush=True)
+        futs = [wpool.submit(merge_chunk, ci, vw) for ci, vw in enumerate(views)]
+        for f in futs:
+            sg = f.result()
             merged.append(sg)
             if with_exchange:
                 pending.append(pool.submit(exchange, sg))
@@ -772,6 +791,9 @@ def bench_merge_strong(job):
         return time.perf_counter() - t_b
     dt_x = job.max_over_ranks(job.guarded("the merge's segment exchange", timed_with_exchange))
     pool.shutdown()
+    wpool.shutdown()
+    for c in wctx[1:]:
+        c.close()
     tot = job.torch.tensor([float(n_in_local), float(st.n_out)], dtype=job.torch.float64, device=job.dev)
     if world > 1:
         job.dist.all_reduce(tot)
@@ -781,8 +803,8 @@ def bench_merge_strong(job):
         "what": "whole job per step: every rank merges its term range chunk by chunk into DV1 segments and every chunk is exchanged "
                 "encoded with all ranks (overlapped with the next chunk's merge) - the exchange is INSIDE the timed region",
         "config": {"workload": "ONE %d-way segment merge of %d terms x mean %.0f postings (BASELINE configs[3]), terms cut into "
-                               "%d contiguous ranges balanced by estimated merge cost (sharding.merge_cost_weights), %d chunks per rank"
-                               % (k, T, args.merge_mean, world, n_chunks),
+                               "%d contiguous ranges balanced by estimated merge + encode cost (sharding.merge_cost_weights), %d chunks per rank merged by "
+                               "%d worker contexts" % (k, T, args.merge_mean, world, n_chunks, n_workers),
                    "postings_in_total": n_in_total, "postings_out_total": n_out_total,
                    "rank0_terms": [int(t0), int(t1)] if rank == 0 else None, "rank0_postings_in": n_in_local if rank == 0 else None,
                    "parallelism": "terms%d" % world},

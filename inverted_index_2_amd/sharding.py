@@ -54,31 +54,42 @@ def concat_in_rank_order(parts: Sequence[np.ndarray]) -> np.ndarray:
     return np.concatenate(list(parts)) if len(parts) else np.empty(0, np.uint32)
 
 
-# Merge cost per posting by term size, relative to a giant term (measured range by range on one MI355X, round 2,
-# scripts/strong_ranges.py, 64 segments): terms above the tile size run through single-term tiles at the same rate
-# whatever their size, except the densest (a tile's doc range fits the LDS bitmap: ~0.75x); batches of small terms pay
-# per list (block decode, slice tables, scans over T x k counts).  Sizes are for the 100M-doc universe of the configs.
-_COST_LOG10_SIZE = np.array([2.2, 3.0, 3.8, 4.6, 6.0, 6.6])
-_COST_PER_POSTING = np.array([2.7, 2.0, 1.18, 1.0, 1.0, 0.75])
+# Merge cost per posting by term size, relative to a giant term (measured range by range on one MI355X, round 3,
+# scripts/strong_ranges.py 16, 64 segments, 0.2 ms of per-call fixed cost taken off): the densest terms go through bitmap tiles
+# (0.7 - 1.0), everything between ~1M and a few thousand postings through range tiles at about twice that whatever the size,
+# batches of small terms pay per list on top (block set-up, one 16-byte piece per tiny list).  Sizes are for the 100M-doc
+# universe of the configs.  (Round 2's table put the mid-size terms at 1.0 - 1.2: with it the two mid ranks of an 8-way
+# split took 2.8 ms against the head rank's 1.7.)
+_COST_LOG10_SIZE = np.array([1.95, 2.35, 2.75, 3.3, 4.4, 4.9, 5.9, 6.45, 7.1, 7.76])
+_COST_PER_POSTING = np.array([3.2, 2.6, 2.1, 2.0, 2.05, 1.93, 1.78, 1.09, 0.71, 1.0])
 
 
-def merge_cost_weights(sizes: np.ndarray) -> np.ndarray:
-    """Estimated merge cost of every term (arbitrary unit: postings of a giant term)."""
+# DV1-encoding the merged postings (merge -> segment, what Shard.Merge does) costs the same per posting whatever the term:
+# ~0.3 - 0.5 ms per 100M postings against 0.82 ms per 100M for merging a giant term; 0.35 balanced the 8-way split of C4 best
+# (BENCH_PRETEND=r/8 python bench.py --workload strong: 3.6 - 4.1 ms per rank with 0.67, 3.8 - 4.1 with 0).
+_ENCODE_COST_PER_POSTING = 0.35
+
+
+def merge_cost_weights(sizes: np.ndarray, encode: bool = False) -> np.ndarray:
+    """Estimated merge cost of every term (arbitrary unit: postings of a giant term); encode: the result is written as a
+    DV1 segment, not as raw ids."""
     sizes = np.asarray(sizes, dtype=np.float64)
-    return sizes * np.interp(np.log10(np.maximum(sizes, 1.0)), _COST_LOG10_SIZE, _COST_PER_POSTING)
+    per = np.interp(np.log10(np.maximum(sizes, 1.0)), _COST_LOG10_SIZE, _COST_PER_POSTING)
+    return sizes * (per + (_ENCODE_COST_PER_POSTING if encode else 0.0))
 
 
 def balanced_term_ranges(n_terms: int, mean_len: float, universe: int, world: int, by: str = "cost") -> List[Tuple[int, int]]:
     """Contiguous term ranges of the big synthetic merge workload, one per rank, balanced by estimated merge COST
     (by="cost": posting count weighted by merge_cost_weights — a posting of a 160-posting term costs 2.7x one of a giant
-    term, so ranges balanced by posting count alone leave the tail rank 2.5x the head rank's time) or by POSTING count
+    term, so ranges balanced by posting count alone leave the tail rank 2.5x the head rank's time; by="cost+encode": the
+    merged postings are DV1-encoded too, a flat cost per posting on top) or by POSTING count
     (by="postings"; Zipf skew: equal term counts would give rank 0 most of the work — SURVEY §8 e), cut at the
     generator's chunk boundaries so that every rank can generate exactly its own share."""
     from . import synth
     sizes, fine = synth.merge_chunk_bounds(n_terms, mean_len, universe)
-    if by not in ("cost", "postings"):
-        raise ValueError("by must be 'cost' or 'postings'")
-    w = merge_cost_weights(sizes) if by == "cost" else sizes.astype(np.float64)
+    if by not in ("cost", "cost+encode", "postings"):
+        raise ValueError("by must be 'cost', 'cost+encode' or 'postings'")
+    w = merge_cost_weights(sizes, encode=by == "cost+encode") if by != "postings" else sizes.astype(np.float64)
     cum = np.concatenate([[0.0], np.cumsum(w)])
     total = float(cum[-1])
     fine = np.asarray(fine)
