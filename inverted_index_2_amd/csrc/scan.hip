@@ -3,6 +3,7 @@
 //   k_scan_reduce   one workgroup per tile of SCAN_TILE elements -> the tile's sum
 //   k_scan_tiles    one workgroup turns the tile sums into exclusive tile bases (in place)
 //   k_scan_apply    every workgroup rescans its tile from its base and writes the result
+// (an input of one tile - up to 4096 elements - takes k_scan_apply alone)
 // Every thread reads all of its inputs before it writes, so `out` may be `in` (same element type).
 #include "dv1_device.h"
 #include "internal.h"
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TI *in, TO *o
         s += v[j];
     }
     uint64_t tot;
-    uint64_t run = part[blockIdx.x] + wg_excl_scan64(s, wsum, &tot);
+    uint64_t run = (part ? part[blockIdx.x] : 0ull) + wg_excl_scan64(s, wsum, &tot);      // (part == nullptr: the input is one tile)
 #pragma unroll
     for (uint32_t j = 0; j < SCAN_PER_THREAD; j++) {
         if (base + j < n) out[base + j] = (TO)run;
@@ -96,6 +97,10 @@ static hipError_t scan_excl(void *tmp, size_t tmp_bytes, const TI *in, TO *out, 
     const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (tmp_bytes < tiles * sizeof(uint64_t)) return hipErrorInvalidValue;
     uint64_t *part = (uint64_t *)tmp;
+    if (tiles == 1) {       // one launch instead of three: a dependent kernel costs ~5 us whatever it does, and the planners scan a lot of short arrays
+        hipLaunchKernelGGL((k_scan_apply<TI, TO>), dim3(1), dim3(SCAN_THREADS), 0, s, in, out, (uint64_t)n, (const uint64_t *)nullptr, guard, guard_max);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL((k_scan_reduce<TI>), dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, (uint64_t)n, part);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_THREADS), 0, s, part, (uint64_t)tiles);
     hipLaunchKernelGGL((k_scan_apply<TI, TO>), dim3((unsigned)tiles), dim3(SCAN_THREADS), 0, s, in, out, (uint64_t)n, (const uint64_t *)part, guard, guard_max);
