@@ -216,6 +216,33 @@ func (c *Ctx) MergeSmall(segs []*Segment, termBytes []byte, termOff, segFirst []
 	return &Segment{out}, kept[:nKept], nil
 }
 
+// ReadSmall is the small Shard.Read in one launch (ii2_read_small): the merged lists of a few small resident segments —
+// dictionary s names the lists listFirst[s].. of segs[s] (nil: from list 0) — on the host.  rep[j] indexes termOff: an
+// input term equal to merged term j; the ids of term j are values[postOff[j]:postOff[j+1]].  ErrTooLarge as for MergeSmall.
+func (c *Ctx) ReadSmall(segs []*Segment, termBytes []byte, termOff, segFirst, listFirst []uint64, capValues int) (rep, postOff []uint64, values []uint32, err error) {
+	hs := make([]*C.ii2_seg, len(segs))
+	for i, s := range segs {
+		hs[i] = s.h
+	}
+	var tb *C.uint8_t
+	if len(termBytes) > 0 {
+		tb = (*C.uint8_t)(unsafe.Pointer(&termBytes[0]))
+	}
+	rep = make([]uint64, len(termOff))
+	postOff = make([]uint64, len(termOff)+1)
+	values = make([]uint32, capValues+1)
+	var nUnion C.uint64_t
+	rc := C.ii2_read_small(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), tb, u64ptr(termOff), u64ptr(segFirst),
+		u64ptr(listFirst), u64ptr(rep), u64ptr(postOff), u32ptr(values), C.uint64_t(capValues), &nUnion)
+	if rc == C.II2_ERANGE {
+		return nil, nil, nil, ErrTooLarge
+	}
+	if rc != 0 {
+		return nil, nil, nil, c.err("read", rc)
+	}
+	return rep[:nUnion], postOff[:nUnion+1], values[:postOff[nUnion]], nil
+}
+
 // ErrTooLarge: the inputs exceed the one-launch merge's limits (II2_SMALL_MERGE_*).
 var ErrTooLarge = fmt.Errorf("gpu: too large for the one-launch merge")
 

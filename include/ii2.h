@@ -201,6 +201,19 @@ int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const 
                     const uint64_t *seg_first, const uint32_t *removed, uint64_t n_removed, ii2_seg **out, uint64_t *kept,
                     uint64_t *n_kept, ii2_merge_stats *stats);
 
+/* The small Shard.Read in ONE launch (reference shard.go:72-75 -> makeIterator shard.go:253-278: the k-way merging iterator
+ * without the tombstone filter): the merged lists of k small segments straight to host memory — what otherwise takes
+ * ii2_align_terms + k x ii2_seg_select_aligned + ii2_merge_segments + two downloads (1.5 ms for a few hundred bytes).
+ * Dictionary s (flat, as for ii2_merge_small) names the lists list_first[s] .. of segs[s] (a range-restricted read passes
+ * the slice of each segment's terms that lies in [min, max]; list_first == NULL: every dictionary starts at list 0).
+ * Output: *n_union merged terms in bytes.Compare order, EVERY one of them (a read drops nothing); rep[j] (capacity
+ * seg_first[k]) = index into term_off of an input term equal to term j; post_off[j] .. post_off[j + 1] (capacity
+ * seg_first[k] + 1) = its ids in values (capacity cap; II2_ECAPACITY and nothing written when they do not fit).
+ * Limits: II2_SMALL_MERGE_TERMS / II2_SMALL_MERGE_POSTINGS (postings of the whole segments), II2_ERANGE beyond them. */
+int ii2_read_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const uint8_t *term_bytes, const uint64_t *term_off,
+                   const uint64_t *seg_first, const uint64_t *list_first, uint64_t *rep, uint64_t *post_off, uint32_t *values,
+                   uint64_t cap, uint64_t *n_union);
+
 /* Multi-term intersection (build-defined operator, absent in the reference — SURVEY §0 D1):
  * ascending ids present in every list segs[i]/list_idx[i], minus the tombstones when
  * tomb != NULL (tomb == NULL is the reference's Read behaviour).

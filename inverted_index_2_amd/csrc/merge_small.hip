@@ -40,6 +40,7 @@ struct SmallIn {
     uint32_t len[SM_T];          // term lengths
     uint32_t toff[SM_T + 1];     // byte offsets of the terms in tbytes
     uint32_t dfirst[MAX_LISTS + 1];   // first term of each dictionary
+    uint32_t lfirst[MAX_LISTS];       // the segment's list that holds a dictionary's first term (a range-restricted read: a slice of the lists)
     uint32_t removed[SM_R];      // ascending
     uint8_t tbytes[SM_TB];
 };
@@ -49,6 +50,7 @@ struct SmallOut {
     uint32_t kept[SM_T];         // per output list: an input term equal to its term
     uint32_t blk_off[SM_T + 1];  // host mirror of the new segment's list table
     uint32_t spans[3 * SM_T];    // per output list {first doc, first doc of the last block, last doc}
+    uint32_t values[SM_P];       // raw mode (ii2_read_small): the merged ids, list after list (blk_off then holds posting offsets)
 };
 struct SmallSeg { const uint32_t *blk_off; const ii2_skip *skip; const uint8_t *payload; const uint32_t *cnt; };
 struct SmallParams {
@@ -56,6 +58,7 @@ struct SmallParams {
     const SmallIn *in;
     SmallOut *out;
     uint32_t k, n_terms, n_removed, long_terms;
+    uint32_t raw;                 // 1: hand the merged lists back as they are (every union term, empty ones too), no segment
     // the new segment's arrays (sized for the limits)
     uint32_t *o_blk_off; ii2_skip *o_skip; uint8_t *o_payload; uint32_t *o_cnt; uint32_t *o_last; uint32_t *o_blk_list;
 };
@@ -74,7 +77,7 @@ struct __align__(16) SmallSmem {
     uint16_t keptu[SM_T + 1];            // union term of every output list
     uint32_t dead[SM_P / 32 + 1], deadpre[SM_P / 32 + 2];
     uint32_t wsum[SM_THREADS / 64];
-    uint32_t dfirst[MAX_LISTS + 1];
+    uint32_t dfirst[MAX_LISTS + 1], lfirst[MAX_LISTS];
     uint32_t n, nu, err;
 };
 
@@ -97,6 +100,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_merge_small(SmallParams p) {
     const uint32_t nt = p.n_terms, k = p.k;
     // ---- 1. the dictionaries: keys and lengths into LDS, then every term's place in their k-way merge
     if (tid <= k) sm.dfirst[tid] = in->dfirst[tid];
+    if (tid < k) sm.lfirst[tid] = in->lfirst[tid];
     if (tid == 0) { sm.err = 0u; sm.n = 0u; }
     __syncthreads();
     uint32_t my_dict = 0;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_merge_small(SmallParams p) {
     if (tid < nt) {               // thread = place
         const uint32_t g = sm.order[tid];
         my_s = sm.dict[g];
-        my_li = g - sm.dfirst[my_s];
+        my_li = g - sm.dfirst[my_s] + sm.lfirst[my_s];
         const SmallSeg sg = p.seg[my_s];
         my_b0 = sg.blk_off[my_li];
         my_nb = sg.blk_off[my_li + 1u] - my_b0;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(SM_THREADS) void k_merge_small(SmallParams p) {
     for (uint32_t pl = wv; pl < nt; pl += SM_THREADS / 64u) {
         const uint32_t base = sm.lbase[pl], cnt = sm.lbase[pl + 1u] - base;
         if (cnt <= 1u) continue;                      // (decided in LDS: no memory round trip for the lists done above)
-        const uint32_t g = sm.order[pl], s = sm.dict[g], li = g - sm.dfirst[s];
+        const uint32_t g = sm.order[pl], s = sm.dict[g], li = g - sm.dfirst[s] + sm.lfirst[s];
         const SmallSeg sg = p.seg[s];
         const uint32_t b0 = sg.blk_off[li], nb = sg.blk_off[li + 1u] - b0;
         for (uint32_t j = 0; j < nb; j++) {
@@ -251,10 +255,11 @@ __global__ __launch_bounds__(SM_THREADS) void k_merge_small(SmallParams p) {
             const uint32_t a = sm.lbase[sm.uhead[tid]], b = sm.lbase[sm.uhead[tid + 1u]];
             c = (b - a) - (dead_before(b) - dead_before(a));
         }
+        const bool keep = tid < nu && (c != 0u || p.raw);       // (a read hands every term back, a merge drops the emptied ones)
         uint32_t n_kept;
-        const uint32_t kx = sm_scan(c ? 1u : 0u, sm.wsum, &n_kept);
+        const uint32_t kx = sm_scan(keep ? 1u : 0u, sm.wsum, &n_kept);
         __syncthreads();
-        if (tid < nu && c) {
+        if (keep) {
             sm.keptu[kx] = (uint16_t)tid;
             sm.tcnt[kx] = (uint16_t)c;                               // (<= 8192)
             p.out->kept[kx] = sm.order[sm.uhead[tid]];               // the term of the union term's first place stands for it
@@ -267,6 +272,16 @@ __global__ __launch_bounds__(SM_THREADS) void k_merge_small(SmallParams p) {
         if (!(ed[j] >> 31)) sm.E[ed[j] - dead_before(ed[j])] = ev[j];
     __syncthreads();
     const uint32_t T2 = sm.nu;
+    if (p.raw) {                 // ---- a read: the merged lists as they are
+        SmallOut *o = p.out;
+        for (uint32_t e = tid; e < n_out; e += SM_THREADS) o->values[e] = sm.E[e];
+        const uint32_t c_r = tid < T2 ? sm.tcnt[tid] : 0u;
+        uint32_t tot_r;
+        const uint32_t off_r = sm_scan(c_r, sm.wsum, &tot_r);
+        if (tid < T2) o->blk_off[tid] = off_r;
+        if (tid == 0) { o->blk_off[T2] = tot_r; o->n_terms_out = T2; o->n_out = n_out; o->n_blocks = 0; o->n_bytes = 0; o->n_in = n; o->error = 0; }
+        return;
+    }
     // ---- 5. encode.  Output list j: c_j postings from fo_j on; its blocks; gaps as varints
     uint32_t c_j = tid < T2 ? sm.tcnt[tid] : 0u;
     uint32_t fo_tot, bo_tot;
@@ -351,14 +366,14 @@ static int fail(ii2_ctx *ctx, int code, const char *msg) {
 }
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const uint8_t *term_bytes, const uint64_t *term_off,
-                               const uint64_t *seg_first, const uint32_t *removed, uint64_t n_removed, ii2_seg **out, uint64_t *kept,
-                               uint64_t *n_kept, ii2_merge_stats *stats) {
-    if (!ctx || !segs || !term_off || !seg_first || !out || !kept || !n_kept || k == 0 || k > MAX_LISTS || (n_removed && !removed))
-        return fail(ctx, II2_EINVAL, "ii2_merge_small: bad argument");
+// Both entry points: the merge (out: a new segment; emptied terms dropped) and the read (raw: post_off / values on the host,
+// every union term).  list_first (may be NULL): the list of segment s that holds its dictionary's first term.
+static int small_core(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const uint8_t *term_bytes, const uint64_t *term_off,
+                      const uint64_t *seg_first, const uint64_t *list_first, const uint32_t *removed, uint64_t n_removed, bool raw,
+                      ii2_seg **out, uint64_t *kept, uint64_t *n_kept, ii2_merge_stats *stats, uint64_t *post_off, uint32_t *values, uint64_t cap) {
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    *out = nullptr;
+    if (out) *out = nullptr;
     *n_kept = 0;
     const uint64_t n = seg_first[k];
     if (seg_first[0] != 0) return fail(ctx, II2_EINVAL, "ii2_merge_small: seg_first[0] must be 0");
@@ -366,7 +381,9 @@ extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *s
     uint64_t n_post = 0;
     for (uint32_t s = 0; s < k; s++) {
         if (!segs[s] || segs[s]->device != ctx->device) return fail(ctx, II2_EINVAL, "ii2_merge_small: a segment is NULL or lives on another device");
-        if (seg_first[s + 1] < seg_first[s] || segs[s]->n_lists != seg_first[s + 1] - seg_first[s])
+        const uint64_t lf = list_first ? list_first[s] : 0;
+        if (seg_first[s + 1] < seg_first[s] || lf > segs[s]->n_lists || seg_first[s + 1] - seg_first[s] > segs[s]->n_lists - lf ||
+            (!list_first && segs[s]->n_lists != seg_first[s + 1] - seg_first[s]))
             return fail(ctx, II2_EINVAL, "ii2_merge_small: every segment must have one list per term of its dictionary");
         n_post += segs[s]->n_postings;
     }
@@ -392,6 +409,7 @@ extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *s
     }
     hi->toff[n] = n ? (uint32_t)term_off[n] : 0u;
     for (uint32_t s = 0; s <= k; s++) hi->dfirst[s] = (uint32_t)seg_first[s];
+    for (uint32_t s = 0; s < k; s++) hi->lfirst[s] = list_first ? (uint32_t)list_first[s] : 0u;
     if (n && term_off[n]) std::memcpy(hi->tbytes, term_bytes, term_off[n]);
     if (n_removed) {
         std::memcpy(hi->removed, removed, n_removed * sizeof(uint32_t));
@@ -406,26 +424,34 @@ extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *s
                  o_cnt = o_pay + up256((size_t)SM_P * 5 + 16), o_last = o_cnt + up256((SM_T + 1) * sizeof(uint32_t)), o_bl = o_last + up256((SM_T + 1) * sizeof(uint32_t)),
                  slab_bytes = o_bl + up256((SM_NB + 1) * sizeof(uint32_t));
     uint8_t *slab = nullptr;
-    if (dm_alloc((void **)&slab, slab_bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "ii2_merge_small: segment allocation failed");
+    if (!raw && dm_alloc((void **)&slab, slab_bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "ii2_merge_small: segment allocation failed");
     SmallParams p;
     std::memset(&p, 0, sizeof p);
     for (uint32_t s = 0; s < k; s++) p.seg[s] = SmallSeg{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt};
     p.in = (const SmallIn *)ctx->d_small_in;
     p.out = (SmallOut *)ctx->d_small_out;
     p.k = k; p.n_terms = (uint32_t)n; p.n_removed = (uint32_t)n_removed; p.long_terms = long_terms;
+    p.raw = raw ? 1u : 0u;
     p.o_blk_off = (uint32_t *)(slab + o_blk); p.o_skip = (ii2_skip *)(slab + o_skip); p.o_payload = slab + o_pay;
     p.o_cnt = (uint32_t *)(slab + o_cnt); p.o_last = (uint32_t *)(slab + o_last); p.o_blk_list = (uint32_t *)(slab + o_bl);
     hipLaunchKernelGGL(k_merge_small, dim3(1), dim3(SM_THREADS), 0, st, p);
     SmallOut *ho = (SmallOut *)ctx->h_small_out;
     hipError_t e = hipGetLastError();
     // sizes first (they say how much of the rest matters) would be a second round trip: the whole block is 12 KB, take it in one
-    if (e == hipSuccess) e = hipMemcpyAsync(ho, ctx->d_small_out, sizeof(SmallOut), hipMemcpyDeviceToHost, st);
+    // (a read also takes the merged ids: at most as many as the lists hold)
+    if (e == hipSuccess) e = hipMemcpyAsync(ho, ctx->d_small_out, offsetof(SmallOut, values) + (raw ? n_post * sizeof(uint32_t) : 0), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { dm_free(slab); ctx->err = std::string("ii2_merge_small: ") + hipGetErrorString(e); return II2_EHIP; }
     if (ho->error) { dm_free(slab); return fail(ctx, II2_ERANGE, "ii2_merge_small: the lists hold more postings than the one-launch merge takes"); }
     if (stats) { stats->n_in = ho->n_in; stats->n_out = ho->n_out; stats->n_terms_out = ho->n_terms_out; stats->n_tiles = 1; }
     *n_kept = ho->n_terms_out;
     for (uint64_t j = 0; j < ho->n_terms_out; j++) kept[j] = ho->kept[j];
+    if (raw) {
+        if (ho->n_out > cap) return fail(ctx, II2_ECAPACITY, "ii2_read_small: the values buffer is too small; nothing was written");
+        for (uint64_t j = 0; j <= ho->n_terms_out; j++) post_off[j] = ho->blk_off[j];
+        if (ho->n_out) std::memcpy(values, ho->values, ho->n_out * sizeof(uint32_t));
+        return II2_OK;
+    }
     if (ho->n_terms_out == 0) { dm_free(slab); return II2_OK; }        // shard.go:219-225: nothing survives, no segment is written
     ii2_seg *seg = new (std::nothrow) ii2_seg();
     if (!seg) { dm_free(slab); return II2_ENOMEM; }
@@ -442,4 +468,22 @@ extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *s
     seg->h_spans.assign(ho->spans, ho->spans + 3 * seg->n_lists);
     *out = seg;
     return II2_OK;
+}
+
+extern "C" int ii2_merge_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const uint8_t *term_bytes, const uint64_t *term_off,
+                               const uint64_t *seg_first, const uint32_t *removed, uint64_t n_removed, ii2_seg **out, uint64_t *kept,
+                               uint64_t *n_kept, ii2_merge_stats *stats) {
+    if (!ctx || !segs || !term_off || !seg_first || !out || !kept || !n_kept || k == 0 || k > MAX_LISTS || (n_removed && !removed))
+        return fail(ctx, II2_EINVAL, "ii2_merge_small: bad argument");
+    return small_core(ctx, k, segs, term_bytes, term_off, seg_first, nullptr, removed, n_removed, false, out, kept, n_kept, stats, nullptr, nullptr, 0);
+}
+
+// The small Shard.Read (reference shard.go:72-75 -> makeIterator shard.go:253-278, a3 without the tombstone filter): the
+// merged lists of k small segments, range-restricted by the caller's dictionaries, straight to host memory in one launch.
+extern "C" int ii2_read_small(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, const uint8_t *term_bytes, const uint64_t *term_off,
+                              const uint64_t *seg_first, const uint64_t *list_first, uint64_t *rep, uint64_t *post_off, uint32_t *values,
+                              uint64_t cap, uint64_t *n_union) {
+    if (!ctx || !segs || !term_off || !seg_first || !rep || !post_off || !n_union || (cap && !values) || k == 0 || k > MAX_LISTS)
+        return fail(ctx, II2_EINVAL, "ii2_read_small: bad argument");
+    return small_core(ctx, k, segs, term_bytes, term_off, seg_first, list_first, nullptr, 0, true, nullptr, rep, n_union, nullptr, post_off, values, cap);
 }

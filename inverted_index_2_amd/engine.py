@@ -313,6 +313,29 @@ class Context:
         terms = [flat[int(g)] for g in kept[: n_kept.value]]
         return (Segment(self, out) if out.value else None), terms, st
 
+    def read_small(self, segs: Sequence["Segment"], dictionaries, list_first=None):
+        """The small Shard.Read in one launch (ii2_read_small): the merged lists of k small segments (dictionaries[s] names the
+        lists list_first[s] .. of segs[s]) on the host.  Returns (terms, post_off, values)."""
+        flat = [t for d in dictionaries for t in d]
+        off = np.zeros(len(flat) + 1, np.uint64)
+        if flat:
+            off[1:] = np.cumsum([len(t) for t in flat])
+        blob = np.frombuffer(b"".join(flat) + b"\0", dtype=np.uint8).copy()
+        first = np.zeros(len(dictionaries) + 1, np.uint64)
+        first[1:] = np.cumsum([len(d) for d in dictionaries])
+        lf = _np(list_first, np.uint64) if list_first is not None else None
+        arr = (C.c_void_p * len(segs))(*[s.h for s in segs])
+        cap = int(sum(s.info.n_postings for s in segs))
+        rep = np.zeros(max(len(flat), 1), np.uint64)
+        post_off = np.zeros(len(flat) + 1, np.uint64)
+        values = np.zeros(max(cap, 1), np.uint32)
+        n_union = C.c_uint64()
+        self._ck(self.lib.ii2_read_small(self.h, len(segs), arr, _ptr(blob), _ptr(off), _ptr(first), _ptr(lf) if lf is not None else None,
+                                         rep.ctypes.data_as(C.POINTER(C.c_uint64)), post_off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         _ptr(values), cap, C.byref(n_union)))
+        nu = n_union.value
+        return [flat[int(g)] for g in rep[:nu]], post_off[: nu + 1].copy(), values[: int(post_off[nu])].copy()
+
     def merge_host(self, seg_offs, seg_vals, removed=()):
         k = len(seg_offs)
         offs = [_np(o, np.uint64) for o in seg_offs]

@@ -467,9 +467,49 @@ class Shard {
         }
     }
 
+    // The small read in one launch (ii2_read_small): a few small segments, the slice of each one's terms that lies in
+    // [min, max].  false: over the limits, take the general path.
+    bool read_small(const std::vector<const Segment *> &segs, const Term *min, const Term *max, std::vector<TermValues> *out) const {
+        if (segs.empty() || segs.size() > II2_MAX_LISTS) return false;
+        std::string bytes;
+        std::vector<uint64_t> off{0}, first{0}, lfirst;
+        std::vector<const ii2_seg *> hs;
+        uint64_t n_post = 0;
+        for (auto *sg : segs) {
+            size_t j0 = 0, j1 = sg->terms.size();
+            if (min) j0 = std::lower_bound(sg->terms.begin(), sg->terms.end(), *min, term_less) - sg->terms.begin();
+            if (max) j1 = std::upper_bound(sg->terms.begin(), sg->terms.end(), *max, term_less) - sg->terms.begin();
+            if (j0 >= j1) continue;                // segment has nothing in range: skipped (shard.go:257-261)
+            ii2_seg_info info;
+            ii2_seg_get_info(sg->seg->h, &info);
+            n_post += info.n_postings;
+            if (off.size() - 1 + (j1 - j0) > II2_SMALL_MERGE_TERMS || n_post > II2_SMALL_MERGE_POSTINGS) return false;
+            for (size_t j = j0; j < j1; j++) { bytes += sg->terms[j]; off.push_back(bytes.size()); }
+            if (bytes.size() > 16384) return false;
+            first.push_back(off.size() - 1);
+            lfirst.push_back(j0);
+            hs.push_back(sg->seg->h);
+        }
+        if (hs.empty()) return true;                // nothing in range: an empty read
+        const uint64_t n = off.size() - 1;
+        std::vector<uint64_t> rep(n), po(n + 1);
+        std::vector<uint32_t> vals(n_post + 1);
+        uint64_t nu = 0;
+        const int rc = ii2_read_small(ctx_, (uint32_t)hs.size(), hs.data(), (const uint8_t *)bytes.data(), off.data(), first.data(), lfirst.data(),
+                                      rep.data(), po.data(), vals.data(), n_post, &nu);
+        if (rc == II2_ERANGE) return false;
+        ck(ctx_, rc, "index read");
+        out->reserve(nu);
+        for (uint64_t u = 0; u < nu; u++)
+            out->push_back(TermValues{Term(bytes.data() + off[rep[u]], off[rep[u] + 1] - off[rep[u]]),
+                                      std::vector<uint32_t>(vals.begin() + po[u], vals.begin() + po[u + 1])});
+        return true;
+    }
+
     std::vector<TermValues> merged(const std::vector<const Segment *> &segs, const Term *min, const Term *max,
                                    const std::vector<uint32_t> *removed) const {
         std::vector<TermValues> out;
+        if (!removed && read_small(segs, min, max, &out)) return out;
         Aligned a = align(ctx_, segs, min, max);
         if (a.views.empty()) return out;
         fold_to_limit(ctx_, a.views);

@@ -99,3 +99,58 @@ def test_limits_are_refused_not_truncated(ctx):
     assert e.value.code == -5                                              # > 512 terms
     with pytest.raises(II2Error):
         ctx.merge_small([ctx.encode_lists([np.array([1], np.uint32)] * 2)], [[b"a"]])      # lists and terms disagree
+
+
+def want_read(dicts, lists):
+    """[(term, merged ids)] in term order, every term kept (a read drops nothing)."""
+    union = sorted(set(t for d in dicts for t in d), key=functools.cmp_to_key(orc.compare_terms))
+    out = []
+    for t in union:
+        parts = [lists[s][d.index(t)] for s, d in enumerate(dicts) if t in d]
+        out.append((t, np.unique(np.concatenate(parts)).astype(np.uint32)))
+    return out
+
+
+@pytest.mark.parametrize("k,n_terms,max_len", [(1, 4, 3), (2, 3, 1), (8, 30, 20), (64, 6, 3), (3, 100, 40)])
+def test_small_read_is_the_merge_without_filter_or_drop(ctx, k, n_terms, max_len):
+    """ii2_read_small (Shard.Read of a few small segments in one launch): the k-way merge of the dictionaries, same-term
+    union, every term handed back - also the ones whose lists are empty - straight to host memory."""
+    rng = np.random.default_rng(4000 + k * 7 + n_terms)
+    vocab = [bytes(rng.integers(97, 100, int(rng.integers(1, 12))).astype(np.uint8)) for _ in range(3 * n_terms)]
+    vocab = sorted(set(vocab), key=functools.cmp_to_key(orc.compare_terms))
+    dicts, lists = [], []
+    for s in range(k):
+        d = sorted(set(vocab[i] for i in rng.choice(len(vocab), min(n_terms, len(vocab)), replace=False)), key=functools.cmp_to_key(orc.compare_terms))
+        dicts.append(d)
+        lists.append([sorted_unique(rng, int(rng.integers(0, max_len + 1)), 5000) for _ in d])
+    segs = [ctx.encode_lists(ls) for ls in lists]
+    terms, po, vals = ctx.read_small(segs, dicts)
+    want = want_read(dicts, lists)
+    assert terms == [t for t, _ in want]
+    assert np.array_equal(np.diff(po.astype(np.int64)), [w.size for _, w in want])
+    assert np.array_equal(vals, np.concatenate([w for _, w in want] + [np.empty(0, np.uint32)]))
+    # a range-restricted read: a slice of every segment's terms (list_first shifts into the segment)
+    lo_t, hi_t = vocab[len(vocab) // 4], vocab[(3 * len(vocab)) // 4]
+    cmpf = orc.compare_terms
+    sl, lf, sub_lists = [], [], []
+    for d, ls in zip(dicts, lists):
+        idx = [j for j, t in enumerate(d) if cmpf(t, lo_t) >= 0 and cmpf(t, hi_t) <= 0]
+        sl.append([d[j] for j in idx])
+        lf.append(idx[0] if idx else 0)
+        sub_lists.append([ls[j] for j in idx])
+    terms2, po2, vals2 = ctx.read_small(segs, sl, lf)
+    want2 = want_read(sl, sub_lists)
+    assert terms2 == [t for t, _ in want2]
+    assert np.array_equal(np.diff(po2.astype(np.int64)), [w.size for _, w in want2])
+    assert np.array_equal(vals2, np.concatenate([w for _, w in want2] + [np.empty(0, np.uint32)]))
+
+
+def test_small_read_limits(ctx):
+    rng = np.random.default_rng(9)
+    big = [sorted_unique(rng, 5000, 1 << 20), sorted_unique(rng, 5000, 1 << 20)]
+    seg = ctx.encode_lists(big)
+    with pytest.raises(II2Error):
+        ctx.read_small([seg], [[b"a", b"b"]])                 # 10000 postings: over II2_SMALL_MERGE_POSTINGS
+    small = ctx.encode_lists([np.array([1, 2], np.uint32)])
+    with pytest.raises(II2Error):
+        ctx.read_small([small], [[b"a", b"b"]])               # the dictionary names more lists than the segment has
