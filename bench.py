@@ -592,7 +592,7 @@ def bench_merge(job):
         t0 = time.perf_counter()
         al = ctx.align_dicts(res_dicts)
         t1 = time.perf_counter()
-        views = [ctx.select_aligned(c, al, i) for i, c in enumerate(compact)]
+        views = ctx.select_aligned_all(compact, al)
         t2 = time.perf_counter()
         _, _, st2 = ctx.merge(views, tomb, out_off, out_vals)
         t3 = time.perf_counter()

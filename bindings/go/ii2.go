@@ -148,6 +148,23 @@ func (c *Ctx) SelectAligned(seg *Segment, a *Alignment, s int, firstList uint64)
 	return &Segment{v}, nil
 }
 
+// SelectAlignedAll builds the views of all the alignment's dictionaries in one call (one wait instead of one per view).
+func (c *Ctx) SelectAlignedAll(segs []*Segment, a *Alignment, firstList []uint64) ([]*Segment, error) {
+	hs := make([]*C.ii2_seg, len(segs))
+	for i, s := range segs {
+		hs[i] = s.h
+	}
+	outs := make([]*C.ii2_seg, len(segs))
+	if rc := C.ii2_seg_select_aligned_all(c.h, (**C.ii2_seg)(unsafe.Pointer(&hs[0])), a.h, u64ptr(firstList), (**C.ii2_seg)(unsafe.Pointer(&outs[0]))); rc != 0 {
+		return nil, c.err("select", rc)
+	}
+	vs := make([]*Segment, len(outs))
+	for i, h := range outs {
+		vs[i] = &Segment{h}
+	}
+	return vs, nil
+}
+
 func (a *Alignment) Free() { C.ii2_align_free(a.h); a.h = nil }
 
 // Dictionary is a segment's sorted, duplicate-free term dictionary resident in HBM (ii2_dict): made once, when the

@@ -151,6 +151,10 @@ int ii2_align_export(ii2_ctx *ctx, const ii2_align *a, uint64_t *rep, int64_t *s
  * Same result as ii2_seg_select with row s of src_list, without the mapping ever visiting the host. */
 int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a, uint32_t s,
                            uint64_t first_list, ii2_seg **out);
+/* The views of ALL k dictionaries of the alignment in one call: srcs[s] / first_list[s] (NULL: 0 for every one) as above,
+ * outs[k].  The same kernels with one wait at the end instead of one per view; all-or-nothing (outs are NULL on error). */
+int ii2_seg_select_aligned_all(ii2_ctx *ctx, const ii2_seg *const *srcs, const ii2_align *a, const uint64_t *first_list,
+                               ii2_seg **outs);
 void ii2_align_free(ii2_align *a);
 
 int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info);

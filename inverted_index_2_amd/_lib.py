@@ -56,6 +56,7 @@ PROTOTYPES = {
     "ii2_align_info": (C.c_int, [vp, u64p, C.POINTER(C.c_uint32)]),
     "ii2_align_export": (C.c_int, [vp, vp, vp, vp]),
     "ii2_seg_select_aligned": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint64, vpp]),
+    "ii2_seg_select_aligned_all": (C.c_int, [vp, vpp, vp, vp, vpp]),
     "ii2_align_free": (None, [vp]),
     "ii2_seg_get_info": (C.c_int, [vp, C.POINTER(SegInfo)]),
     "ii2_seg_free": (None, [vp]),

@@ -451,11 +451,9 @@ int ii2_align_export(ii2_ctx *ctx, const ii2_align *a, uint64_t *rep, int64_t *s
     return II2_OK;
 }
 
-int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a, uint32_t s, uint64_t first_list, ii2_seg **out) {
-    if (!ctx || !src || !a || !out || s >= a->k || src->device != ctx->device || a->device != ctx->device)
-        return fail(ctx, II2_EINVAL, "ii2_seg_select_aligned: bad argument");
-    std::lock_guard<std::mutex> g(ctx->mu);
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
+// one aligned view (ctx->mu held); wait: the stream is synchronised before the view is handed out (a batch waits once, at its end:
+// the views' kernels follow each other on the context's stream, so they may share the scratch)
+static int select_aligned_one(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a, uint32_t s, uint64_t first_list, ii2_seg **out, bool wait) {
     *out = nullptr;
     const uint64_t n_dict = a->seg_first[s + 1] - a->seg_first[s];
     if (first_list + n_dict > src->n_lists) return fail(ctx, II2_EINVAL, "ii2_seg_select_aligned: the dictionary does not fit the segment's lists");
@@ -489,13 +487,40 @@ int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a,
                                (const uint32_t *)(a->d_uidx + a->seg_first[s]), d_blk_list);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess && wait) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
         dm_free(d_blk_off); dm_free(d_cnt); dm_free(d_last); dm_free(d_blk_list);
         ctx->err = std::string("ii2_seg_select_aligned: ") + hipGetErrorString(e);
         return II2_EHIP;
     }
     return ii2_seg_adopt_view(ctx, src, nu, d_blk_off, d_cnt, d_last, d_blk_list, out);
+}
+
+int ii2_seg_select_aligned(ii2_ctx *ctx, const ii2_seg *src, const ii2_align *a, uint32_t s, uint64_t first_list, ii2_seg **out) {
+    if (!ctx || !src || !a || !out || s >= a->k || src->device != ctx->device || a->device != ctx->device)
+        return fail(ctx, II2_EINVAL, "ii2_seg_select_aligned: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return select_aligned_one(ctx, src, a, s, first_list, out, true);
+}
+
+// all k views of an alignment in one call: the same kernels, one wait at the end instead of one per view
+int ii2_seg_select_aligned_all(ii2_ctx *ctx, const ii2_seg *const *srcs, const ii2_align *a, const uint64_t *first_list, ii2_seg **outs) {
+    if (!ctx || !srcs || !a || !outs || a->device != ctx->device) return fail(ctx, II2_EINVAL, "ii2_seg_select_aligned_all: bad argument");
+    std::lock_guard<std::mutex> g(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (uint32_t s = 0; s < a->k; s++) outs[s] = nullptr;
+    int rc = II2_OK;
+    for (uint32_t s = 0; s < a->k && !rc; s++) {
+        if (!srcs[s] || srcs[s]->device != ctx->device) rc = fail(ctx, II2_EINVAL, "ii2_seg_select_aligned_all: a segment is NULL or lives on another device");
+        else rc = select_aligned_one(ctx, srcs[s], a, s, first_list ? first_list[s] : 0, &outs[s], false);
+    }
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, II2_EHIP, "ii2_seg_select_aligned_all: sync failed");
+    if (rc) {
+        (void)hipStreamSynchronize(ctx->stream);            // (nothing of a failed batch is still being written when its views go)
+        for (uint32_t s = 0; s < a->k; s++) { if (outs[s]) ii2_seg_free(outs[s]); outs[s] = nullptr; }
+    }
+    return rc;
 }
 
 void ii2_align_free(ii2_align *a) {

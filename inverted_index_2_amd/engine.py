@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import sys
-from typing import Optional, Sequence
+from typing import List, Optional, Sequence
 
 import numpy as np
 
@@ -230,6 +230,14 @@ class Context:
         out = C.c_void_p()
         self._ck(self.lib.ii2_seg_select_aligned(self.h, seg.h, alignment.h, s, first_list, C.byref(out)))
         return Segment(self, out)
+
+    def select_aligned_all(self, segs: Sequence["Segment"], alignment: "Alignment", first_list=None) -> List["Segment"]:
+        """The aligned views of all the alignment's dictionaries in one call (ii2_seg_select_aligned_all)."""
+        arr = (C.c_void_p * len(segs))(*[s.h for s in segs])
+        outs = (C.c_void_p * len(segs))()
+        fl = _np(first_list, np.uint64) if first_list is not None else None
+        self._ck(self.lib.ii2_seg_select_aligned_all(self.h, arr, alignment.h, _ptr(fl) if fl is not None else None, outs))
+        return [Segment(self, C.c_void_p(h)) for h in outs]
 
     def select(self, seg: "Segment", src_list) -> "Segment":
         src = _np(src_list, np.int64)

@@ -426,11 +426,12 @@ class Shard {
             ck(ctx, ii2_align_export(ctx, al, rep.data(), nullptr), "index read");
             a.terms.reserve(nu);
             for (uint64_t u = 0; u < nu; u++) a.terms.emplace_back(bytes.data() + off[rep[u]], off[rep[u] + 1] - off[rep[u]]);
-            for (size_t i = 0; i < parts.size(); i++) {
-                ii2_seg *v = nullptr;
-                ck(ctx, ii2_seg_select_aligned(ctx, parts[i].seg->seg->h, al, (uint32_t)i, parts[i].j0, &v), "index read");
-                a.views.push_back(std::make_shared<SegHandle>(v));
-            }
+            std::vector<const ii2_seg *> srcs;
+            std::vector<uint64_t> fl;
+            for (auto &pt : parts) { srcs.push_back(pt.seg->seg->h); fl.push_back(pt.j0); }
+            std::vector<ii2_seg *> vs(parts.size(), nullptr);
+            ck(ctx, ii2_seg_select_aligned_all(ctx, srcs.data(), al, fl.data(), vs.data()), "index read");     // (one wait for all the views)
+            for (ii2_seg *v : vs) a.views.push_back(std::make_shared<SegHandle>(v));
             return a;
         }
         // more than II2_MAX_LISTS segments: union dictionary on the host, views through ii2_seg_select

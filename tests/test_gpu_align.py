@@ -101,7 +101,8 @@ def test_aligned_views_feed_the_merge(ctx):
         offs.append(off)
         vals.append(np.concatenate([lists[s][j] for j in src[s] if j >= 0]) if any(j >= 0 for j in src[s]) else np.empty(0, np.uint32))
     w_off, w_vals, _ = orc.merge_segments(offs, vals, removed)
-    for vs in (views, host_views):
+    batch_views = ctx.select_aligned_all(segs, al)            # all k views in one call: same views
+    for vs in (views, host_views, batch_views):
         out_off, out_vals, st = ctx.merge(vs, tomb)
         assert np.array_equal(out_off.download(), w_off) and np.array_equal(out_vals.download(int(st.n_out)), w_vals)
     # a dictionary that is a slice of a segment's terms (range-restricted Read): first_list shifts the view
