@@ -274,10 +274,10 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             // sums are recomputed in the loops below: one v_sad_u8 each, cheaper than sixteen live registers)
             uint32_t acc = 0, wide = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 16u; k++) {
-                const uint32_t gs = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u);
-                wide |= gs;                                                      // a group sum >= 32 sets a bit above bit 4
-                acc += gs;
+            for (uint32_t k = 0; k < 16u; k += 2u) {                             // (two groups per step: three-input or / add)
+                const uint32_t g0 = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u), g1 = __builtin_amdgcn_sad_u8(ww[k + 1u], 0u, 0u);
+                wide |= g0 | g1;                                                 // a group sum >= 32 sets a bit above bit 4
+                acc += g0 + g1;
             }
             // exclusive scan of the lane sums inside the row's four lanes (quad permutes)
             const uint32_t s = live ? acc : 0u;
@@ -299,11 +299,13 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             // link-time constant that ends up in the ds instruction's offset field: no address add per group)
             uint32_t *lds_all = &lds[0][0];
             const uint32_t bmbits = (uint32_t)(bm - lds_all) * 32u;
-            auto lds_word = [&](uint32_t q) -> uint32_t * { return lds_all + ((bmbits + q) >> 5); };
             if (act) {
                 // a group's mask starts AT the posting before it (bit 0 = position q: the block's first doc for the row's
                 // first lane, else a posting an earlier group already set — setting it again is harmless)
-                uint32_t q = u;
+                // (q carries the bitmap's bit offset inside the workgroup's LDS array - a multiple of 32, so q & 31 is unchanged -:
+                // one add per lane instead of one per group)
+                uint32_t q = u + bmbits;
+                const uint32_t limb = lim + bmbits;
 #pragma unroll
                 for (uint32_t k = 0; k < 16u; k++) {
                     const uint32_t x = ww[k];
@@ -314,11 +316,12 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
                     M = (M << ((x >> 8) & 31u)) | 1u;
                     M = (M << (x & 31u)) | 1u;                                   // bit 0: the posting before the group
                     M = isw ? 0u : M;
-                    const uint32_t qc = q < lim ? q : lim;                       // groups beyond the window: harmless bits in the guard
+                    const uint32_t qc = q < limb ? q : limb;                     // groups beyond the window: harmless bits in the guard
                     const uint32_t sh = qc & 31u;
-                    uint32_t *dst = lds_word(qc);
-                    atomicOr(dst, M << sh);
-                    atomicOr(dst + 1, (M >> 1) >> (31u - sh));                   // the part that spills into the next word (0 for most)
+                    uint32_t *dst = lds_all + (qc >> 5);
+                    const unsigned long long m64 = (unsigned long long)M << sh;    // (one 64-bit shift: both words)
+                    atomicOr(dst, (uint32_t)m64);
+                    atomicOr(dst + 1, (uint32_t)(m64 >> 32));                    // the part that spills into the next word (0 for most)
                     q += gs;
                 }
             }
