@@ -389,15 +389,8 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             for (uint32_t i = 4u * (uint32_t)l; i < ncl; i += 256u) *reinterpret_cast<uint4 *>(&bm[i]) = make_uint4(0, 0, 0, 0);
         };
 
-        Pass P = gen();
-        Bytes B = fetch(P);
-        II2_STAMP(0)          // prologue: searches, first entries, first fetch issued
-        while (P.flags & PF_VALID) {
-            if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            II2_STAMP(2)      // waiting for the prefetched payload
-            const Pass Q = gen();
-            const Bytes Bq = fetch(Q);                        // in flight while P is marked
-            II2_STAMP(1)      // generator + fetch issue
+        // one pass: clear / fold, mark, and the window's result when it was the window's last pass
+        auto run_pass = [&](const Pass &P, const Bytes &B) {
             const uint32_t nw = (P.wspan >> 5) + 1u;
             const uint32_t ncl = nw + 2u * (DN_GU / 32u) + 2u;   // <= DN_NW - 2; cleared in 4-word steps
             if (P.flags & PF_FIRST) { clear(bmA, ncl); if (!UNION) clear(bmB, ncl); }
@@ -410,8 +403,27 @@ __global__ __launch_bounds__(256) void k_dense_tiles(DenseParams p) {
             II2_STAMP(4)      // mark
             if (P.flags & PF_LAST) finalise(P.wlo, P.wspan, P.lowbits);
             II2_STAMP(5)      // finalise
-            P = Q;
-            B = Bq;
+        };
+        // Two passes per trip, their roles swapped: while P is marked, Q (entries + payload) is in flight, and the other way
+        // round - the pass that was fetched ahead is marked where it sits (moving it into "the current pass" was 30 register
+        // copies per pass, in a kernel that is VALU-issue-bound).
+        Pass P = gen();
+        Bytes B = fetch(P);
+        II2_STAMP(0)          // prologue: searches, first entries, first fetch issued
+        while (P.flags & PF_VALID) {
+            if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            II2_STAMP(2)      // waiting for the prefetched payload
+            Pass Q = gen();
+            Bytes Bq = fetch(Q);                              // in flight while P is marked
+            II2_STAMP(1)      // generator + fetch issue
+            run_pass(P, B);
+            if (!(Q.flags & PF_VALID)) break;
+            if (stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            II2_STAMP(2)
+            P = gen();
+            B = fetch(P);                                     // in flight while Q is marked
+            II2_STAMP(1)
+            run_pass(Q, Bq);
         }
         count = wave_sum(count);
     }
