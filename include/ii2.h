@@ -158,7 +158,15 @@ int ii2_seg_select_aligned_all(ii2_ctx *ctx, const ii2_seg *const *srcs, const i
 void ii2_align_free(ii2_align *a);
 
 int ii2_seg_get_info(const ii2_seg *seg, ii2_seg_info *info);
+/* Frees a segment.  As with any free, no call that reads the segment may still be running (the library's calls are
+ * synchronous: that is "after they returned"; a query started with ii2_intersect_async is waited for first).  The
+ * segment's device arrays go back to a size-class cache and are handed out again by the next segment that is made — a
+ * stream of Shard.Merge calls allocates nothing and no free waits for the device.  The cache keeps at most
+ * II2_DEVMEM_CACHE_MB megabytes (environment, default 16384; 0: every free goes to the driver) and is emptied when the
+ * process's last context is destroyed. */
 void ii2_seg_free(ii2_seg *seg);
+/* Bytes of segment arrays handed out / waiting in the cache for reuse (either pointer may be NULL). */
+void ii2_devmem_stats(uint64_t *live_bytes, uint64_t *idle_bytes);
 
 /* ---- tombstones ------------------------------------------------------------------------ */
 /* Replaces RemovedLists.Values() + slices.BinarySearch per value (removed_list.go:44-54,

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ii2_merge_segments": (C.c_int, [vp, C.c_uint32, vpp, vp, vp, vp, C.c_uint64, C.POINTER(MergeStats)]),
     "ii2_merge_segments_to_seg": (C.c_int, [vp, C.c_uint32, vpp, vp, vpp, C.POINTER(MergeStats)]),
     "ii2_merge_small": (C.c_int, [vp, C.c_uint32, vpp, vp, vp, vp, vp, C.c_uint64, vpp, u64p, u64p, C.POINTER(MergeStats)]),
+    "ii2_devmem_stats": (None, [u64p, u64p]),
     "ii2_read_small": (C.c_int, [vp, C.c_uint32, vpp, vp, vp, vp, vp, u64p, u64p, vp, C.c_uint64, u64p]),
     "ii2_intersect": (C.c_int, [vp, C.c_uint32, vpp, u64p, vp, vp, C.c_uint64, u64p]),
     "ii2_intersect_async": (C.c_int, [vp, C.c_uint32, vpp, u64p, vp, vp, C.c_uint64, vp]),

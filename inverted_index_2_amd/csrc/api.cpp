@@ -612,10 +612,12 @@ int ii2_seg_adopt_view(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, uint32_
 
 extern "C" {
 
+void ii2_devmem_stats(uint64_t *live_bytes, uint64_t *idle_bytes) { dm_stats(live_bytes, idle_bytes); }
+
 void ii2_seg_free(ii2_seg *seg) {
     if (!seg) return;
-    // the caller guarantees no call that reads the segment is still running (as with any free); hipFree itself waits for
-    // the device's pending work
+    // the caller guarantees no call that reads the segment is still running (as with any free); the arrays go back to the
+    // size-class cache (devmem.cpp), which does not wait for the device
     (void)hipSetDevice(seg->device);
     seg_release(seg);
 }

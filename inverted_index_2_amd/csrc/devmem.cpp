@@ -110,6 +110,16 @@ void dm_trim(size_t keep_bytes) {
     for (auto &kv : out) (void)hipFree(kv.second);
 }
 
+void dm_stats(uint64_t *live_bytes, uint64_t *idle_bytes) {
+    std::lock_guard<std::mutex> g(g_cache.mu);
+    if (live_bytes) {
+        uint64_t t = 0;
+        for (auto &kv : g_cache.live) t += kv.second & ~(size_t)0xFF;
+        *live_bytes = t;
+    }
+    if (idle_bytes) *idle_bytes = g_cache.idle_bytes;
+}
+
 void dm_user(int delta) {
     bool last = false;
     {

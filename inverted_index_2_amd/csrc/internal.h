@@ -73,6 +73,7 @@ hipError_t dm_alloc(void **p, size_t bytes);
 void dm_free(void *p);
 void dm_trim(size_t keep_bytes);
 void dm_user(int delta);
+void dm_stats(uint64_t *live_bytes, uint64_t *idle_bytes);
 }  // namespace ii2
 
 struct ii2_seg_store {

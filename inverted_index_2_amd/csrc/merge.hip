@@ -20,9 +20,13 @@
 // survivor goes straight from its register to its final rank in the output (no compaction pass, no sorted copy).
 // Bitmap tiles mark, clear the tombstoned words and extract.  A bucket that overflows (clustered ids) or a range that
 // holds more than LDS sends the range to a bisection whose leaves are small enough for the bitmap — exact for any input.
+// A range tile decodes only its own part of every block: the plan cuts each list at the tiles' doc bounds (cut_for /
+// k_merge_tile_runs*: the block that straddles a bound is walked once, there).
 // Tiles are independent: each parks its survivors in a scratch array (batches at the input rank of their first term,
-// tiles of a large term through a bump allocator inside the term's region); a scan of the tile counts and a packing
-// pass then produce the CSR the reference's writer would have been fed: terms ascending, ids ascending.
+// tiles of a large term through a bump allocator inside the term's region).  When the caller's buffer is known to hold
+// any result the tiles then move them to their final place themselves (ticket order, a scanner workgroup turns the
+// published counts into offsets: "direct placement" below); otherwise a scan of the tile counts and a packing pass
+// follow.  Either way the result is the CSR the reference's writer would have been fed: terms ascending, ids ascending.
 #include <type_traits>
 
 #include "dv1_device.h"

@@ -157,3 +157,28 @@ def test_segment_allgather_with_one_rank_is_a_copy(ctx):
     b = ctx.empty(1200, np.uint8)
     assert ctx.allgatherv_bytes(a, 777, b, 1) == [777]
     assert np.array_equal(b.download(777), (np.arange(777) % 251).astype(np.uint8))
+
+
+def test_freed_segment_arrays_are_reused_not_returned_to_the_driver(ctx):
+    """devmem.cpp: a freed segment's device arrays wait in a size-class cache; making the same segment again takes them out
+    of it instead of allocating (ii2_devmem_stats: live bytes come back to the same value, idle bytes do not grow)."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    lists = [np.unique(rng.integers(0, 1 << 24, 50_000)).astype(np.uint32) for _ in range(20)]
+
+    def stats():
+        live, idle = C.c_uint64(), C.c_uint64()
+        ctx.lib.ii2_devmem_stats(C.byref(live), C.byref(idle))
+        return live.value, idle.value
+    seg = ctx.encode_lists(lists)
+    live1, idle1 = stats()
+    seg.free()
+    live0, idle0 = stats()
+    assert live0 < live1 and idle0 > idle1                      # the arrays moved from "handed out" to "waiting"
+    for _ in range(5):
+        seg = ctx.encode_lists(lists)
+        assert stats() == (live1, idle1)                        # the same arrays again: nothing new, nothing left over
+        _, v = seg.decode()
+        assert np.array_equal(v, np.concatenate(lists))
+        seg.free()
+        assert stats() == (live0, idle0)
