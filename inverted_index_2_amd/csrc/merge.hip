@@ -483,13 +483,6 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
         }
     }
     const unsigned long long pay64 = (unsigned long long)(uintptr_t)sv.payload;
-    // every lane asks for its own block's cache lines now: the shared walks below then find them in the L2 (one round of
-    // memory latency for the whole wave instead of one per pair of blocks)
-    if (walk) {
-        uint32_t touch = 0;
-        for (uint32_t o = 0; o < len; o += 128u) touch |= gload4(sv.payload + start + o);
-        asm volatile("" ::"v"(touch));
-    }
     for (unsigned long long need = __ballot(walk); need != 0ull;) {
         // the four lowest lanes that need a walk: one per group of 16 lanes (a block is walked 16 pieces = 256 bytes at a time,
         // and most walks end in their first or second step: the crossing is half a block in on average)
