@@ -53,6 +53,12 @@ type HostShard interface {
 }
 
 // ShardMerge is the body of Shard.Merge (shard.go:127-245) with the loop :163-212 on the GPU.
+//
+// This body hands host slices over (MergeAligned = ii2_merge_host): the segments' postings cross PCIe on every call.  A shard
+// that keeps its segments resident (Ctx.Encode once per segment, *Segment handles next to the file handles) replaces the
+// whole body by ONE call for the usual merge of a few small segments - Ctx.MergeSmall (ii2_merge_small: alignment, union,
+// removed-list filter, empty-term drop and encode in one launch, ~30 us) - and falls back to NewDictionary / AlignDicts /
+// SelectAlignedAll / MergeSegmentsToSeg when it answers ErrTooLarge.  ShardRead likewise: Ctx.ReadSmall (ii2_read_small).
 func ShardMerge(c *Ctx, s HostShard, reqCount, mCount int) (mergedSegmentsLen int, err error) {
 	n, err := s.PickAndLock(reqCount, mCount)
 	if err != nil || n < 2 {
