@@ -273,6 +273,32 @@ func (c *Ctx) SegAllGather(local *Segment) (*Segment, error) {
 	return &Segment{out}, nil
 }
 
+// MergeSegmentsToSeg merges k term-aligned resident segments (views from SelectAligned / SelectAlignedAll) into a new
+// resident segment, minus RemovedLists.Values() (ii2_tomb_create + ii2_merge_segments_to_seg): the general path behind
+// MergeSmall.  It returns nil when no posting survives (shard.go:219-225); the caller drops the emptied term slots.
+func (c *Ctx) MergeSegmentsToSeg(segs []*Segment, removed []uint32) (*Segment, error) {
+	hs := make([]*C.ii2_seg, len(segs))
+	for i, s := range segs {
+		hs[i] = s.h
+	}
+	var tomb *C.ii2_tomb
+	if len(removed) > 0 {
+		if rc := C.ii2_tomb_create(c.h, u32ptr(removed), C.uint64_t(len(removed)), C.II2_HOST, &tomb); rc != 0 {
+			return nil, c.err("merge", rc)
+		}
+		defer C.ii2_tomb_free(tomb)
+	}
+	var out *C.ii2_seg
+	var st C.ii2_merge_stats
+	if rc := C.ii2_merge_segments_to_seg(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), tomb, &out, &st); rc != 0 {
+		return nil, c.err("merge", rc)
+	}
+	if out == nil {
+		return nil, nil
+	}
+	return &Segment{out}, nil
+}
+
 // Union replaces PrefixSearch's append + slices.Sort + slices.Compact (inverted_index.go:274-292).
 func (c *Ctx) Union(listOff []uint64, values, removed []uint32) ([]uint32, error) {
 	return c.lists(true, listOff, values, removed)
