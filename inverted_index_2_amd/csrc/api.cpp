@@ -857,11 +857,16 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         const uint32_t grid = (dp.n_waves + 3u) / 4u;
         dp.n_meta = grid * 4u;
         dp.base32 = dense_first_doc & ~31u;
-        const uint64_t bm_words = (((uint64_t)dense_last_doc - dp.base32) >> 5) + 1 + dp.n_meta + 8;
+        // two lists: the longer one is marked, the shorter one's postings are tested where they sit (intersect_and2.hip): the
+        // hand-over to the second kernel is one bit per posting of the shorter list instead of a result bitmap
+        const bool and2 = n == 2 && ctx->opt_intersect_and2 && bpw == 16u;
+        const uint64_t bm_words = and2 ? (uint64_t)dp.n_meta * 128u : (((uint64_t)dense_last_doc - dp.base32) >> 5) + 1 + dp.n_meta + 8;
         size_t need = align_up(bm_words * sizeof(uint32_t)) + align_up((size_t)dp.n_meta * sizeof(uint4)) + align_up((size_t)grid * sizeof(uint32_t)) + 4096;
         int rc = ii2_ws_reserve(ctx, need);
         if (rc) return rc;
         dp.bitmap = ws_take<uint32_t>(ctx, bm_words);
+        dp.hmask = and2 ? reinterpret_cast<uint2 *>(dp.bitmap) : nullptr;
+        if (and2) dp.bpw = ctx->opt_intersect_and2 == 2 ? 4u : 16u;      // (experiment: the tile kernel built for 4 waves per SIMD)
         dp.meta = ws_take<uint4>(ctx, dp.n_meta);
         dp.wg_sum = ws_take<uint32_t>(ctx, grid);
         dp.tomb = tomb ? tomb->d_words : nullptr;
@@ -879,7 +884,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         ii2_profile_pair(ctx, &e0, &e1);
-        HIP_TRY(ctx, launch_intersect_dense(dp, st, e0, e1));
+        HIP_TRY(ctx, and2 ? launch_intersect_and2(dp, st, e0, e1) : launch_intersect_dense(dp, st, e0, e1));
         return II2_OK;
     }
     // a tiny sparse driver (a rare term against long lists) would keep only a handful of workgroups busy, each decoding
@@ -1183,6 +1188,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;
+    else if (k == "intersect.and2") ctx->opt_intersect_and2 = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

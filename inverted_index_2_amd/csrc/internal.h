@@ -53,6 +53,7 @@ struct ii2_ctx {
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_intersect_dense = 1;    // dense 2..4-list queries go to the wave-streaming kernels (intersect_dense.hip)
     int64_t opt_dense_bpw = 0;          // driver blocks per wave there (0 = default)
+    int64_t opt_intersect_and2 = 0;     // dense 2-list ANDs: the shorter list's postings are tested against the longer one's bitmap (intersect_and2.hip)
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read
@@ -249,8 +250,11 @@ struct DenseParams {
     uint64_t *d_count;
     unsigned long long *debug;   // optional per-workgroup cycle counters [2048][8] (diagnostics)
     uint32_t debug_expand;       // the counters are the expand kernel's (option debug.stamps = 2), else the tile kernel's
+    uint2 *hmask;                // two-list AND (intersect_and2.hip): one answer bit per posting of lists[0], 64 bits per lane of a wave
 };
 hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+// AND of exactly two lists: lists[1] is marked, the postings of lists[0] are tested against it (meta = {first doc, last doc, ids, flags})
+hipError_t launch_intersect_and2(const DenseParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
 hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s);

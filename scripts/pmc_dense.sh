@@ -15,7 +15,7 @@ for pas in ("p1", "p2"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open("gpurun_out/prof/$tag/%s/%s_counter_collection.csv" % (pas, pas))):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if "dense" in k:
+        if "dense" in k or "and2" in k:
             acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         print(k, {c: round(sum(v[1:]) / max(len(v[1:]), 1)) for c, v in d.items()})
