@@ -170,6 +170,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (ctx->d_segs) (void)hipFree(ctx->d_segs);
     for (uint8_t *q : ctx->pool) if (q) (void)hipFree(q);
     if (ctx->d_debug) (void)hipFree(ctx->d_debug);
+    if (ctx->d_lb) (void)hipFree(ctx->d_lb);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_mail) (void)hipFree(ctx->d_mail);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
@@ -187,6 +188,15 @@ int ii2_ctx_sync(ii2_ctx *ctx) {
     if (!ctx) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->lb_pending && ctx->d_lb) {
+        // asynchronous two-list ANDs since the last look: did a bounded wait of any of them run out?  (its count is all ones)
+        unsigned long long e = 0;
+        const uint32_t first = ctx->lb_pending;
+        ctx->lb_pending = 0;
+        HIP_TRY(ctx, hipMemcpy(&e, ctx->d_lb, sizeof e, hipMemcpyDeviceToHost));
+        if (e >= first && e <= ctx->lb_epoch)
+            return fail(ctx, II2_EHIP, "ii2_intersect_async: a workgroup's bounded wait ran out (that call's count is all ones); repeat it with ii2_intersect");
+    }
     return II2_OK;
 }
 
@@ -866,7 +876,36 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         if (rc) return rc;
         dp.bitmap = ws_take<uint32_t>(ctx, bm_words);
         dp.hmask = and2 ? reinterpret_cast<uint2 *>(dp.bitmap) : nullptr;
-        if (and2) dp.bpw = ctx->opt_intersect_and2 == 2 ? 4u : 16u;      // (experiment: the tile kernel built for 4 waves per SIMD)
+        if (and2 && ctx->opt_intersect_and2 == 1) {
+            // one launch (k_and2_fused): the look-back records live in a buffer of their own (only these kernels write it, every
+            // word tagged with its launch's number: nothing to clear between launches)
+            const size_t n_grp = (grid + 63u) / 64u;
+            if (grid > ctx->lb_cap || ctx->lb_epoch == 0xFFFFFFFFu) {
+                HIP_TRY(ctx, hipStreamSynchronize(st));
+                if (grid > ctx->lb_cap) {
+                    if (ctx->d_lb) (void)hipFree(ctx->d_lb);
+                    ctx->d_lb = nullptr;
+                    ctx->lb_cap = 0;
+                    const size_t cap_wg = std::max<size_t>(4096, (size_t)grid + grid / 4);
+                    if (hipMalloc((void **)&ctx->d_lb, (8 + cap_wg + 2 * ((cap_wg + 63) / 64)) * sizeof(unsigned long long)) != hipSuccess)
+                        return fail(ctx, II2_ENOMEM, "look-back records allocation failed");
+                    ctx->lb_cap = cap_wg;
+                }
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_lb, 0, (8 + ctx->lb_cap + 2 * ((ctx->lb_cap + 63) / 64)) * sizeof(unsigned long long), st));
+                ctx->lb_epoch = 0;
+                ctx->lb_pending = 0;
+            }
+            (void)n_grp;
+            dp.lb_err = ctx->d_lb;
+            dp.lb_agg = ctx->d_lb + 8;
+            dp.lb_grp = ctx->d_lb + 8 + ctx->lb_cap;
+            dp.lb_epoch = ++ctx->lb_epoch;
+            if (!ctx->lb_pending) ctx->lb_pending = dp.lb_epoch;
+            dp.lb_spin = ctx->opt_and2_spin > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_and2_spin, 0x7FFFFFFF) : 0u;
+            const double spanA = (double)dp.last_doc[1] - (double)dp.first_doc[1] + 1.0;
+            dp.a_scale = (float)((double)views[1].nblk / spanA);
+            dp.b_dpb = (float)per_block_span;
+        }
         dp.meta = ws_take<uint4>(ctx, dp.n_meta);
         dp.wg_sum = ws_take<uint32_t>(ctx, grid);
         dp.tomb = tomb ? tomb->d_words : nullptr;
@@ -1132,6 +1171,21 @@ int ii2_intersect(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const ui
     if (!d_cnt) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + II2_MAIL_COUNT, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *count = ctx->h_mail[II2_MAIL_COUNT];
+    if (*count == ~0ull && ctx->lb_pending) {
+        // a bounded wait of the one-launch two-list AND ran out (its workgroups did not start in index order): nothing is
+        // wrong with the inputs — the same query again through the two-kernel form, which has no inter-workgroup waits
+        ctx->lb_pending = 0;
+        ctx->lb_fallbacks++;
+        const int64_t keep = ctx->opt_intersect_and2;
+        ctx->opt_intersect_and2 = 2;
+        rc = intersect_unlocked(ctx, n, segs, list_idx, tomb, d_out, cap, d_cnt ? d_cnt : ctx->d_mail);
+        ctx->opt_intersect_and2 = keep;
+        if (rc) return rc;
+        if (!d_cnt) HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + II2_MAIL_COUNT, ctx->d_mail, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        *count = ctx->h_mail[II2_MAIL_COUNT];
+    }
+    ctx->lb_pending = 0;
     if (*count > cap) return fail(ctx, II2_ECAPACITY, "ii2_intersect: result does not fit the output buffer (content unspecified)");
     return II2_OK;
 }
@@ -1188,7 +1242,8 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;
-    else if (k == "intersect.and2") ctx->opt_intersect_and2 = value;
+    else if (k == "intersect.and2") ctx->opt_intersect_and2 = value;      // 0: n-list kernel, 1: one launch (look-back), 2: two kernels
+    else if (k == "intersect.and2_spin") ctx->opt_and2_spin = value;
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

@@ -53,6 +53,12 @@ struct ii2_ctx {
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_intersect_dense = 1;    // dense 2..4-list queries go to the wave-streaming kernels (intersect_dense.hip)
     int64_t opt_dense_bpw = 0;          // driver blocks per wave there (0 = default)
+    int64_t opt_and2_spin = 0;          // bounded waits of its look-back: polls (0 = default; 1 forces the fallback in tests)
+    unsigned long long *d_lb = nullptr; // look-back records of the fused two-list AND: [0] error word, then agg[], grp[]
+    size_t lb_cap = 0;                  // workgroups the records hold
+    uint32_t lb_epoch = 0;              // launches so far
+    uint64_t lb_fallbacks = 0;          // calls repeated through the two-kernel form
+    uint32_t lb_pending = 0;            // epoch of a fused launch whose error word has not been looked at yet (0: none)
     int64_t opt_intersect_and2 = 0;     // dense 2-list ANDs: the shorter list's postings are tested against the longer one's bitmap (intersect_and2.hip)
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
@@ -251,6 +257,14 @@ struct DenseParams {
     unsigned long long *debug;   // optional per-workgroup cycle counters [2048][8] (diagnostics)
     uint32_t debug_expand;       // the counters are the expand kernel's (option debug.stamps = 2), else the tile kernel's
     uint2 *hmask;                // two-list AND (intersect_and2.hip): one answer bit per posting of lists[0], 64 bits per lane of a wave
+    // ... in one launch (k_and2_fused): look-back records {epoch << 32 | ids}; lb_agg == nullptr selects the two-kernel form
+    unsigned long long *lb_agg;  // [workgroups]
+    unsigned long long *lb_grp;  // [2 * groups of 64 workgroups] {ids of the group, ids up to and including the group}
+    unsigned long long *lb_err;  // = the launch's epoch when a workgroup's bounded wait ran out
+    uint32_t lb_epoch;           // this launch's number (never 0)
+    uint32_t lb_spin;            // polls a wait may take (0 = default)
+    float a_scale;               // blocks of lists[1] per doc and ...
+    float b_dpb;                 // ... docs per block of lists[0]: where a wave's first probe of lists[1]'s skip table goes
 };
 hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // AND of exactly two lists: lists[1] is marked, the postings of lists[0] are tested against it (meta = {first doc, last doc, ids, flags})

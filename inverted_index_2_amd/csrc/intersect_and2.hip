@@ -427,7 +427,6 @@ __device__ __forceinline__ void and2_tiles_body(const DenseParams &p) {
 }
 
 __global__ __launch_bounds__(256) void k_and2_tiles(DenseParams p) { and2_tiles_body(p); }
-__global__ __launch_bounds__(256, 4) void k_and2_tiles_w4(DenseParams p) { and2_tiles_body(p); }
 
 // ---- kernel 2: the B postings whose answer bit is set -> the final ascending id array ------------------------------
 // Workgroup g re-walks the B blocks of tile workgroup g (same decomposition).  Its output offset = the counts of the
@@ -568,11 +567,414 @@ __global__ __launch_bounds__(256) void k_and2_expand(DenseParams p) {
 #undef II2_STAMP
 }
 
+
+// ---- one launch: mark A, test B, place the ids ---------------------------------------------------------------------
+// The two kernels above hand the answers over through HBM and the second one reads B again (entries, payload, answer bits:
+// two dependent round trips before its first useful instruction).  Here the wave that found the answers still holds B's
+// bytes and H in registers: it stages its ids (16-bit offsets, wave-private LDS, over the bitmap that is dead by then) and
+// writes them out once it knows where — the number of ids of all workgroups before its own.
+//
+// That prefix comes from a two-level look-back over small records in HBM (8-byte {epoch, value} words, relaxed agent-scope
+// stores and loads: the value and its ready flag travel in one word, so no fence is needed; the epoch is this launch's
+// number, so the records are never cleared):
+//   agg[g]            ids of workgroup g, published as soon as its four waves have counted;
+//   grp[2 G]          ids of group G (64 consecutive workgroups), published by the group's last workgroup once the group's
+//                     other members have published;
+//   grp[2 G + 1]      ids of all groups up to and including G, published by the same workgroup when it knows its own prefix.
+// A workgroup needs: the groups before its own — it reads their records 64 at a time, nearest first, and stops at the first
+// one that already carries a prefix — plus the members of its own group before it: two hops behind the slowest workgroup it
+// depends on, and it stages its ids while they travel.  Every wait is for a workgroup with a SMALLER index.  The hardware
+// starts the workgroups of a launch in index order on every XCD, so the lowest unfinished workgroup is always running and
+// waits for nobody: that is not a HIP guarantee, so every wait is bounded — a workgroup that runs out of patience writes the
+// launch's epoch into the error words and leaves without writing ids, the last workgroup then poisons the count (all ones),
+// and the host repeats a failed call through the two kernels above.
+constexpr uint32_t A2_LB_GROUP = 64;
+constexpr uint32_t A2_LB_SPIN = 1u << 21;                        // polls (each >= ~1 us): seconds in all
+constexpr uint32_t A2F_STAGE_W = (A2_STAGE + 1u) / 2u;            // stage in words (aliases the bitmap, which is dead by then)
+constexpr uint32_t A2F_WAVE_LDS = (A2F_STAGE_W > A2_NW ? A2F_STAGE_W : A2_NW) + A2_HS;
+static_assert(A2F_STAGE_W % 4u == 0u, "16-byte alignment of the per-wave LDS regions");
+
+__device__ __forceinline__ unsigned long long a2_ld(const unsigned long long *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void a2_st(unsigned long long *q, unsigned long long v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
+    __shared__ __align__(16) uint32_t lds[4][A2F_WAVE_LDS];
+    __shared__ uint32_t wcnt[4];
+    __shared__ unsigned long long wg_off;
+    __shared__ uint32_t wg_err;
+    const int l = lane_id();
+    const uint32_t wv = a2_uni(threadIdx.x >> 6);
+    const uint32_t rl = (uint32_t)l & 3u, row = (uint32_t)l >> 2;
+    const uint32_t g = blockIdx.x;
+    const uint32_t w = g * 4u + wv;                          // this wave's number in doc order
+    uint32_t *lds_all = &lds[0][0];
+    uint32_t *bmA = lds[wv], *hs = bmA + (A2F_WAVE_LDS - A2_HS);
+    uint16_t *st = reinterpret_cast<uint16_t *>(bmA);
+    const uint32_t bmbits = (uint32_t)(bmA - lds_all) * 32u;
+    const ListView LB = p.lists[0], LA = p.lists[1];
+    const uint32_t b0 = w * A2_ROWS;
+    const uint32_t b1 = b0 + A2_ROWS < LB.nblk ? b0 + A2_ROWS : LB.nblk;
+    const uint32_t ep = p.lb_epoch;
+    const unsigned long long eptag = (unsigned long long)ep << 32;
+    const uint32_t spin_limit = p.lb_spin ? p.lb_spin : A2_LB_SPIN;
+    uint32_t count = 0, lo = 0, hi = 0;
+    unsigned long long H = 0ull, hm_any = 0ull;
+    A2Lane LN;
+    uint4 EB = make_uint4(0, 0, 0, 0);
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    const bool stamps = p.debug != nullptr;
+#define II2_STAMP(i)                                                    \
+    if (stamps) {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();    \
+        tacc[i] += tn_ - tprev;                                         \
+        tprev = tn_;                                                    \
+    }
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0) wg_err = 0u;
+    const bool work = b0 < b1;                               // wave-uniform
+    const uint32_t nvB = work ? b1 - b0 : 0u;
+    const bool rvB = row < nvB;
+
+    if (work) {
+        // ---- first round trip: B's entries and, beside them, a 128-entry window of A's skip table around the place where a
+        // uniform list would have this wave's first doc (B's docs-per-block and A's blocks-per-doc from the host: a guess that
+        // the entries themselves confirm or refute)
+        EB = a2_ent_load(LB, b0, row);
+        const uint32_t fj = p.first_doc[1];
+        uint32_t wb = 0;
+        uint2 P0 = make_uint2(0, 0), P1 = make_uint2(0, 0);
+        const bool probing = LA.nblk >= 128u;
+        if (probing) {
+            const float lo_guess = (float)p.first_doc[0] + (float)b0 * p.b_dpb;
+            const float rel = lo_guess - (float)fj;
+            float gs = rel > 0.f ? rel * p.a_scale : 0.f;
+            if (gs > (float)LA.nblk) gs = (float)LA.nblk;
+            const uint32_t gi = (uint32_t)gs;
+            wb = gi > 40u ? gi - 40u : 0u;
+            if (wb + 128u > LA.nblk) wb = LA.nblk - 128u;
+            wb = a2_uni(wb);
+            const ii2_skip e0 = LA.skip[wb + (uint32_t)l], e1 = LA.skip[wb + 64u + (uint32_t)l];
+            P0 = make_uint2(e0.first_doc, e0.byte_off);
+            P1 = make_uint2(e1.first_doc, e1.byte_off);
+        }
+        const uint32_t b_last = a2_uni(*LB.last_doc);
+        lo = a2_uni(EB.x);                                                      // (row 0 = block b0)
+        const uint32_t nf = (uint32_t)__builtin_amdgcn_readlane((int)EB.z, (int)(4u * (nvB - 1u)));
+        hi = b1 < LB.nblk ? nf - 1u : b_last;
+        // where A enters this wave's doc range: the last block that starts at or before lo
+        uint32_t a0;
+        bool from_probe = false;
+        {
+            uint32_t ub = 0xFFFFFFFFu;
+            if (probing) {
+                const uint32_t c0 = (uint32_t)__popcll(__ballot(P0.x <= lo)), c1 = (uint32_t)__popcll(__ballot(P1.x <= lo));   // first docs ascend: the matches are a prefix
+                const uint32_t cnt = c0 + c1;
+                if ((cnt > 0u || wb == 0u) && (cnt < 128u || wb + 128u == LA.nblk)) { ub = wb + cnt; from_probe = true; }
+            }
+            if (ub == 0xFFFFFFFFu) ub = a2_skip_upper_bound(LA.skip, LA.nblk, lo);
+            ub = a2_uni(ub);
+            a0 = ub ? ub - 1u : 0u;
+        }
+        II2_STAMP(0)          // prologue: B's entries, A's window, search
+
+        uint32_t wlo = lo & ~31u;
+        uint32_t a_cur = a0;
+        bool first_window = true;
+        for (;;) {
+            const uint32_t wspan = hi - wlo < A2_CAPW ? hi - wlo : A2_CAPW - 1u;
+            const uint32_t whi = wlo + wspan;
+            const uint32_t nw = (wspan >> 5) + 1u;
+            const uint32_t ncl = nw + 2u * (A2_GU / 32u) + 2u;       // <= A2_NW - 2; cleared in 4-word steps
+            uint32_t cur = a_cur;
+            uint4 Ecur, Enext;
+            // the entries of A's first two passes: out of the window's registers when it holds them (no second round trip)
+            if (first_window && from_probe && cur + 2u * A2_ROWS + 1u <= wb + 127u && cur + 2u * A2_ROWS + 1u <= LA.nblk) {
+                auto pick = [&](uint32_t j, uint32_t &fd, uint32_t &bo) {      // entry wb + j, j < 128 (per lane)
+                    const int src = (int)((j & 63u) << 2);
+                    const uint32_t f0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)P0.x), f1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)P1.x);
+                    const uint32_t o0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)P0.y), o1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)P1.y);
+                    fd = j < 64u ? f0 : f1;
+                    bo = j < 64u ? o0 : o1;
+                };
+                const uint32_t j0 = cur - wb + row;
+                pick(j0, Ecur.x, Ecur.y); pick(j0 + 1u, Ecur.z, Ecur.w);
+                pick(j0 + A2_ROWS, Enext.x, Enext.y); pick(j0 + A2_ROWS + 1u, Enext.z, Enext.w);
+            } else {
+                Ecur = a2_ent_load(LA, cur, row);
+                Enext = a2_ent_load(LA, cur + A2_ROWS, row);
+            }
+            for (uint32_t i = 4u * (uint32_t)l; i < ncl; i += 256u) *reinterpret_cast<uint4 *>(&bmA[i]) = make_uint4(0, 0, 0, 0);
+            bool rv = cur + row < LA.nblk && Ecur.x <= whi;          // first docs ascend: the valid rows are a prefix
+            uint32_t nv = (uint32_t)__popcll(__ballot(rv)) >> 2;
+            A2Bytes Bcur = a2_fetch(LA.payload, rv, Ecur.y, Ecur.w, rl);
+            A2Bytes X;
+            uint32_t tw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            II2_STAMP(1)      // clear, A's entries, first fetch
+            for (;;) {
+                const bool more = nv == A2_ROWS;
+                const bool rvn = more && cur + A2_ROWS + row < LA.nblk && Enext.x <= whi;
+                const uint32_t nvn = (uint32_t)__popcll(__ballot(rvn)) >> 2;
+                const bool last = nvn == 0u;
+                X = a2_fetch(last ? LB.payload : LA.payload, last ? rvB : rvn, last ? EB.y : Enext.y, last ? EB.w : Enext.w, rl);
+                if (last && p.tomb) {                                // (a window holds <= 512 words: eight per lane, requested together)
+                    const uint32_t tw0 = wlo >> 5;
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; k++) {
+                        const uint32_t i = 64u * k + (uint32_t)l;
+                        tw[k] = (i < nw && tw0 + i < p.tomb_nwords) ? p.tomb[tw0 + i] : 0u;
+                    }
+                }
+                if (nv != 0u) a2_mark_rows(lds_all, bmA, LA.payload, rv, Ecur.x, Ecur.y, Ecur.w, Bcur, wlo, wspan, rl, row);
+                cur += nv;
+                if (last) break;
+                Ecur = Enext; Bcur = X; rv = rvn; nv = nvn;
+                Enext = a2_ent_load(LA, cur + A2_ROWS, row);
+            }
+            if (cur > a_cur + 1u) a_cur = cur - 1u;                  // A's last block in the window may reach past it
+            II2_STAMP(2)      // mark A
+            if (p.tomb) {                                            // removed docs are absent from A: no B posting finds them
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    const uint32_t i = 64u * k + (uint32_t)l;
+                    if (64u * k < nw && tw[k] != 0u) bmA[A2_GU / 32u + i] &= ~tw[k];
+                }
+            }
+            // ---- B's postings against the bitmap
+            a2_lane_setup(LN, X, rvB, EB, rl, row);
+            hm_any = LN.hm;
+            if (LN.hm != 0ull && first_window) { hs[2 * l] = 0u; hs[2 * l + 1] = 0u; }      // answers of the hard rows are collected in LDS
+            const bool single = first_window && hi - wlo < A2_CAPW;
+            if (single) H |= a2_test_lane<false>(lds_all, bmbits, LN, wlo, wspan);
+            else H |= a2_test_lane<true>(lds_all, bmbits, LN, wlo, wspan);
+            if (LN.hm != 0ull) {
+#pragma unroll 1
+                for (uint32_t r = 0; r < A2_ROWS; r++) {
+                    if (((LN.hm >> (4u * r)) & 0xFull) == 0ull) continue;
+                    const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)EB.x, (int)(4u * r)), q0r = (uint32_t)__builtin_amdgcn_readlane((int)EB.y, (int)(4u * r)),
+                                   q1r = (uint32_t)__builtin_amdgcn_readlane((int)EB.w, (int)(4u * r));
+                    uint32_t *hr = hs + 8u * r;
+                    auto probe = [&](uint32_t ix, uint32_t id) {
+                        const uint32_t d = id - wlo;
+                        if (d <= wspan && ix < 256u) {
+                            const uint32_t u = d + A2_GU;
+                            if ((bmA[u >> 5] >> (u & 31u)) & 1u) atomicOr(&hr[ix >> 5], 1u << (ix & 31u));
+                        }
+                    };
+                    decode_block_wave4(GlobalBytes{LB.payload}, q0r, q1r, fq,
+                                       [&](uint32_t ix, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                                           if (mask & 1u) { probe(ix, id0); ix++; }
+                                           if (mask & 2u) { probe(ix, id1); ix++; }
+                                           if (mask & 4u) { probe(ix, id2); ix++; }
+                                           if (mask & 8u) { probe(ix, id3); ix++; }
+                                       });
+                }
+            }
+            II2_STAMP(3)      // tombstones, test B
+            if (hi - wlo < A2_CAPW) break;
+            wlo += A2_CAPW;
+            first_window = false;
+        }
+        if (hm_any != 0ull) {
+            const bool rowhard = ((hm_any >> (4u * row)) & 0xFull) != 0ull;
+            if (rowhard) H = ((unsigned long long)hs[8u * row + 2u * rl + 1u] << 32) | hs[8u * row + 2u * rl];
+        }
+    }
+    const uint32_t pc = (uint32_t)__popcll(H);
+    const uint32_t incl = wave_incl_scan(pc);
+    count = wave_bcast(incl, 63);
+    const uint32_t q0 = incl - pc;              // my first id's place among the wave's ids
+    if (l == 0) wcnt[wv] = count;
+    lds_barrier();
+    const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    const uint32_t total = c0 + c1 + c2 + c3;
+    const uint32_t before = wv == 0u ? 0u : wv == 1u ? c0 : wv == 2u ? c0 + c1 : c0 + c1 + c2;
+    const uint32_t G = g / A2_LB_GROUP, gi = g % A2_LB_GROUP;
+    const bool leader = gi == A2_LB_GROUP - 1u || g == gridDim.x - 1u;
+    unsigned long long *agg = p.lb_agg, *grp = p.lb_grp;
+    if (threadIdx.x == 0) a2_st(&agg[g], eptag | total);
+    II2_STAMP(4)              // count, barrier, publish
+    if (wv == 1u && leader) {                   // the group's ids, as soon as its other members have published theirs
+        uint32_t spins = 0;
+        unsigned long long v;
+        bool bad = false;
+        for (;;) {
+            v = (uint32_t)l < gi ? a2_ld(&agg[(size_t)G * A2_LB_GROUP + (uint32_t)l]) : eptag;
+            if (__ballot((uint32_t)(v >> 32) != ep) == 0ull) break;
+            if (++spins > spin_limit) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const uint32_t gtot = wave_sum(bad ? 0u : (uint32_t)v) + total;
+        if (l == 0) {
+            if (!bad) a2_st(&grp[2 * (size_t)G], eptag | gtot);
+            else { wg_err = 1u; a2_st(p.lb_err, (unsigned long long)ep); }
+        }
+    }
+    // ---- stage the ids of my postings whose answer bit is set: 16-bit offsets from the round's first doc, in output order
+    const bool wide = work && hi - lo > 0xFFFFu;             // (a sparse stretch: ids go out one by one, below)
+    if (work && !wide && count != 0u) {
+        const unsigned long long He = LN.live ? H : 0ull;
+        uint32_t q = q0;
+        uint32_t v = LN.base - lo;
+        if (He & 1ull) { st[q] = (uint16_t)v; q++; }
+#pragma unroll
+        for (uint32_t k = 0; k < 63u; k++) {
+            v += (LN.ww[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
+            if ((He >> (k + 1u)) & 1ull) { st[q] = (uint16_t)v; q++; }
+        }
+        if (hm_any != 0ull) {                   // rows with multi-byte gaps: decoded again, every hit ranks itself among its row's answers
+#pragma unroll 1
+            for (uint32_t r = 0; r < A2_ROWS; r++) {
+                if (((hm_any >> (4u * r)) & 0xFull) == 0ull) continue;
+                const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)EB.x, (int)(4u * r)), q0r = (uint32_t)__builtin_amdgcn_readlane((int)EB.y, (int)(4u * r)),
+                               q1r = (uint32_t)__builtin_amdgcn_readlane((int)EB.w, (int)(4u * r));
+                const uint32_t qrow = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)(4u * r));
+                const uint32_t *hr = hs + 8u * r;
+                auto place = [&](uint32_t ix, uint32_t id) {
+                    if (ix >= 256u) return;
+                    const uint32_t wd = hr[ix >> 5];
+                    if (!((wd >> (ix & 31u)) & 1u)) return;
+                    uint32_t rk = (uint32_t)__popc(wd & ((1u << (ix & 31u)) - 1u));
+                    for (uint32_t j = 0; j < (ix >> 5); j++) rk += (uint32_t)__popc(hr[j]);
+                    st[qrow + rk] = (uint16_t)(id - lo);
+                };
+                decode_block_wave4(GlobalBytes{LB.payload}, q0r, q1r, fq,
+                                   [&](uint32_t ix, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                                       if (mask & 1u) { place(ix, id0); ix++; }
+                                       if (mask & 2u) { place(ix, id1); ix++; }
+                                       if (mask & 4u) { place(ix, id2); ix++; }
+                                       if (mask & 8u) { place(ix, id3); ix++; }
+                                   });
+            }
+        }
+    }
+    II2_STAMP(5)              // stage
+    // ---- the ids of all workgroups before mine (wave 0)
+    if (wv == 0u) {
+        bool bad = false;
+        uint32_t spins = 0;
+        unsigned long long a;
+        for (;;) {                              // members of my group before me
+            a = (uint32_t)l < gi ? a2_ld(&agg[(size_t)G * A2_LB_GROUP + (uint32_t)l]) : eptag;
+            if (__ballot((uint32_t)(a >> 32) != ep) == 0ull) break;
+            if (++spins > spin_limit) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        const unsigned long long mem = wave_sum(bad ? 0u : (uint32_t)a);
+        unsigned long long accg = 0ull;         // groups before mine: 64 at a time, nearest first
+        int top = (int)G - 1;
+        while (top >= 0 && !bad) {
+            const int j = top - l;
+            const bool inr = j >= 0;
+            unsigned long long ga = eptag, gp = 0ull;
+            if (inr) { ga = a2_ld(&grp[2 * (size_t)j]); gp = a2_ld(&grp[2 * (size_t)j + 1]); }
+            const unsigned long long gav = __ballot(!inr || (uint32_t)(ga >> 32) == ep);
+            const unsigned long long gpv = __ballot(inr && (uint32_t)(gp >> 32) == ep);
+            if (gpv != 0ull) {                  // nearest group that already carries its prefix: the groups between it and me by their own ids
+                const uint32_t d = (uint32_t)__ffsll((long long)gpv) - 1u;
+                const unsigned long long need = (1ull << d) - 1ull;
+                if ((gav & need) == need) {
+                    const uint32_t part = wave_sum((uint32_t)l < d ? (uint32_t)ga : 0u);
+                    const unsigned long long gl = (unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)gp, (int)d);
+                    accg += part + (gl & 0xFFFFFFFFull);
+                    top = -1;
+                    break;
+                }
+            } else if (gav == ~0ull) {
+                accg += wave_sum(inr ? (uint32_t)ga : 0u);
+                top -= 64;
+                spins = 0;
+                continue;
+            }
+            if (++spins > spin_limit) { bad = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (l == 0) {
+            if (!bad) {
+                wg_off = accg + mem;
+                if (leader) a2_st(&grp[2 * (size_t)G + 1], eptag | ((accg + mem + total) & 0xFFFFFFFFull));
+            } else { wg_off = 0ull; wg_err = 1u; a2_st(p.lb_err, (unsigned long long)ep); }
+        }
+    }
+    II2_STAMP(6)              // look-back
+    lds_barrier();
+    const bool err = wg_err != 0u;
+    const unsigned long long off = wg_off + before;
+    if (g == gridDim.x - 1u && threadIdx.x == 0) {          // the last workgroup: the total, or all ones when some workgroup gave up
+        const bool anyerr = err || a2_ld(p.lb_err) == (unsigned long long)ep;
+        *p.d_count = anyerr ? ~0ull : wg_off + total;
+    }
+    if (work && !err && count != 0u) {
+        if (!wide) {
+            const bool fits = off + count <= p.out_cap;
+            for (uint32_t c = 4u * (uint32_t)l; c < count; c += 256u) {        // 16 bytes per lane (wave-private LDS: program order is enough)
+                const uint2 pk = *reinterpret_cast<const uint2 *>(&st[c]);
+                const uint4 ids = make_uint4(lo + (pk.x & 0xFFFFu), lo + (pk.x >> 16), lo + (pk.y & 0xFFFFu), lo + (pk.y >> 16));
+                if (c + 4u <= count && fits) {
+                    uint32_t *dst = p.out + off + c;
+                    __builtin_memcpy(dst, &ids, 16);                // one 16-byte store, any 4-byte alignment
+                } else {
+                    const uint32_t vv[4] = {ids.x, ids.y, ids.z, ids.w};
+                    for (uint32_t k = 0; k < 4u; k++)
+                        if (c + k < count && off + c + k < p.out_cap) p.out[off + c + k] = vv[k];
+                }
+            }
+        } else {
+            const unsigned long long He = LN.live ? H : 0ull;
+            uint32_t q = q0;
+            uint32_t v = LN.base;
+            if ((He & 1ull) && off + q < p.out_cap) p.out[off + q] = v;
+            q += (uint32_t)(He & 1ull);
+#pragma unroll
+            for (uint32_t k = 0; k < 63u; k++) {
+                v += (LN.ww[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
+                const uint32_t hit = (uint32_t)((He >> (k + 1u)) & 1ull);
+                if (hit && off + q < p.out_cap) p.out[off + q] = v;
+                q += hit;
+            }
+            if (hm_any != 0ull) {
+#pragma unroll 1
+                for (uint32_t r = 0; r < A2_ROWS; r++) {
+                    if (((hm_any >> (4u * r)) & 0xFull) == 0ull) continue;
+                    const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)EB.x, (int)(4u * r)), q0r = (uint32_t)__builtin_amdgcn_readlane((int)EB.y, (int)(4u * r)),
+                                   q1r = (uint32_t)__builtin_amdgcn_readlane((int)EB.w, (int)(4u * r));
+                    const uint32_t qrow = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)(4u * r));
+                    const uint32_t *hr = hs + 8u * r;
+                    auto place = [&](uint32_t ix, uint32_t id) {
+                        if (ix >= 256u) return;
+                        const uint32_t wd = hr[ix >> 5];
+                        if (!((wd >> (ix & 31u)) & 1u)) return;
+                        uint32_t rk = (uint32_t)__popc(wd & ((1u << (ix & 31u)) - 1u));
+                        for (uint32_t j = 0; j < (ix >> 5); j++) rk += (uint32_t)__popc(hr[j]);
+                        if (off + qrow + rk < p.out_cap) p.out[off + qrow + rk] = id;
+                    };
+                    decode_block_wave4(GlobalBytes{LB.payload}, q0r, q1r, fq,
+                                       [&](uint32_t ix, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
+                                           if (mask & 1u) { place(ix, id0); ix++; }
+                                           if (mask & 2u) { place(ix, id1); ix++; }
+                                           if (mask & 4u) { place(ix, id2); ix++; }
+                                           if (mask & 8u) { place(ix, id3); ix++; }
+                                       });
+                }
+            }
+        }
+    }
+    II2_STAMP(7)              // flush
+    if (stamps && l == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&p.debug[(uint64_t)(blockIdx.x % 2048u) * 8u + i], tacc[i]);
+#undef II2_STAMP
+}
+
 hipError_t launch_intersect_and2(const DenseParams &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, s);
     const uint32_t grid = (p.n_waves + 3u) / 4u;
-    if (p.bpw == 4u) hipLaunchKernelGGL(k_and2_tiles_w4, dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_and2_tiles, dim3(grid), dim3(256), 0, s, p);
+    if (p.lb_agg != nullptr) {
+        hipLaunchKernelGGL(k_and2_fused, dim3(grid), dim3(256), 0, s, p);
+        if (ev1) (void)hipEventRecord(ev1, s);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_and2_tiles, dim3(grid), dim3(256), 0, s, p);
     hipLaunchKernelGGL(k_and2_expand, dim3(grid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);
     return hipGetLastError();

@@ -43,7 +43,7 @@ def timed(tb, steps=50, warm=10):
     return ctx.profile_region_ms() * 1e3 / steps
 
 
-for and2 in (1, 0, 2):
+for and2 in (1, 2, 0, 1):
     ctx.set_option("intersect.and2", and2)
     for tb, w, name in ((None, want, "plain"), (tomb, want_t, "tombstones")):
         ctx.intersect_async(lists, tb, out, dcnt)
@@ -55,9 +55,8 @@ for and2 in (1, 0, 2):
 
 if want_stamps:
     ctx.set_option("intersect.and2", 1)
-    names = {1: ["prologue", "clear", "mark A", "tombstones", "test B", "count+store"],
-             2: ["prologue", "lane sums+scan", "stage", "flush"]}
-    for mode in (1, 2):
+    names = {1: ["prologue", "clear+fetch", "mark A", "tomb+test B", "count+publish", "stage", "look-back", "flush"]}
+    for mode in (1,):
         ctx.set_option("debug.stamps", mode)
         ctx.intersect_async(lists, None, out, dcnt)
         ctx.sync()

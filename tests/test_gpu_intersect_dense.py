@@ -11,6 +11,7 @@ from oracle import oracle as orc
 from tests.gpu_util import ctx, sorted_unique  # noqa: F401
 
 pytestmark = pytest.mark.gpu
+AND2_DEFAULT = 1
 
 
 def bernoulli(rng, p, lo, hi):
@@ -32,9 +33,10 @@ def _check(ctx, lists, removed=None, split=False):
         seg = ctx.encode_lists(lists)
         ls = [(seg, i) for i in range(len(lists))]
     out = ctx.empty(min(l.size for l in lists) + 16)
-    # dense = 1: two lists go through intersect_and2.hip (the shorter list tested against the longer one's bitmap) unless
-    # intersect.and2 = 0, which sends them through the n-list streaming kernel like three or four lists; dense = 0: general tiles
-    for dense, and2 in ((1, 1), (1, 0), (0, 0)):
+    # dense = 1: two lists go through intersect_and2.hip (the shorter list tested against the longer one's bitmap; and2 = 1:
+    # one launch with a look-back for the output offsets, 2: two kernels) unless intersect.and2 = 0, which sends them through
+    # the n-list streaming kernel like three or four lists; dense = 0: general tiles
+    for dense, and2 in ((1, 1), (1, 2), (1, 0), (0, 0)):
         ctx.set_option("intersect.dense", dense)
         ctx.set_option("intersect.and2", and2)
         out.upload(np.full(out.count, 0xDEADBEEF, np.uint32))
@@ -44,7 +46,7 @@ def _check(ctx, lists, removed=None, split=False):
         assert np.array_equal(got, want), (dense, and2)
         assert np.all(out.download()[n:] == 0xDEADBEEF), (dense, and2)       # nothing written past the result
     ctx.set_option("intersect.dense", 1)
-    ctx.set_option("intersect.and2", 1)
+    ctx.set_option("intersect.and2", AND2_DEFAULT)
     for bpw in (32, 64):                           # longer waves: several rounds per wave, carried boundary words
         ctx.set_option("intersect.dense_bpw", bpw)
         _, n = ctx.intersect(ls, tomb=tomb, out=out)
