@@ -163,6 +163,27 @@ __device__ __forceinline__ void a2_mark_rows(uint32_t *lds_all, uint32_t *bm, co
     const bool exactlane = haswide && !inrange;
     const uint32_t lim = wspan + 2u * A2_GU - 64u;                       // a position in the upper guard: where out-of-window groups are parked
     const uint32_t bmbits = (uint32_t)(bm - lds_all) * 32u;              // the bitmap's place inside the workgroup's LDS array, folded into the position
+    if (__ballot(act && haswide) == 0ull) {
+        // the usual pass: every lane that marks starts inside [wlo - GU, wlo + wspan] and spans < 512 docs, so no group needs
+        // the clamp, the wide-group test or the second loop (the bitmap's upper guard holds 512 + 32 bits past the window)
+        if (act) {
+            uint32_t q = u + bmbits;
+#pragma unroll
+            for (uint32_t k = 0; k < 16u; k++) {
+                const uint32_t x = ww[k];
+                uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;
+                M = (M << ((x >> 16) & 31u)) | 1u;
+                M = (M << ((x >> 8) & 31u)) | 1u;
+                M = (M << (x & 31u)) | 1u;                               // bit 0: the posting before the group
+                uint32_t *dst = lds_all + (q >> 5);
+                const unsigned long long m64 = (unsigned long long)M << (q & 31u);
+                atomicOr(dst, (uint32_t)m64);
+                atomicOr(dst + 1, (uint32_t)(m64 >> 32));
+                q += __builtin_amdgcn_sad_u8(x, 0u, 0u);
+            }
+        }
+        return;
+    }
     if (act) {
         uint32_t q = u + bmbits;
         const uint32_t limb = lim + bmbits;
@@ -815,14 +836,43 @@ __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
     const bool wide = work && hi - lo > 0xFFFFu;             // (a sparse stretch: ids go out one by one, below)
     if (work && !wide && count != 0u) {
         const unsigned long long He = LN.live ? H : 0ull;
-        uint32_t q = q0;
+        // 64 steps, the same for every lane: the running id advances by the gap byte (SDWA picks it), the answer word is
+        // shifted left by adding it to itself — the bit that falls out is the step's write mask — and the lanes whose bit
+        // was set store the id's 16-bit offset at their place and move on: 3 vector + 1 LDS + 2 scalar instructions a posting
+        // (s_and_saveexec writes SCC: the clobber list says so — the compiler keeps branch conditions there across statements).
+        // (The compiler's form of `if (bit) st[q++] = v` is 7 + 1 + 2.)
+        uint32_t qa = (uint32_t)(uintptr_t)st + 2u * q0;        // (low 32 bits of an LDS pointer = its offset)
         uint32_t v = LN.base - lo;
-        if (He & 1ull) { st[q] = (uint16_t)v; q++; }
-#pragma unroll
-        for (uint32_t k = 0; k < 63u; k++) {
-            v += (LN.ww[k >> 2] >> (8u * (k & 3u))) & 0xFFu;
-            if ((He >> (k + 1u)) & 1ull) { st[q] = (uint16_t)v; q++; }
-        }
+        uint32_t h = __builtin_bitreverse32((uint32_t)He);
+        unsigned long long sx;
+        asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\t"
+                     "s_and_saveexec_b64 %3, vcc\n\t"
+                     "ds_write_b16 %2, %0\n\t"
+                     "v_add_u32 %2, 2, %2\n\t"
+                     "s_mov_b64 exec, %3"
+                     : "+v"(v), "+v"(h), "+v"(qa), "=&s"(sx) : : "vcc", "scc", "memory");
+#define A2_STEP_TXT(SEL)                                                                                               \
+        "v_add_u32_sdwa %0, %0, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL "\n\t"           \
+        "v_add_co_u32 %1, vcc, %1, %1\n\t"                                                                            \
+        "s_and_saveexec_b64 %3, vcc\n\t"                                                                              \
+        "ds_write_b16 %2, %0\n\t"                                                                                     \
+        "v_add_u32 %2, 2, %2\n\t"                                                                                     \
+        "s_mov_b64 exec, %3\n\t"
+#define A2_STAGE_STEP(W, SEL) asm volatile(A2_STEP_TXT(SEL) : "+v"(v), "+v"(h), "+v"(qa), "=&s"(sx) : "v"(W) : "vcc", "scc", "memory");
+#define A2_STAGE_3(W) asm volatile(A2_STEP_TXT("BYTE_0") A2_STEP_TXT("BYTE_1") A2_STEP_TXT("BYTE_2") : "+v"(v), "+v"(h), "+v"(qa), "=&s"(sx) : "v"(W) : "vcc", "scc", "memory");
+#define A2_STAGE_WORD(W) asm volatile(A2_STEP_TXT("BYTE_0") A2_STEP_TXT("BYTE_1") A2_STEP_TXT("BYTE_2") A2_STEP_TXT("BYTE_3") : "+v"(v), "+v"(h), "+v"(qa), "=&s"(sx) : "v"(W) : "vcc", "scc", "memory");
+        A2_STAGE_WORD(LN.ww[0]) A2_STAGE_WORD(LN.ww[1]) A2_STAGE_WORD(LN.ww[2]) A2_STAGE_WORD(LN.ww[3])
+        A2_STAGE_WORD(LN.ww[4]) A2_STAGE_WORD(LN.ww[5]) A2_STAGE_WORD(LN.ww[6])
+        A2_STAGE_3(LN.ww[7])                                                                                        // postings 1..31
+        h = __builtin_bitreverse32((uint32_t)(He >> 32));
+        A2_STAGE_STEP(LN.ww[7], "BYTE_3")
+        A2_STAGE_WORD(LN.ww[8]) A2_STAGE_WORD(LN.ww[9]) A2_STAGE_WORD(LN.ww[10]) A2_STAGE_WORD(LN.ww[11])
+        A2_STAGE_WORD(LN.ww[12]) A2_STAGE_WORD(LN.ww[13]) A2_STAGE_WORD(LN.ww[14])
+        A2_STAGE_3(LN.ww[15])                                                                                       // postings 33..63
+#undef A2_STAGE_WORD
+#undef A2_STAGE_3
+#undef A2_STAGE_STEP
+#undef A2_STEP_TXT
         if (hm_any != 0ull) {                   // rows with multi-byte gaps: decoded again, every hit ranks itself among its row's answers
 #pragma unroll 1
             for (uint32_t r = 0; r < A2_ROWS; r++) {
