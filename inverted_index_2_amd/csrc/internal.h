@@ -59,7 +59,7 @@ struct ii2_ctx {
     uint32_t lb_epoch = 0;              // launches so far
     uint64_t lb_fallbacks = 0;          // calls repeated through the two-kernel form
     uint32_t lb_pending = 0;            // epoch of a fused launch whose error word has not been looked at yet (0: none)
-    int64_t opt_intersect_and2 = 0;     // dense 2-list ANDs: the shorter list's postings are tested against the longer one's bitmap (intersect_and2.hip)
+    int64_t opt_intersect_and2 = 1;     // dense 2-list ANDs: the shorter list's postings are tested against the longer one's bitmap (intersect_and2.hip)
     int64_t opt_profile_events = 0;     // N > 0: bracket the dominant kernel of every Nth call with HIP events
     uint64_t prof_calls = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;   // recorded pairs since the last read

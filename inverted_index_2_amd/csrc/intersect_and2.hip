@@ -77,39 +77,35 @@ __device__ __forceinline__ A2Bytes a2_fetch(const uint8_t *payload, bool rv, uin
     return B;
 }
 
-// The lane's 64 bytes as sixteen words with the bytes past the block's end zeroed; `hard` = my row's block has a multi-byte gap
-// (or more than 256 payload bytes) and must go through the general decoder.  Returns the ballot of the hard rows' lanes.
+// The lane's 64 bytes as sixteen words.  A FULL block of one-byte gaps has 255 payload bytes: the row's last lane holds one byte
+// that is not its own (zeroed here).  Every other block of a valid row — a list's short last block, a block with a multi-byte
+// gap — is `hard`: it goes through the general wave decoder, which takes any block.  Returns the ballot of the hard rows' lanes.
 __device__ __forceinline__ unsigned long long a2_prep(const A2Bytes &B, bool rv, uint32_t len, uint32_t rl, uint32_t (&ww)[16]) {
-    const uint32_t myoff = 64u * rl;
-    const uint32_t nb = len > myoff ? (len - myoff < 64u ? len - myoff : 64u) : 0u;   // my bytes that belong to the block
     ww[0] = B.g[0].x; ww[1] = B.g[0].y; ww[2] = B.g[0].z; ww[3] = B.g[0].w;
     ww[4] = B.g[1].x; ww[5] = B.g[1].y; ww[6] = B.g[1].z; ww[7] = B.g[1].w;
     ww[8] = B.g[2].x; ww[9] = B.g[2].y; ww[10] = B.g[2].z; ww[11] = B.g[2].w;
-    ww[12] = B.g[3].x; ww[13] = B.g[3].y; ww[14] = B.g[3].z; ww[15] = B.g[3].w;
-    if (__ballot(rv && len != 255u) == 0ull) {      // full blocks: only the row's last lane holds a byte that is not its own
-        if (rl == 3u) ww[15] &= 0x00FFFFFFu;
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < 16u; k++) {
-            const uint32_t n = nb > 4u * k ? (nb - 4u * k < 4u ? nb - 4u * k : 4u) : 0u;
-            ww[k] &= n >= 4u ? 0xFFFFFFFFu : ((1u << (8u * n)) - 1u);
-        }
-    }
+    ww[12] = B.g[3].x; ww[13] = B.g[3].y; ww[14] = B.g[3].z;
+    ww[15] = rl == 3u ? (B.g[3].w & 0x00FFFFFFu) : B.g[3].w;
     uint32_t any = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16u; k++) any |= ww[k];
-    const bool hard = rv && (len > 256u || (any & 0x80808080u) != 0u);
+    const bool hard = rv && (len != 255u || (any & 0x80808080u) != 0u);
     return __ballot(hard);
 }
 
 // id of the posting right before my bytes: the block's first doc + the gap sums of the row's lanes before me (rows of
 // one-byte gaps only; `live` = my row is one).  *wide_or = OR of my sixteen group sums (a bit above bit 4 = some group of four
 // postings spans 32 docs or more).
+__device__ __forceinline__ uint32_t a2_group_sum(uint32_t x) {      // sum of a word's four bytes; opaque, so that the compiler recomputes it where it
+    uint32_t g;                                                       // is needed instead of keeping sixteen of them (or their prefix sums) in registers
+    asm volatile("v_sad_u8 %0, %1, 0, 0" : "=v"(g) : "v"(x));
+    return g;
+}
 __device__ __forceinline__ uint32_t a2_lane_base(const uint32_t (&ww)[16], bool live, uint32_t f, uint32_t rl, uint32_t *wide_or) {
     uint32_t acc = 0, wide = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 16u; k += 2u) {                             // (two groups per step: three-input or / add)
-        const uint32_t g0 = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u), g1 = __builtin_amdgcn_sad_u8(ww[k + 1u], 0u, 0u);
+        const uint32_t g0 = a2_group_sum(ww[k]), g1 = a2_group_sum(ww[k + 1u]);
         wide |= g0 | g1;
         acc += g0 + g1;
     }
@@ -179,7 +175,7 @@ __device__ __forceinline__ void a2_mark_rows(uint32_t *lds_all, uint32_t *bm, co
                 const unsigned long long m64 = (unsigned long long)M << (q & 31u);
                 atomicOr(dst, (uint32_t)m64);
                 atomicOr(dst + 1, (uint32_t)(m64 >> 32));
-                q += __builtin_amdgcn_sad_u8(x, 0u, 0u);
+                q += a2_group_sum(x);
             }
         }
         return;
@@ -190,7 +186,7 @@ __device__ __forceinline__ void a2_mark_rows(uint32_t *lds_all, uint32_t *bm, co
 #pragma unroll
         for (uint32_t k = 0; k < 16u; k++) {
             const uint32_t x = ww[k];
-            const uint32_t gs = __builtin_amdgcn_sad_u8(x, 0u, 0u);
+            const uint32_t gs = a2_group_sum(x);
             const bool isw = exactlane || gs >= 32u;                     // the four gaps do not fit one 32-bit mask: placed by the loop below
             uint32_t M = (1u << ((x >> 24) & 31u)) | 1u;
             M = (M << ((x >> 16) & 31u)) | 1u;
@@ -210,7 +206,7 @@ __device__ __forceinline__ void a2_mark_rows(uint32_t *lds_all, uint32_t *bm, co
         uint32_t prev = 0u;
 #pragma unroll
         for (uint32_t k = 0; k < 16u; k++) {
-            const uint32_t gs = __builtin_amdgcn_sad_u8(ww[k], 0u, 0u);
+            const uint32_t gs = a2_group_sum(ww[k]);
             const bool isw = act && haswide && (exactlane || gs >= 32u);
             if (__ballot(isw) != 0ull) {
                 if (isw) {
@@ -239,16 +235,16 @@ struct A2Lane {
     unsigned long long valid;    // bit j: posting 64 rl + j of my row's block exists (live lanes; 0 otherwise)
 };
 __device__ __forceinline__ void a2_lane_setup(A2Lane &L, const A2Bytes &B, bool rv, const uint4 &E, uint32_t rl, uint32_t row) {
-    const uint32_t len = rv ? E.w - E.y : 0u;
+    uint32_t q1 = E.w;
+    asm volatile("" : "+v"(q1));            // (opaque: everything below stays where the call is — hoisted above the marking passes it would hold registers there)
+    const uint32_t len = rv ? q1 - E.y : 0u;
     L.hm = a2_prep(B, rv, len, rl, L.ww);
     const bool rowhard = ((L.hm >> (4u * row)) & 0xFull) != 0ull;
     L.live = rv && !rowhard;
     uint32_t wide;
     L.base = a2_lane_base(L.ww, L.live, E.x, rl, &wide);
-    // a block of one-byte gaps holds len + 1 postings; mine are 64 rl ... 64 rl + 63: the one before my bytes, then my bytes 0..62
-    const uint32_t cnt = len + 1u;
-    const uint32_t nm = cnt > 64u * rl ? (cnt - 64u * rl < 64u ? cnt - 64u * rl : 64u) : 0u;
-    L.valid = !L.live ? 0ull : nm >= 64u ? ~0ull : ((1ull << nm) - 1ull);
+    // a live row's block is full (256 postings): mine are 64 rl ... 64 rl + 63 — the one before my bytes, then my bytes 0..62
+    L.valid = L.live ? ~0ull : 0ull;
 }
 
 template <bool RANGE>
