@@ -901,7 +901,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
             dp.lb_grp = ctx->d_lb + 8 + ctx->lb_cap;
             dp.lb_epoch = ++ctx->lb_epoch;
             if (!ctx->lb_pending) ctx->lb_pending = dp.lb_epoch;
-            dp.lb_spin = ctx->opt_and2_spin > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_and2_spin, 0x7FFFFFFF) : 0u;
+            dp.lb_spin = ctx->opt_and2_spin > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_and2_spin, 0x7FFFFFFF) : ctx->opt_and2_spin < 0 ? 0xFFFFFFFFu : 0u;
             const double spanA = (double)dp.last_doc[1] - (double)dp.first_doc[1] + 1.0;
             dp.a_scale = (float)((double)views[1].nblk / spanA);
             dp.b_dpb = (float)per_block_span;

@@ -110,6 +110,45 @@ def test_dense_zipf_pairs_match_the_oracle(ctx):
     _check(ctx, [lo, hi])
 
 
+def test_and2_bounded_wait_runs_out(ctx):
+    """The one-launch two-list AND orders its output with waits between workgroups (look-back).  Every wait is bounded; when one
+    runs out (forced here for workgroup 1: option intersect.and2_spin < 0) the call's count is all ones, ii2_intersect repeats
+    the query through the two-kernel form and still returns the exact result, and ii2_ctx_sync reports the asynchronous call."""
+    from inverted_index_2_amd.engine import II2Error
+    rng = np.random.default_rng(11)
+    U = 3_000_000
+    a, b = bernoulli(rng, 0.5, 0, U), bernoulli(rng, 0.3, 0, U)
+    want = np.intersect1d(a, b, assume_unique=True).astype(np.uint32)
+    seg = ctx.encode_lists([a, b])
+    ls = [(seg, 0), (seg, 1)]
+    out = ctx.empty(b.size + 16)
+    dcnt = ctx.empty(8, np.uint64)
+    ctx.set_option("intersect.and2", 1)
+    try:
+        ctx.set_option("intersect.and2_spin", -1)
+        _, n = ctx.intersect(ls, out=out)                     # synchronous: repeated inside the call
+        assert n == want.size and np.array_equal(out.download(n), want)
+        ctx.intersect_async(ls, None, out, dcnt)              # asynchronous: poisoned count, reported at the next sync
+        with pytest.raises(II2Error):
+            ctx.sync()
+        assert int(dcnt.download(1)[0]) == 0xFFFFFFFFFFFFFFFF
+        ctx.set_option("intersect.and2_spin", 0)
+        ctx.intersect_async(ls, None, out, dcnt)              # and the next call is clean again
+        ctx.sync()
+        n = int(dcnt.download(1)[0])
+        assert n == want.size and np.array_equal(out.download(n), want)
+        for spin in (1, 2, 5):                                # a tiny budget: some waits run out on their own; the sync call stays exact
+            ctx.set_option("intersect.and2_spin", spin)
+            _, n = ctx.intersect(ls, out=out)
+            assert n == want.size and np.array_equal(out.download(n), want), spin
+    finally:
+        ctx.set_option("intersect.and2_spin", 0)
+        try:
+            ctx.sync()
+        except II2Error:
+            pass
+
+
 # ---- the same kernel with OR semantics: unions paced by a long dense list (PrefixSearch, inverted_index.go:274-292) ----
 def _check_union(ctx, lists, removed=None, split=False):
     want = lists[0]
