@@ -767,6 +767,34 @@ static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, con
     return II2_OK;
 }
 
+// Look-back records for a launch of n_wg workgroups (lookback.h): a buffer of the context's own that only those kernels write,
+// every word tagged with its launch's number - nothing to clear between launches (cleared when it grows or the numbers wrap).
+int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb) {
+    hipStream_t st = ctx->stream;
+    if (n_wg > ctx->lb_cap || ctx->lb_epoch >= (1u << 24) - 1u) {
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (n_wg > ctx->lb_cap) {
+            if (ctx->d_lb) (void)hipFree(ctx->d_lb);
+            ctx->d_lb = nullptr;
+            ctx->lb_cap = 0;
+            const size_t cap_wg = std::max<size_t>(4096, n_wg + n_wg / 4);
+            if (hipMalloc((void **)&ctx->d_lb, (8 + cap_wg + 2 * ((cap_wg + 63) / 64)) * sizeof(unsigned long long)) != hipSuccess)
+                return fail(ctx, II2_ENOMEM, "look-back records allocation failed");
+            ctx->lb_cap = cap_wg;
+        }
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_lb, 0, (8 + ctx->lb_cap + 2 * ((ctx->lb_cap + 63) / 64)) * sizeof(unsigned long long), st));
+        ctx->lb_epoch = 0;
+        ctx->lb_pending = 0;
+    }
+    lb->err = ctx->d_lb;
+    lb->agg = ctx->d_lb + 8;
+    lb->grp = ctx->d_lb + 8 + ctx->lb_cap;
+    lb->epoch = ++ctx->lb_epoch;
+    lb->spin = 0;
+    if (!ctx->lb_pending) ctx->lb_pending = lb->epoch;
+    return II2_OK;
+}
+
 // first doc, first doc of the last block and last doc of a non-empty list: fetched once per (segment, list), then cached
 static int list_span(ii2_ctx *ctx, const ii2_seg *seg, uint64_t idx, const ListView &v, ii2_seg::ListSpan *out) {
     if (seg->h_spans.size() == 3 * seg->n_lists && idx < seg->n_lists) {      // mirrored when the segment was created: no fetch, no sync
@@ -879,29 +907,8 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         if (and2 && ctx->opt_intersect_and2 == 1) {
             // one launch (k_and2_fused): the look-back records live in a buffer of their own (only these kernels write it, every
             // word tagged with its launch's number: nothing to clear between launches)
-            const size_t n_grp = (grid + 63u) / 64u;
-            if (grid > ctx->lb_cap || ctx->lb_epoch == 0xFFFFFFFFu) {
-                HIP_TRY(ctx, hipStreamSynchronize(st));
-                if (grid > ctx->lb_cap) {
-                    if (ctx->d_lb) (void)hipFree(ctx->d_lb);
-                    ctx->d_lb = nullptr;
-                    ctx->lb_cap = 0;
-                    const size_t cap_wg = std::max<size_t>(4096, (size_t)grid + grid / 4);
-                    if (hipMalloc((void **)&ctx->d_lb, (8 + cap_wg + 2 * ((cap_wg + 63) / 64)) * sizeof(unsigned long long)) != hipSuccess)
-                        return fail(ctx, II2_ENOMEM, "look-back records allocation failed");
-                    ctx->lb_cap = cap_wg;
-                }
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_lb, 0, (8 + ctx->lb_cap + 2 * ((ctx->lb_cap + 63) / 64)) * sizeof(unsigned long long), st));
-                ctx->lb_epoch = 0;
-                ctx->lb_pending = 0;
-            }
-            (void)n_grp;
-            dp.lb_err = ctx->d_lb;
-            dp.lb_agg = ctx->d_lb + 8;
-            dp.lb_grp = ctx->d_lb + 8 + ctx->lb_cap;
-            dp.lb_epoch = ++ctx->lb_epoch;
-            if (!ctx->lb_pending) ctx->lb_pending = dp.lb_epoch;
-            dp.lb_spin = ctx->opt_and2_spin > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_and2_spin, 0x7FFFFFFF) : ctx->opt_and2_spin < 0 ? 0xFFFFFFFFu : 0u;
+            if (int rcl = ii2_lookback_prepare(ctx, grid, &dp.lb)) return rcl;
+            if (ctx->opt_and2_spin) dp.lb.spin = ctx->opt_and2_spin > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_and2_spin, 0x7FFFFFFF) : 0xFFFFFFFFu;
             const double spanA = (double)dp.last_doc[1] - (double)dp.first_doc[1] + 1.0;
             dp.a_scale = (float)((double)views[1].nblk / spanA);
             dp.b_dpb = (float)per_block_span;

@@ -233,6 +233,15 @@ struct UnionRankParams {
 };
 hipError_t launch_union_rank(const UnionRankParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 
+// output offsets inside one launch (lookback.h): records {epoch : 24 | value : 40} in a buffer of the context's own
+struct LookBack {
+    unsigned long long *agg;     // [workgroups]
+    unsigned long long *grp;     // [2 * ceil(workgroups / 64)]
+    unsigned long long *err;     // = epoch when a bounded wait ran out
+    uint32_t epoch;              // this launch's number, 1 .. 2^24 - 1
+    uint32_t spin;               // polls a wait may take (0: default; 0xFFFFFFFF: tests - workgroup 1 gives up at once)
+};
+
 // dense streaming intersection (intersect_dense.hip)
 constexpr uint32_t DENSE_MAXL = 4;             // lists it takes
 constexpr uint32_t DENSE_CAPW = 16384;         // docs per LDS window of a wave
@@ -257,18 +266,17 @@ struct DenseParams {
     unsigned long long *debug;   // optional per-workgroup cycle counters [2048][8] (diagnostics)
     uint32_t debug_expand;       // the counters are the expand kernel's (option debug.stamps = 2), else the tile kernel's
     uint2 *hmask;                // two-list AND (intersect_and2.hip): one answer bit per posting of lists[0], 64 bits per lane of a wave
-    // ... in one launch (k_and2_fused): look-back records {epoch << 32 | ids}; lb_agg == nullptr selects the two-kernel form
-    unsigned long long *lb_agg;  // [workgroups]
-    unsigned long long *lb_grp;  // [2 * groups of 64 workgroups] {ids of the group, ids up to and including the group}
-    unsigned long long *lb_err;  // = the launch's epoch when a workgroup's bounded wait ran out
-    uint32_t lb_epoch;           // this launch's number (never 0)
-    uint32_t lb_spin;            // polls a wait may take (0 = default)
+    LookBack lb;                 // ... in one launch (k_and2_fused): the output offsets come from a look-back; lb.agg == nullptr selects the two-kernel form
     float a_scale;               // blocks of lists[1] per doc and ...
     float b_dpb;                 // ... docs per block of lists[0]: where a wave's first probe of lists[1]'s skip table goes
 };
 hipError_t launch_intersect_dense(const DenseParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 // AND of exactly two lists: lists[1] is marked, the postings of lists[0] are tested against it (meta = {first doc, last doc, ids, flags})
 hipError_t launch_intersect_and2(const DenseParams &p, hipStream_t s, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
+}  // namespace ii2
+int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb);      // api.cpp; ctx->mu held
+namespace ii2 {
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;
 hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s);

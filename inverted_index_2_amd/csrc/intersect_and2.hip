@@ -21,6 +21,7 @@
 
 #include "dv1_device.h"
 #include "internal.h"
+#include "lookback.h"
 
 namespace ii2 {
 
@@ -591,28 +592,12 @@ __global__ __launch_bounds__(256) void k_and2_expand(DenseParams p) {
 // bytes and H in registers: it stages its ids (16-bit offsets, wave-private LDS, over the bitmap that is dead by then) and
 // writes them out once it knows where — the number of ids of all workgroups before its own.
 //
-// That prefix comes from a two-level look-back over small records in HBM (8-byte {epoch, value} words, relaxed agent-scope
-// stores and loads: the value and its ready flag travel in one word, so no fence is needed; the epoch is this launch's
-// number, so the records are never cleared):
-//   agg[g]            ids of workgroup g, published as soon as its four waves have counted;
-//   grp[2 G]          ids of group G (64 consecutive workgroups), published by the group's last workgroup once the group's
-//                     other members have published;
-//   grp[2 G + 1]      ids of all groups up to and including G, published by the same workgroup when it knows its own prefix.
-// A workgroup needs: the groups before its own — it reads their records 64 at a time, nearest first, and stops at the first
-// one that already carries a prefix — plus the members of its own group before it: two hops behind the slowest workgroup it
-// depends on, and it stages its ids while they travel.  Every wait is for a workgroup with a SMALLER index.  The hardware
-// starts the workgroups of a launch in index order on every XCD, so the lowest unfinished workgroup is always running and
-// waits for nobody: that is not a HIP guarantee, so every wait is bounded — a workgroup that runs out of patience writes the
-// launch's epoch into the error words and leaves without writing ids, the last workgroup then poisons the count (all ones),
-// and the host repeats a failed call through the two kernels above.
-constexpr uint32_t A2_LB_GROUP = 64;
-constexpr uint32_t A2_LB_SPIN = 1u << 21;                        // polls (each >= ~1 us): seconds in all
+// That prefix comes from the look-back of lookback.h (two hops behind the slowest workgroup it depends on; every wait bounded:
+// a workgroup that runs out of patience leaves without writing ids, the last workgroup then poisons the count - all ones - and
+// the host repeats a failed call through the two kernels above).
 constexpr uint32_t A2F_STAGE_W = (A2_STAGE + 1u) / 2u;            // stage in words (aliases the bitmap, which is dead by then)
 constexpr uint32_t A2F_WAVE_LDS = (A2F_STAGE_W > A2_NW ? A2F_STAGE_W : A2_NW) + A2_HS;
 static_assert(A2F_STAGE_W % 4u == 0u, "16-byte alignment of the per-wave LDS regions");
-
-__device__ __forceinline__ unsigned long long a2_ld(const unsigned long long *q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void a2_st(unsigned long long *q, unsigned long long v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
     __shared__ __align__(16) uint32_t lds[4][A2F_WAVE_LDS];
@@ -631,10 +616,6 @@ __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
     const ListView LB = p.lists[0], LA = p.lists[1];
     const uint32_t b0 = w * A2_ROWS;
     const uint32_t b1 = b0 + A2_ROWS < LB.nblk ? b0 + A2_ROWS : LB.nblk;
-    const uint32_t ep = p.lb_epoch;
-    const unsigned long long eptag = (unsigned long long)ep << 32;
-    const uint32_t spin_limit = p.lb_spin ? p.lb_spin : A2_LB_SPIN;
-    const bool force_bad = p.lb_spin == 0xFFFFFFFFu && blockIdx.x == 1u;      // (tests: workgroup 1 behaves as if its wait had run out)
     uint32_t count = 0, lo = 0, hi = 0;
     unsigned long long H = 0ull, hm_any = 0ull;
     A2Lane LN;
@@ -808,26 +789,10 @@ __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
     const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
     const uint32_t total = c0 + c1 + c2 + c3;
     const uint32_t before = wv == 0u ? 0u : wv == 1u ? c0 : wv == 2u ? c0 + c1 : c0 + c1 + c2;
-    const uint32_t G = g / A2_LB_GROUP, gi = g % A2_LB_GROUP;
-    const bool leader = gi == A2_LB_GROUP - 1u || g == gridDim.x - 1u;
-    unsigned long long *agg = p.lb_agg, *grp = p.lb_grp;
-    if (threadIdx.x == 0) a2_st(&agg[g], eptag | total);
+    if (threadIdx.x == 0) lb_publish(p.lb, g, total);
     II2_STAMP(4)              // count, barrier, publish
-    if (wv == 1u && leader) {                   // the group's ids, as soon as its other members have published theirs
-        uint32_t spins = 0;
-        unsigned long long v;
-        bool bad = false;
-        for (;;) {
-            v = (uint32_t)l < gi ? a2_ld(&agg[(size_t)G * A2_LB_GROUP + (uint32_t)l]) : eptag;
-            if (__ballot((uint32_t)(v >> 32) != ep) == 0ull) break;
-            if (++spins > spin_limit) { bad = true; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        const uint32_t gtot = wave_sum(bad ? 0u : (uint32_t)v) + total;
-        if (l == 0) {
-            if (!bad) a2_st(&grp[2 * (size_t)G], eptag | gtot);
-            else { wg_err = 1u; a2_st(p.lb_err, (unsigned long long)ep); }
-        }
+    if (wv == 1u && lb_is_leader(g, gridDim.x)) {            // the group's ids, as soon as its other members have published theirs
+        if (!lb_group_publish(p.lb, g, total) && l == 0) { wg_err = 1u; lb_fail(p.lb); }
     }
     // ---- stage the ids of my postings whose answer bit is set: 16-bit offsets from the round's first doc, in output order
     const bool wide = work && hi - lo > 0xFFFFu;             // (a sparse stretch: ids go out one by one, below)
@@ -899,49 +864,11 @@ __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
     II2_STAMP(5)              // stage
     // ---- the ids of all workgroups before mine (wave 0)
     if (wv == 0u) {
-        bool bad = force_bad;
-        uint32_t spins = 0;
-        unsigned long long a;
-        for (;;) {                              // members of my group before me
-            a = (uint32_t)l < gi ? a2_ld(&agg[(size_t)G * A2_LB_GROUP + (uint32_t)l]) : eptag;
-            if (__ballot((uint32_t)(a >> 32) != ep) == 0ull) break;
-            if (bad || ++spins > spin_limit) { bad = true; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
-        const unsigned long long mem = wave_sum(bad ? 0u : (uint32_t)a);
-        unsigned long long accg = 0ull;         // groups before mine: 64 at a time, nearest first
-        int top = (int)G - 1;
-        while (top >= 0 && !bad) {
-            const int j = top - l;
-            const bool inr = j >= 0;
-            unsigned long long ga = eptag, gp = 0ull;
-            if (inr) { ga = a2_ld(&grp[2 * (size_t)j]); gp = a2_ld(&grp[2 * (size_t)j + 1]); }
-            const unsigned long long gav = __ballot(!inr || (uint32_t)(ga >> 32) == ep);
-            const unsigned long long gpv = __ballot(inr && (uint32_t)(gp >> 32) == ep);
-            if (gpv != 0ull) {                  // nearest group that already carries its prefix: the groups between it and me by their own ids
-                const uint32_t d = (uint32_t)__ffsll((long long)gpv) - 1u;
-                const unsigned long long need = (1ull << d) - 1ull;
-                if ((gav & need) == need) {
-                    const uint32_t part = wave_sum((uint32_t)l < d ? (uint32_t)ga : 0u);
-                    const unsigned long long gl = (unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)gp, (int)d);
-                    accg += part + (gl & 0xFFFFFFFFull);
-                    top = -1;
-                    break;
-                }
-            } else if (gav == ~0ull) {
-                accg += wave_sum(inr ? (uint32_t)ga : 0u);
-                top -= 64;
-                spins = 0;
-                continue;
-            }
-            if (++spins > spin_limit) { bad = true; break; }
-            __builtin_amdgcn_s_sleep(8);
-        }
+        unsigned long long pre = 0ull;
+        const bool ok = lb_prefix(p.lb, g, gridDim.x, total, &pre);
         if (l == 0) {
-            if (!bad) {
-                wg_off = accg + mem;
-                if (leader) a2_st(&grp[2 * (size_t)G + 1], eptag | ((accg + mem + total) & 0xFFFFFFFFull));
-            } else { wg_off = 0ull; wg_err = 1u; a2_st(p.lb_err, (unsigned long long)ep); }
+            wg_off = ok ? pre : 0ull;
+            if (!ok) { wg_err = 1u; lb_fail(p.lb); }
         }
     }
     II2_STAMP(6)              // look-back
@@ -949,7 +876,7 @@ __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
     const bool err = wg_err != 0u;
     const unsigned long long off = wg_off + before;
     if (g == gridDim.x - 1u && threadIdx.x == 0) {          // the last workgroup: the total, or all ones when some workgroup gave up
-        const bool anyerr = err || a2_ld(p.lb_err) == (unsigned long long)ep;
+        const bool anyerr = err || lb_failed(p.lb);
         *p.d_count = anyerr ? ~0ull : wg_off + total;
     }
     if (work && !err && count != 0u) {
@@ -1016,7 +943,7 @@ __global__ __launch_bounds__(256, 3) void k_and2_fused(DenseParams p) {
 hipError_t launch_intersect_and2(const DenseParams &p, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
     if (ev0) (void)hipEventRecord(ev0, s);
     const uint32_t grid = (p.n_waves + 3u) / 4u;
-    if (p.lb_agg != nullptr) {
+    if (p.lb.agg != nullptr) {
         hipLaunchKernelGGL(k_and2_fused, dim3(grid), dim3(256), 0, s, p);
         if (ev1) (void)hipEventRecord(ev1, s);
         return hipGetLastError();

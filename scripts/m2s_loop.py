@@ -1,0 +1,46 @@
+"""C3 / C4-shaped merge into a DV1 segment (ii2_merge_segments_to_seg) next to the raw merge, wall clock per call, for rocprofv3.
+Usage: python scripts/m2s_loop.py [terms=N] [segments=K] [steps=N] [check=0|1] [opt=value ...]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from inverted_index_2_amd import Context, synth
+T, k, steps, check = 1_000_000, 16, 5, 0
+ctx = Context(0)
+for kv in sys.argv[1:]:
+    key, v = kv.split("=")
+    if key == "terms": T = int(v)
+    elif key == "segments": k = int(v)
+    elif key == "steps": steps = int(v)
+    elif key == "check": check = int(v)
+    else: ctx.set_option(key, int(v))
+offs, vals, removed = synth.merge_workload_big(T, k, 1000.0, 100_000_000, threads=min(len(os.sched_getaffinity(0)), 32))
+segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+tomb = ctx.tombstones(removed)
+n_in = int(sum(int(o[-1]) for o in offs))
+del offs, vals
+out_off = ctx.empty(T + 1, np.uint64); out_vals = ctx.empty(n_in)
+_, _, st = ctx.merge(segs, tomb, out_off, out_vals)
+ctx.sync()
+t0 = time.perf_counter()
+for _ in range(steps):
+    ctx.merge(segs, tomb, out_off, out_vals)
+ctx.sync()
+raw_ms = (time.perf_counter() - t0) / steps * 1e3
+seg, st2 = ctx.merge_to_segment(segs, tomb)
+ctx.sync()
+if check:
+    import ctypes as C
+    want_off = out_off.download(); want_vals = out_vals.download(int(st.n_out))
+    got_off, got_vals = seg.decode()
+    assert np.array_equal(got_off, want_off) and np.array_equal(got_vals, want_vals), "merge_to_segment differs from the raw merge"
+    print("check ok", flush=True)
+info = seg.info
+seg.free()
+t0 = time.perf_counter()
+for _ in range(steps):
+    s2, _ = ctx.merge_to_segment(segs, tomb)
+    s2.free()
+ctx.sync()
+seg_ms = (time.perf_counter() - t0) / steps * 1e3
+print("postings_in", n_in, "out", int(st.n_out), "raw merge ms", round(raw_ms, 3), "to segment ms", round(seg_ms, 3), "ratio", round(seg_ms / raw_ms, 3),
+      "out bytes", int(info.n_bytes), "blocks", int(info.n_blocks), flush=True)
