@@ -274,9 +274,11 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
         HIP_TRY(ctx, launch_list_last_doc(seg->d_blk_off, seg->d_skip, seg->d_payload, seg->n_lists, seg->d_cnt, seg->d_blk_list, seg->d_last_doc,
                                           ctx->stream));
     }
-    seg->h_blk_off.resize(seg->n_lists + 1);
-    HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    if (seg->n_lists <= ii2_seg::SPAN_MIRROR_MAX) {      // (a segment of many lists mirrors them when a query first asks: ii2_seg_host_blk_off)
+        seg->h_blk_off.resize(seg->n_lists + 1);
+        HIP_TRY(ctx, hipMemcpyAsync(seg->h_blk_off.data(), seg->d_blk_off, (seg->n_lists + 1) * sizeof(uint32_t),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+    }
     // the lists' spans (what a query's path choice looks at), mirrored now so that no query has to fetch them
     if (seg->n_lists && seg->n_lists <= ii2_seg::SPAN_MIRROR_MAX) {
         if (int rcw = ii2_ws_reserve(ctx, align_up(3 * seg->n_lists * sizeof(uint32_t)) + 256)) return rcw;
@@ -334,6 +336,59 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     HIP_TRY(ctx, launch_enc_write(d_post_off, seg->d_blk_off, n_lists, d_values, nb, d_boff, seg->d_skip,
                                   seg->d_payload, n_postings, seg->d_blk_list, st));
     HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
+    int rc = seg_finish(ctx, seg.get(), true);
+    if (rc) return rc;
+    *out = seg.release();
+    return II2_OK;
+}
+
+// encode from device-resident CSR in ONE pass over the ids (encode_stream.hip) - the tail of Shard.Merge (shard.go:207 ->
+// file/writer.go:32-59).  The caller knows the number of non-empty lists and an upper bound of the payload (a merge: the inputs'
+// payload bytes + 5 per input block - a merged gap is never longer than the gap its posting had in its input list, and only
+// the inputs' block-first ids had none), so every array is allocated before the first kernel and nothing is read back until the
+// end.  Falls back to the two-pass encoder above when a bounded wait of the look-back runs out or the bound does not hold.
+int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values, uint64_t n_postings,
+                                   uint64_t n_nonempty, uint64_t payload_bound, ii2_seg **out) {
+    hipStream_t st = ctx->stream;
+    if (!ctx->opt_encode_stream || n_postings == 0) return ii2_seg_encode_dev_unlocked(ctx, n_lists, d_post_off, d_values, n_postings, out);
+    std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
+    if (!seg) return II2_ENOMEM;
+    seg->device = ctx->device;
+    seg->n_lists = n_lists;
+    seg->n_postings = n_postings;
+    const uint64_t nb_bound = n_postings / II2_DV1_BLOCK + std::min<uint64_t>(n_nonempty, n_lists) + 1;
+    if (nb_bound >= (1ull << 31)) return fail(ctx, II2_ERANGE, "too many DV1 blocks for one segment");
+    const uint64_t cap = std::min<uint64_t>(std::min<uint64_t>(payload_bound, 5ull * n_postings), 0xFFFFFFEFull);
+    seg->n_blocks = nb_bound;                      // (sizes the per-block arrays; the exact count comes back with the result)
+    if (dm_alloc((void **)&seg->d_blk_off, (n_lists + 1) * sizeof(uint32_t)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_skip, (nb_bound + 1) * sizeof(ii2_skip)) != hipSuccess ||
+        dm_alloc((void **)&seg->d_payload, cap + 16) != hipSuccess)
+        return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    if (int rcm = seg_alloc_meta(ctx, seg.get())) return rcm;
+    const size_t tmpb = scan_temp_bytes((size_t)n_lists + 1);
+    if (int rcw = ii2_ws_reserve(ctx, align_up((n_lists + 1) * sizeof(uint32_t)) + align_up(tmpb) + 4096)) return rcw;
+    uint32_t *d_nblk = ws_take<uint32_t>(ctx, n_lists + 1);
+    void *d_scan_tmp = ws_take<uint8_t>(ctx, tmpb);
+    HIP_TRY(ctx, launch_enc_list_blocks(d_post_off, n_lists, d_nblk, st));
+    HIP_TRY(ctx, scan_excl_u32(d_scan_tmp, tmpb, d_nblk, seg->d_blk_off, n_lists + 1, st));
+    LookBack lb;
+    if (int rcl = ii2_lookback_prepare(ctx, (size_t)enc_stream_workgroups(n_postings), &lb)) return rcl;
+    ctx->lb_pending = 0;                           // (this call looks at its own result below)
+    if (ctx->opt_encode_stream < 0) lb.spin = 0xFFFFFFFFu;      // tests: a wait runs out, the two-pass encoder takes over
+    uint64_t *d_res = ctx->d_mail + 8;
+    HIP_TRY(ctx, launch_enc_stream(d_post_off, d_values, seg->d_blk_off, n_lists, n_postings, seg->d_skip, seg->d_payload, cap, seg->d_blk_list,
+                                   d_res, lb, st));
+    HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_res, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    const uint64_t nbytes = ctx->h_mail[8], nb = ctx->h_mail[9];
+    if (nbytes == ~0ull || nb > nb_bound) {        // a bounded wait ran out, or the bound did not hold: the exact two-pass form
+        ctx->lb_fallbacks++;
+        seg.reset();
+        return ii2_seg_encode_dev_unlocked(ctx, n_lists, d_post_off, d_values, n_postings, out);
+    }
+    seg->n_blocks = nb;
+    seg->n_bytes = nbytes;
     int rc = seg_finish(ctx, seg.get(), true);
     if (rc) return rc;
     *out = seg.release();
@@ -1251,6 +1306,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;
     else if (k == "intersect.and2") ctx->opt_intersect_and2 = value;      // 0: n-list kernel, 1: one launch (look-back), 2: two kernels
     else if (k == "intersect.and2_spin") ctx->opt_and2_spin = value;
+    else if (k == "encode.stream") ctx->opt_encode_stream = value;        // 1: one-pass encoder behind a merge (default), 0: two-pass, -1: forced fallback (tests)
     else return fail(ctx, II2_EINVAL, "unknown option");
     return II2_OK;
 }

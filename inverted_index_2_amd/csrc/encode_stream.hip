@@ -1,0 +1,274 @@
+// encode_stream.hip — DV1 encoding of a CSR (post_off, values) in ONE pass over the ids (gfx950, wave64).
+// Role: Writer.Append -> intcomp.CompressUint32 of every merged term (reference shard.go:207, file/writer.go:32-59); the byte
+// format is this build's own (DV1, include/ii2.h) and the bytes are identical to the two-pass encoder's (codec.hip).
+//
+// codec.hip encodes block by block: a wave walks eight blocks one after the other, and every block costs it three dependent
+// round trips (owner list, its offsets, the ids) - and it does so twice, once for the blocks' sizes and, after a scan and a host
+// round trip for the payload's size, once more for the bytes: 2 x 3.9 GB read at ~2 TB/s for the 0.98 G postings of BASELINE
+// configs[2]'s merge, 5 ms behind an 11 ms merge.  Here the unit is a run of consecutive OUTPUT POSITIONS, whatever lists they
+// belong to:
+//   * a wave takes 1024 consecutive ids, 16 per lane (four 16-byte loads), a workgroup 4096;
+//   * which lists they belong to: one 64-way search of post_off for the wave's first position, then the lists that start inside
+//     the wave's run are read 64 at a time and leave their number at their first position in a wave-private LDS array; a prefix
+//     maximum over it tells every lane the list it starts in, one load tells it where that list began and which block it began
+//     with - from there the lane walks its 16 ids alone: position in the list (a multiple of 256 = a block's first id, which
+//     is not encoded), gap, varint length;
+//   * the workgroup's byte count goes through the look-back of lookback.h (payload offsets are a prefix sum over all
+//     workgroups); while it travels the wave writes its varints into LDS, then the bytes leave as aligned 16-byte stores and
+//     the blocks' skip entries {first id, byte offset} and owners are written by the lanes that hold their first ids.
+// One read of the ids, one write of the payload, no sizes array, no scan launch, no host round trip before the payload exists
+// (the caller allocates it from an upper bound).
+#include "dv1_device.h"
+#include "internal.h"
+#include "lookback.h"
+
+namespace ii2 {
+
+constexpr uint32_t ES_PER_LANE = 16;
+constexpr uint32_t ES_WAVE = 64u * ES_PER_LANE;              // ids per wave (1024)
+constexpr uint32_t ES_WG = 4u * ES_WAVE;                     // ids per workgroup
+constexpr uint32_t ES_STAGE = ES_WAVE * 5u + 32u;            // a wave's bytes at worst (five per id) + read-ahead of the copy-out
+constexpr uint32_t ES_WAVE_LDS = ((ES_STAGE > ES_WAVE * 4u ? ES_STAGE : ES_WAVE * 4u) + 15u) & ~15u;   // bytes: the stage, or (before it) one u32 per position
+
+// first index i in [0, n) with a[i] > x (a non-decreasing), searched 64 ways per round by the whole wave
+__device__ __forceinline__ uint64_t es_upper_bound(const uint64_t *__restrict__ a, uint64_t n, uint64_t x) {
+    const uint64_t l = (uint64_t)lane_id();
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t sp = hi - lo;
+        const uint64_t st = (sp + 63u) >> 6;
+        const uint64_t pos = lo + l * st;
+        const bool in = pos < hi;
+        const uint64_t f = in ? a[pos] : 0ull;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(in && f <= x));     // probes ascend: the matches are a prefix
+        const uint32_t nin = (uint32_t)__popcll(__ballot(in));
+        if (st == 1u) return cnt < nin ? lo + cnt : hi;
+        const uint64_t nlo = cnt ? lo + (uint64_t)(cnt - 1u) * st + 1u : lo;
+        hi = cnt < nin ? lo + (uint64_t)cnt * st : hi;
+        lo = nlo;
+    }
+    return lo;
+}
+
+// inclusive prefix maximum over the 64 lanes of a wave (lanes without a source see 0)
+__device__ __forceinline__ uint32_t es_wave_incl_max(uint32_t x) {
+    uint32_t y;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x = y > x ? y : x;
+    y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = y > x ? y : x;
+    return x;
+}
+
+// bytes of gap's LEB128 varint: ceil(bits / 7), bits >= 1
+__device__ __forceinline__ uint32_t es_varint_len(uint32_t gap) {
+    const uint32_t bits = 32u - (uint32_t)__clz((int)(gap | 1u));
+    return ((bits + 6u) * 37u) >> 8;                        // = (bits + 6) / 7 for bits <= 32
+}
+
+struct EncStreamParams {
+    const uint64_t *post_off;    // [n_lists + 1]
+    const uint32_t *values;      // [n]
+    const uint32_t *blk_off;     // [n_lists + 1] first block of every list (exclusive scan of ceil(cnt / 256))
+    uint64_t n_lists, n;
+    ii2_skip *skip;              // [n_blocks + 1]
+    uint8_t *payload;            // upper-bound allocation (+ 16)
+    uint32_t *blk_list;          // [n_blocks + 1]
+    uint64_t payload_cap;        // bytes the payload may take (the call fails, nothing useful written, when the bytes exceed it)
+    uint64_t *d_result;          // [0] payload bytes (all ones: a bounded wait ran out or the payload did not fit), [1] blocks
+    LookBack lb;
+};
+
+__global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
+    __shared__ __align__(16) uint8_t lds[4][ES_WAVE_LDS];
+    __shared__ uint32_t wcnt[4];
+    __shared__ unsigned long long wg_off;
+    __shared__ uint32_t wg_err;
+    const int l = lane_id();
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t g = blockIdx.x;
+    const uint64_t P0 = ((uint64_t)g * 4u + wv) * ES_WAVE;           // my wave's first output position
+    const bool work = P0 < p.n;                                       // wave-uniform
+    const uint32_t nloc = work ? (uint32_t)(p.n - P0 < ES_WAVE ? p.n - P0 : ES_WAVE) : 0u;
+    uint32_t *own = reinterpret_cast<uint32_t *>(lds[wv]);
+    uint8_t *st = lds[wv];
+    if (threadIdx.x == 0) wg_err = 0u;
+
+    uint32_t v[ES_PER_LANE];
+    uint32_t prev0 = 0;                      // the id before my first one
+    uint64_t l0 = 0;                         // list that holds position P0
+    uint32_t lens_lo = 0, lens_hi = 0;       // 3 bits per id: bytes of its varint (0: a block's first id)
+    uint32_t starts = 0;                     // bit j: my id j is a block's first
+    uint32_t lane_bytes = 0;
+    uint32_t my_list = 0;                    // list of my first id (relative to l0) ...
+    uint32_t my_pos = 0, my_blk = 0;         // ... its position in that list, and the list's first block
+    uint32_t ownv[ES_PER_LANE];
+    const uint32_t i0 = ES_PER_LANE * (uint32_t)l;
+    if (work) {
+        // ---- my 16 ids (guarded at the array's end) and the one before them
+        if (nloc == ES_WAVE) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.values + P0 + i0);
+            const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < ES_PER_LANE; j++) v[j] = i0 + j < nloc ? p.values[P0 + i0 + j] : 0u;
+        }
+        const uint32_t before_wave = P0 ? p.values[P0 - 1u] : 0u;
+        // ---- lists: the one that holds P0, then every non-empty list that starts inside (P0, P0 + nloc)
+        for (uint32_t i = 4u * (uint32_t)l; i < ES_WAVE; i += 256u) *reinterpret_cast<uint4 *>(&own[i]) = make_uint4(0, 0, 0, 0);
+        l0 = es_upper_bound(p.post_off, p.n_lists + 1u, P0) - 1ull;
+        const uint64_t P1 = P0 + nloc;
+        for (uint64_t i = (uint64_t)l;; i += 64u) {
+            const uint64_t li = l0 + 1ull + i;
+            const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
+            const bool in = s < P1;
+            if (in && li < p.n_lists && p.post_off[li + 1ull] > s) own[(uint32_t)(s - P0)] = (uint32_t)(li - l0);      // (several empty lists may share s: the non-empty one owns it)
+            if (__ballot(!in) != 0ull) break;
+        }
+        prev0 = wave_shift_up1(v[ES_PER_LANE - 1u], before_wave);
+        // ---- the list my first id belongs to: the last list that started at or before it
+        {
+            const uint4 *o4 = reinterpret_cast<const uint4 *>(&own[i0]);
+            const uint4 a = o4[0], b = o4[1], c = o4[2], d = o4[3];
+            ownv[0] = a.x; ownv[1] = a.y; ownv[2] = a.z; ownv[3] = a.w; ownv[4] = b.x; ownv[5] = b.y; ownv[6] = b.z; ownv[7] = b.w;
+            ownv[8] = c.x; ownv[9] = c.y; ownv[10] = c.z; ownv[11] = c.w; ownv[12] = d.x; ownv[13] = d.y; ownv[14] = d.z; ownv[15] = d.w;
+        }
+        uint32_t mx = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) mx = ownv[j] > mx ? ownv[j] : mx;      // (list numbers ascend with the position)
+        const uint32_t incl = es_wave_incl_max(mx);
+        uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (l == 0) before = 0u;
+        my_list = before;
+        const uint64_t ls = p.post_off[l0 + my_list];
+        my_blk = p.blk_off[l0 + my_list];
+        my_pos = (uint32_t)(P0 + i0 - ls);               // (a list holds < 2^32 ids)
+        // ---- walk A: position in the list, block starts, gaps, varint lengths
+        uint32_t pos = my_pos, pr = prev0;
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+            pos = ownv[j] ? 0u : pos;
+            const bool valid = i0 + j < nloc;
+            const bool start = (pos & 255u) == 0u;
+            const uint32_t len = (!valid || start) ? 0u : es_varint_len(v[j] - pr);
+            if (valid && start) starts |= 1u << j;
+            if (j < 8u) lens_lo |= len << (3u * j); else lens_hi |= len << (3u * (j - 8u));
+            lane_bytes += len;
+            pr = v[j];
+            pos++;
+        }
+    }
+    const uint32_t incl_b = wave_incl_scan(lane_bytes);
+    const uint32_t wave_bytes = wave_bcast(incl_b, 63);
+    const uint32_t lane_off = incl_b - lane_bytes;
+    if (l == 0) wcnt[wv] = wave_bytes;
+    lds_barrier();
+    const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    const uint32_t total = c0 + c1 + c2 + c3;
+    const uint32_t before_w = wv == 0u ? 0u : wv == 1u ? c0 : wv == 2u ? c0 + c1 : c0 + c1 + c2;
+    if (threadIdx.x == 0) lb_publish(p.lb, g, total);
+    if (wv == 1u && lb_is_leader(g, gridDim.x)) {
+        if (!lb_group_publish(p.lb, g, total) && l == 0) { wg_err = 1u; lb_fail(p.lb); }
+    }
+    // ---- walk B: my varints into the wave's LDS stage (over the list numbers, which every lane has read by now)
+    if (work && wave_bytes != 0u) {
+        uint32_t q = lane_off;
+        uint32_t pr = prev0;
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+            const uint32_t len = j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
+            uint32_t gap = v[j] - pr;
+            pr = v[j];
+            if (__ballot(len > 1u) == 0ull) {                // the usual step: one byte per gap
+                if (len) st[q] = (uint8_t)gap;
+                q += len;
+            } else {
+#pragma unroll
+                for (uint32_t k = 0; k < 5u; k++) {
+                    if (k < len) st[q + k] = (uint8_t)((gap & 0x7Fu) | (k + 1u < len ? 0x80u : 0u));
+                    gap >>= 7;
+                }
+                q += len;
+            }
+        }
+    }
+    // ---- where the workgroup's bytes begin
+    if (wv == 0u) {
+        unsigned long long pre = 0ull;
+        const bool ok = lb_prefix(p.lb, g, gridDim.x, total, &pre);
+        if (l == 0) {
+            wg_off = ok ? pre : 0ull;
+            if (!ok) { wg_err = 1u; lb_fail(p.lb); }
+        }
+    }
+    lds_barrier();
+    const bool err = wg_err != 0u;
+    const unsigned long long base = wg_off + before_w;           // global byte offset of my wave's first byte
+    const bool fits = wg_off + total <= p.payload_cap;
+    if (g == gridDim.x - 1u && threadIdx.x == 0) {              // the last workgroup: totals, the closing skip entry, the padding
+        const bool bad = err || lb_failed(p.lb) || !fits;
+        const unsigned long long nbytes = wg_off + total;
+        p.d_result[0] = bad ? ~0ull : nbytes;
+        const uint64_t nblk = p.blk_off[p.n_lists];
+        p.d_result[1] = nblk;
+        if (!bad) {
+            p.skip[nblk].first_doc = p.n ? p.values[p.n - 1u] : 0u;
+            p.skip[nblk].byte_off = (uint32_t)nbytes;
+            p.blk_list[nblk] = 0xFFFFFFFFu;
+            for (uint32_t k = 0; k < 16u; k++) p.payload[nbytes + k] = 0;
+        }
+    }
+    if (!work || err || !fits) return;
+    // ---- walk C: the skip entries and owners of the blocks whose first ids I hold
+    if (__ballot(starts != 0u) != 0ull) {
+        uint32_t pos = my_pos, lst = my_list, blk0 = my_blk, q = lane_off;
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+            if (ownv[j]) { blk0 += (pos + 255u) >> 8; pos = 0u; lst = ownv[j]; }      // the list before mine ends here: its blocks lie before my first
+            if ((starts >> j) & 1u) {
+                const uint32_t b = blk0 + (pos >> 8);
+                ii2_skip e;
+                e.first_doc = v[j];
+                e.byte_off = (uint32_t)(base + q);
+                p.skip[b] = e;
+                p.blk_list[b] = (uint32_t)(l0 + lst);
+            }
+            q += j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
+            pos++;
+        }
+    }
+    // ---- the wave's bytes leave as aligned 16-byte stores (LDS reads at any byte offset: five words + alignbyte), ragged ends byte by byte
+    if (wave_bytes != 0u) {
+        uint8_t *dst = p.payload + base;
+        const uint32_t mis = (uint32_t)((uintptr_t)dst & 15u);
+        const uint32_t head = mis ? (16u - mis < wave_bytes ? 16u - mis : wave_bytes) : 0u;      // bytes before the first aligned chunk
+        if ((uint32_t)l < head) dst[l] = st[l];
+        const uint32_t body = (wave_bytes - head) & ~15u;
+        const LdsBytes16 src{st};
+        for (uint32_t o = 16u * (uint32_t)l; o < body; o += 1024u) {
+            const uint4 w = src(head + o);
+            *reinterpret_cast<uint4 *>(dst + head + o) = w;
+        }
+        const uint32_t tail0 = head + body;
+        if (tail0 + (uint32_t)l < wave_bytes) dst[tail0 + l] = st[tail0 + l];
+    }
+}
+
+hipError_t launch_enc_stream(const uint64_t *post_off, const uint32_t *values, const uint32_t *blk_off, uint64_t n_lists, uint64_t n,
+                             ii2_skip *skip, uint8_t *payload, uint64_t payload_cap, uint32_t *blk_list, uint64_t *d_result, const LookBack &lb,
+                             hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    EncStreamParams p;
+    p.post_off = post_off; p.values = values; p.blk_off = blk_off; p.n_lists = n_lists; p.n = n;
+    p.skip = skip; p.payload = payload; p.blk_list = blk_list; p.payload_cap = payload_cap; p.d_result = d_result; p.lb = lb;
+    const uint64_t grid = (n + ES_WG - 1u) / ES_WG;
+    hipLaunchKernelGGL(k_enc_stream, dim3((unsigned)grid), dim3(256), 0, s, p);
+    return hipGetLastError();
+}
+uint64_t enc_stream_workgroups(uint64_t n) { return (n + ES_WG - 1u) / ES_WG; }
+
+}  // namespace ii2

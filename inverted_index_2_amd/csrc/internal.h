@@ -53,6 +53,7 @@ struct ii2_ctx {
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
     int64_t opt_intersect_dense = 1;    // dense 2..4-list queries go to the wave-streaming kernels (intersect_dense.hip)
     int64_t opt_dense_bpw = 0;          // driver blocks per wave there (0 = default)
+    int64_t opt_encode_stream = 1;      // merged segments are encoded in one pass over the ids (encode_stream.hip)
     int64_t opt_and2_spin = 0;          // bounded waits of its look-back: polls (0 = default; 1 forces the fallback in tests)
     unsigned long long *d_lb = nullptr; // look-back records of the fused two-list AND: [0] error word, then agg[], grp[]
     size_t lb_cap = 0;                  // workgroups the records hold
@@ -140,6 +141,8 @@ int ii2_union_dense_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *seg
 int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values,
                                 uint64_t n_postings, ii2_seg **out);
 int ii2_seg_decode_dev_unlocked(ii2_ctx *ctx, const ii2_seg *seg, uint64_t *d_post_off, uint32_t *d_values);
+int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *d_post_off, const uint32_t *d_values, uint64_t n_postings,
+                                   uint64_t n_nonempty, uint64_t payload_bound, ii2_seg **out);
 
 namespace ii2 {
 
@@ -296,6 +299,10 @@ hipError_t launch_enc_block_sizes(const uint64_t *post_off, const uint32_t *blk_
 hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, uint64_t n_lists,
                             const uint32_t *values, uint64_t n_blocks, const uint64_t *byte_off64,
                             ii2_skip *skip, uint8_t *payload, uint64_t n_postings, uint32_t *blk_list, hipStream_t s);
+hipError_t launch_enc_stream(const uint64_t *post_off, const uint32_t *values, const uint32_t *blk_off, uint64_t n_lists, uint64_t n,
+                             ii2_skip *skip, uint8_t *payload, uint64_t payload_cap, uint32_t *blk_list, uint64_t *d_result, const LookBack &lb,
+                             hipStream_t s);
+uint64_t enc_stream_workgroups(uint64_t n);
 hipError_t launch_enc_list_meta(const uint64_t *post_off, const uint32_t *values, uint64_t n_lists, uint32_t *cnt, uint32_t *last_doc, hipStream_t s);
 hipError_t launch_dec_block_counts(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, uint32_t *counts, hipStream_t s);
 hipError_t launch_dec_write(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, const uint64_t *bpo,

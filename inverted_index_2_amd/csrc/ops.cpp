@@ -257,8 +257,8 @@ int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *se
     *out = nullptr;
     int rc = check_segs(ctx, k, segs);
     if (rc) return rc;
-    uint64_t n_in = 0;
-    for (uint32_t s = 0; s < k; s++) n_in += segs[s]->n_postings;
+    uint64_t n_in = 0, bytes_in = 0, blocks_in = 0;
+    for (uint32_t s = 0; s < k; s++) { n_in += segs[s]->n_postings; bytes_in += segs[s]->n_bytes; blocks_in += segs[s]->n_blocks; }
     const uint64_t T = segs[0]->n_lists;
     // the merged CSR waits for the encoder in the context's grow-only staging buffers (no hipMalloc per Shard.Merge)
     uint64_t *off = (uint64_t *)ii2_pool_get(ctx, 2, (T + 1) * sizeof(uint64_t));
@@ -269,7 +269,8 @@ int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *se
     if (rc) return rc;
     if (stats) *stats = local;
     if (local.n_terms_out == 0) return II2_OK;      // shard.go:219-225: nothing survives, no segment is written
-    return ii2_seg_encode_dev_unlocked(ctx, T, off, vals, local.n_out, out);
+    // (payload bound: a merged gap is never longer than the gap its posting had in its input list; the inputs' block-first ids had none)
+    return ii2_seg_encode_stream_unlocked(ctx, T, off, vals, local.n_out, local.n_terms_out, bytes_in + 5 * blocks_in, out);
 }
 
 int ii2_union(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, const uint64_t *list_idx, const ii2_tomb *tomb,
