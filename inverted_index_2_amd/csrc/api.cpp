@@ -366,9 +366,11 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     if (int rcm = seg_alloc_meta(ctx, seg.get())) return rcm;
     const size_t tmpb = scan_temp_bytes((size_t)n_lists + 1);
-    if (int rcw = ii2_ws_reserve(ctx, align_up((n_lists + 1) * sizeof(uint32_t)) + align_up(tmpb) + 4096)) return rcw;
+    const size_t n_part = 4 * (size_t)enc_stream_workgroups(n_postings);
+    if (int rcw = ii2_ws_reserve(ctx, align_up((n_lists + 1) * sizeof(uint32_t)) + align_up(tmpb) + align_up(n_part * sizeof(uint32_t)) + 4096)) return rcw;
     uint32_t *d_nblk = ws_take<uint32_t>(ctx, n_lists + 1);
     void *d_scan_tmp = ws_take<uint8_t>(ctx, tmpb);
+    uint32_t *d_part = ws_take<uint32_t>(ctx, n_part);
     HIP_TRY(ctx, launch_enc_list_blocks(d_post_off, n_lists, d_nblk, st));
     HIP_TRY(ctx, scan_excl_u32(d_scan_tmp, tmpb, d_nblk, seg->d_blk_off, n_lists + 1, st));
     LookBack lb;
@@ -377,7 +379,7 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
     if (ctx->opt_encode_stream < 0) lb.spin = 0xFFFFFFFFu;      // tests: a wait runs out, the two-pass encoder takes over
     uint64_t *d_res = ctx->d_mail + 8;
     HIP_TRY(ctx, launch_enc_stream(d_post_off, d_values, seg->d_blk_off, n_lists, n_postings, seg->d_skip, seg->d_payload, cap, seg->d_blk_list,
-                                   d_res, lb, st));
+                                   d_part, d_res, lb, st));
     HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_res, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

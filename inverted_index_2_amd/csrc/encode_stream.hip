@@ -8,8 +8,8 @@
 // configs[2]'s merge, 5 ms behind an 11 ms merge.  Here the unit is a run of consecutive OUTPUT POSITIONS, whatever lists they
 // belong to:
 //   * a wave takes 1024 consecutive ids, 16 per lane (four 16-byte loads), a workgroup 4096;
-//   * which lists they belong to: one 64-way search of post_off for the wave's first position, then the lists that start inside
-//     the wave's run are read 64 at a time and leave their number at their first position in a wave-private LDS array; a prefix
+//   * which lists they belong to: the list of the wave's first position comes from a small partition pass (k_enc_partition: a
+//     bisection of post_off per wave, all waves at once), then the lists that start inside the wave's run are read 64 at a time and leave their number at their first position in a wave-private LDS array; a prefix
 //     maximum over it tells every lane the list it starts in, one load tells it where that list began and which block it began
 //     with - from there the lane walks its 16 ids alone: position in the list (a multiple of 256 = a block's first id, which
 //     is not encoded), gap, varint length;
@@ -68,6 +68,18 @@ __device__ __forceinline__ uint32_t es_varint_len(uint32_t gap) {
     return ((bits + 6u) * 37u) >> 8;                        // = (bits + 6) / 7 for bits <= 32
 }
 
+// list that holds every wave's first output position: the last list that starts at or before it.  One thread per wave of
+// k_enc_stream (a bisection of post_off each: a few dozen microseconds for a million waves, instead of a four-round search at the
+// head of every wave's chain of dependent loads)
+__global__ __launch_bounds__(256) void k_enc_partition(const uint64_t *__restrict__ post_off, uint64_t n_lists, uint64_t n, uint32_t *__restrict__ part) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t P0 = w * ES_WAVE;
+    if (P0 >= n) return;
+    uint64_t lo = 0, hi = n_lists + 1u;           // first index with post_off > P0 (post_off[n_lists] = n > P0)
+    while (lo < hi) { const uint64_t mid = lo + ((hi - lo) >> 1); if (post_off[mid] <= P0) lo = mid + 1u; else hi = mid; }
+    part[w] = (uint32_t)(lo - 1u);
+}
+
 struct EncStreamParams {
     const uint64_t *post_off;    // [n_lists + 1]
     const uint32_t *values;      // [n]
@@ -77,6 +89,7 @@ struct EncStreamParams {
     uint8_t *payload;            // upper-bound allocation (+ 16)
     uint32_t *blk_list;          // [n_blocks + 1]
     uint64_t payload_cap;        // bytes the payload may take (the call fails, nothing useful written, when the bytes exceed it)
+    const uint32_t *part;        // [waves] list that holds every wave's first position (k_enc_partition)
     uint64_t *d_result;          // [0] payload bytes (all ones: a bounded wait ran out or the payload did not fit), [1] blocks
     LookBack lb;
 };
@@ -120,13 +133,14 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
         const uint32_t before_wave = P0 ? p.values[P0 - 1u] : 0u;
         // ---- lists: the one that holds P0, then every non-empty list that starts inside (P0, P0 + nloc)
         for (uint32_t i = 4u * (uint32_t)l; i < ES_WAVE; i += 256u) *reinterpret_cast<uint4 *>(&own[i]) = make_uint4(0, 0, 0, 0);
-        l0 = es_upper_bound(p.post_off, p.n_lists + 1u, P0) - 1ull;
+        l0 = p.part[(uint64_t)g * 4u + wv];
         const uint64_t P1 = P0 + nloc;
         for (uint64_t i = (uint64_t)l;; i += 64u) {
             const uint64_t li = l0 + 1ull + i;
             const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
+            const uint64_t s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;          // (both requested together)
             const bool in = s < P1;
-            if (in && li < p.n_lists && p.post_off[li + 1ull] > s) own[(uint32_t)(s - P0)] = (uint32_t)(li - l0);      // (several empty lists may share s: the non-empty one owns it)
+            if (in && s1 > s) own[(uint32_t)(s - P0)] = (uint32_t)(li - l0);      // (several empty lists may share s: the non-empty one owns it)
             if (__ballot(!in) != 0ull) break;
         }
         prev0 = wave_shift_up1(v[ES_PER_LANE - 1u], before_wave);
@@ -259,10 +273,13 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
 }
 
 hipError_t launch_enc_stream(const uint64_t *post_off, const uint32_t *values, const uint32_t *blk_off, uint64_t n_lists, uint64_t n,
-                             ii2_skip *skip, uint8_t *payload, uint64_t payload_cap, uint32_t *blk_list, uint64_t *d_result, const LookBack &lb,
-                             hipStream_t s) {
+                             ii2_skip *skip, uint8_t *payload, uint64_t payload_cap, uint32_t *blk_list, uint32_t *part, uint64_t *d_result,
+                             const LookBack &lb, hipStream_t s) {
     if (n == 0) return hipSuccess;
+    const uint64_t waves = (n + ES_WAVE - 1u) / ES_WAVE;
+    hipLaunchKernelGGL(k_enc_partition, dim3((unsigned)((waves + 255u) / 256u)), dim3(256), 0, s, post_off, n_lists, n, part);
     EncStreamParams p;
+    p.part = part;
     p.post_off = post_off; p.values = values; p.blk_off = blk_off; p.n_lists = n_lists; p.n = n;
     p.skip = skip; p.payload = payload; p.blk_list = blk_list; p.payload_cap = payload_cap; p.d_result = d_result; p.lb = lb;
     const uint64_t grid = (n + ES_WG - 1u) / ES_WG;

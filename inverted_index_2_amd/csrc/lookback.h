@@ -56,12 +56,13 @@ __device__ __forceinline__ bool lb_group_publish(const LookBack &lb, uint32_t g,
     const uint32_t l = (uint32_t)lane_id(), G = g / LB_GROUP, gi = g % LB_GROUP;
     const uint32_t limit = lb_limit(lb);
     uint32_t spins = 0;
-    unsigned long long v;
+    unsigned long long v = lb_tag(lb);
+    bool have = l >= gi;
     for (;;) {
-        v = l < gi ? lb_ld(&lb.agg[(size_t)G * LB_GROUP + l]) : lb_tag(lb);
-        if (__ballot(!lb_ready(lb, v)) == 0ull) break;
+        if (!have) { v = lb_ld(&lb.agg[(size_t)G * LB_GROUP + l]); have = lb_ready(lb, v); }
+        if (__ballot(!have) == 0ull) break;
         if (++spins > limit) return false;
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(16);
     }
     const unsigned long long tot = lb_wave_sum64(v & LB_VALUE_MASK) + own;
     if (l == 0) lb_st(&lb.grp[2 * (size_t)G], lb_tag(lb) | (tot & LB_VALUE_MASK));
@@ -70,48 +71,72 @@ __device__ __forceinline__ bool lb_group_publish(const LookBack &lb, uint32_t g,
 
 // ONE WAVE (all 64 lanes) of workgroup g: the amounts of all workgroups before g.  A group's last workgroup also publishes the
 // group's inclusive prefix (`own` = its own amount).  Returns false when a wait ran out.
+// Polls are uncached loads, one fabric transaction each, and a launch may have hundreds of thousands of workgroups: a record
+// that has been seen ready is not read again, and the groups are looked at 16 at a time (the nearest one that carries a prefix
+// is normally one or two groups back) - the first version read 64 + 2 x 64 records per poll and its polls alone were as much
+// traffic as the payload of k_enc_stream.
+constexpr uint32_t LB_WINDOW = 16;
 __device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32_t n_wg, unsigned long long own, unsigned long long *prefix) {
     const uint32_t l = (uint32_t)lane_id(), G = g / LB_GROUP, gi = g % LB_GROUP;
     const uint32_t limit = lb_limit(lb);
     if (lb.spin == 0xFFFFFFFFu && g == 1u) return false;
+    // Three sets of records, ALL requested in the same round (an uncached load under a streaming kernel's traffic is ~3 us: three
+    // rounds one after the other were most of a workgroup's life in k_enc_stream):
+    //   a   members of my group before me;
+    //   b   all members of the group right before mine - by its members' amounts (one hop behind them) rather than by the group's
+    //       record (two: its last workgroup has to collect them first);
+    //   ga / gp   amount and inclusive prefix of the LB_WINDOW groups before that, nearest first.
+    unsigned long long a = lb_tag(lb), b = lb_tag(lb);
+    bool have_a = l >= gi, have_b = G == 0u;
+    int top = (int)G - 2;
+    unsigned long long accg = 0ull;
+    bool groups_done = top < 0;
     uint32_t spins = 0;
-    unsigned long long a;
-    for (;;) {                                  // members of my group before me
-        a = l < gi ? lb_ld(&lb.agg[(size_t)G * LB_GROUP + l]) : lb_tag(lb);
-        if (__ballot(!lb_ready(lb, a)) == 0ull) break;
-        if (++spins > limit) return false;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    const unsigned long long mem = lb_wave_sum64(a & LB_VALUE_MASK);
-    unsigned long long accg = 0ull;             // groups before mine: 64 at a time, nearest first
-    int top = (int)G - 1;
-    spins = 0;
-    while (top >= 0) {
+    for (;;) {                                  // one pass per window of groups (normally one)
         const int j = top - (int)l;
-        const bool inr = j >= 0;
+        const bool inr = !groups_done && j >= 0 && l < LB_WINDOW;
         unsigned long long ga = lb_tag(lb), gp = 0ull;
-        if (inr) { ga = lb_ld(&lb.grp[2 * (size_t)j]); gp = lb_ld(&lb.grp[2 * (size_t)j + 1]); }
-        const unsigned long long gav = __ballot(!inr || lb_ready(lb, ga));
-        const unsigned long long gpv = __ballot(inr && lb_ready(lb, gp));
-        if (gpv != 0ull) {                      // nearest group that already carries its prefix: the groups between it and me by their own amounts
-            const uint32_t d = (uint32_t)__ffsll((long long)gpv) - 1u;
-            const unsigned long long need = (1ull << d) - 1ull;
-            if ((gav & need) == need) {
-                const unsigned long long part = lb_wave_sum64(l < d ? (ga & LB_VALUE_MASK) : 0ull);
-                const unsigned long long gl = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gp >> 32), (int)d) << 32) |
-                                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gp, (int)d);
-                accg += part + (gl & LB_VALUE_MASK);
-                break;
+        bool have_ga = !inr, have_gp = false;
+        bool next = false;
+        for (;;) {
+            if (!have_a) a = lb_ld(&lb.agg[(size_t)G * LB_GROUP + l]);
+            if (!have_b) b = lb_ld(&lb.agg[(size_t)(G - 1u) * LB_GROUP + l]);
+            if (inr && !have_gp) gp = lb_ld(&lb.grp[2 * (size_t)j + 1]);
+            if (!have_ga) ga = lb_ld(&lb.grp[2 * (size_t)j]);
+            have_a = have_a || lb_ready(lb, a);
+            have_b = have_b || lb_ready(lb, b);
+            have_gp = inr && (have_gp || lb_ready(lb, gp));
+            have_ga = have_ga || lb_ready(lb, ga);
+            const bool mem_ok = __ballot(!have_a || !have_b) == 0ull;
+            if (!groups_done) {
+                const unsigned long long gav = __ballot(have_ga);
+                const unsigned long long gpv = __ballot(have_gp);
+                if (gpv != 0ull) {              // nearest group that already carries its prefix: the groups between it and me by their own amounts
+                    const uint32_t d = (uint32_t)__ffsll((long long)gpv) - 1u;
+                    const unsigned long long need = (1ull << d) - 1ull;
+                    if ((gav & need) == need) {
+                        const unsigned long long part = lb_wave_sum64(l < d ? (ga & LB_VALUE_MASK) : 0ull);
+                        const unsigned long long gl = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gp >> 32), (int)d) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gp, (int)d);
+                        accg += part + (gl & LB_VALUE_MASK);
+                        groups_done = true;
+                    }
+                } else if (gav == ~0ull) {      // no prefix among them, but all their amounts: on to the next window
+                    accg += lb_wave_sum64(inr ? (ga & LB_VALUE_MASK) : 0ull);
+                    next = true;
+                }
             }
-        } else if (gav == ~0ull) {
-            accg += lb_wave_sum64(inr ? (ga & LB_VALUE_MASK) : 0ull);
-            top -= 64;
-            spins = 0;
-            continue;
+            if (next || (groups_done && mem_ok)) break;
+            if (++spins > limit) return false;
+            __builtin_amdgcn_s_sleep(16);
         }
-        if (++spins > limit) return false;
-        __builtin_amdgcn_s_sleep(8);
+        if (!next) break;
+        top -= (int)LB_WINDOW;
+        if (top < 0) groups_done = true;
+        if (groups_done && __ballot(!have_a || !have_b) == 0ull) break;
+        spins = 0;
     }
+    const unsigned long long mem = lb_wave_sum64(a & LB_VALUE_MASK) + lb_wave_sum64(b & LB_VALUE_MASK);
     *prefix = accg + mem;
     if (l == 0 && lb_is_leader(g, n_wg)) lb_st(&lb.grp[2 * (size_t)G + 1], lb_tag(lb) | ((accg + mem + own) & LB_VALUE_MASK));
     return true;
