@@ -57,7 +57,7 @@ def test_config1_reduced_through_the_host_mirror(ctx):
     gpu.close()
 
 
-def _check_merge(ctx, offs, vals, removed, threads):
+def _check_merge(ctx, offs, vals, removed, threads, to_segment=False):
     segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
     tomb = ctx.tombstones(removed)
     out_off, out_vals, st = ctx.merge(segs, tomb)
@@ -65,12 +65,23 @@ def _check_merge(ctx, offs, vals, removed, threads):
     g_vals = out_vals.download(int(st.n_out))
     out_off.free()
     out_vals.free()
+    exported = None
+    if to_segment:      # Shard.Merge's real output (shard.go:207 -> file/writer.go:32-59): the merged terms as an encoded segment
+        merged, st2 = ctx.merge_to_segment(segs, tomb)
+        assert int(st2.n_out) == int(st.n_out)
+        exported = merged.export()
+        merged.free()
     for s in segs:
         s.free()
     w_off, w_vals, w_terms = orc.merge_segments(offs, vals, removed, threads=threads)
     assert int(st.n_out) == int(w_off[-1]) and st.n_terms_out == w_terms
     assert np.array_equal(g_off, w_off)
     assert np.array_equal(g_vals, w_vals)
+    if exported is not None:      # byte for byte the DV1 encoding of the oracle's merge
+        oblk, oskip, opayload = orc.dv1_encode(w_off, w_vals)
+        blk, skip, payload = exported
+        assert np.array_equal(blk, oblk) and np.array_equal(skip["first_doc"], oskip["first_doc"]) and np.array_equal(skip["byte_off"], oskip["byte_off"])
+        assert np.array_equal(payload, opayload)
     return st
 
 
@@ -80,7 +91,7 @@ def test_config3_full_size_16way_merge_of_1m_terms(ctx):
     offs, vals, removed = synth.merge_workload_big(1_000_000, 16, 1000.0, 100_000_000, threads=min(CORES, 16))
     n_in = sum(int(v.size) for v in vals)
     assert n_in > 1_000_000_000
-    st = _check_merge(ctx, offs, vals, removed, threads=min(CORES, 32))
+    st = _check_merge(ctx, offs, vals, removed, threads=min(CORES, 32), to_segment=True)
     assert st.n_in == n_in and 0.85 * n_in < st.n_out < n_in
     del offs, vals
     gc.collect()
@@ -90,7 +101,7 @@ def test_config4_one_gpu_shape_64way_merge(ctx):
     # configs[3]'s per-GPU shape: 64 segments x 125,000 terms (Zipf, mean 1000, ~1.3e8 postings), tombstones on — the
     # first time the k = 64 tile kernel sees large-term tiles, 33-term batches and 64-run folds at real sizes
     offs, vals, removed = synth.merge_workload_big(125_000, 64, 1000.0, 100_000_000, threads=min(CORES, 16))
-    st = _check_merge(ctx, offs, vals, removed, threads=min(CORES, 32))
+    st = _check_merge(ctx, offs, vals, removed, threads=min(CORES, 32), to_segment=True)
     assert st.n_tiles > 10_000
     # and a light share of the 8-way term split of the 1M-term index (terms 375k..500k: all batches of tiny lists)
     offs, vals, removed = synth.merge_workload_big(1_000_000, 64, 1000.0, 100_000_000, threads=min(CORES, 16),

@@ -123,6 +123,56 @@ def test_merge_to_segment_roundtrip(ctx):
     assert np.array_equal(po2, w_off) and np.array_equal(v2, w_vals)
 
 
+def _segment_equals_oracle_encoding(seg, w_off, w_vals):
+    oblk, oskip, opayload = orc.dv1_encode(w_off, w_vals)
+    blk, skip, payload = seg.export()
+    assert seg.info.n_postings == int(w_off[-1]) and seg.info.n_blocks == oskip.size - 1 and seg.info.n_bytes == opayload.size
+    assert np.array_equal(blk, oblk)
+    assert np.array_equal(skip["first_doc"], oskip["first_doc"]) and np.array_equal(skip["byte_off"], oskip["byte_off"])
+    assert np.array_equal(payload, opayload)
+    po, v = seg.decode()
+    assert np.array_equal(po, w_off) and np.array_equal(v, w_vals)
+
+
+@pytest.mark.parametrize("stream", [1, 0, -1])
+def test_merged_segment_bytes_equal_the_oracles_encoding(ctx, stream):
+    """Shard.Merge ends in Writer.Append of every merged term (shard.go:207, file/writer.go:32-59): the segment that
+    ii2_merge_segments_to_seg returns must be, byte for byte, the DV1 encoding of the oracle's merge - through the one-pass
+    encoder (encode.stream = 1), the two-pass one (0) and the one-pass one giving up on a look-back wait (-1: it hands over to
+    the two-pass encoder).  Shapes: many tiny and empty lists, lists of exactly 255 / 256 / 257 / 512 / 513 postings, sparse lists
+    (3- to 5-byte gaps), ids next to 2^32, a list far longer than a workgroup's 4096 ids, everything removed from some terms."""
+    rng = np.random.default_rng(123)
+    ctx.set_option("encode.stream", stream)
+    try:
+        # (a) random small terms with empty ones in between, four segments, tombstones
+        offs, vals = _rand_segments(rng, 4, 3000, 40, 5_000_000, p_empty=0.5)
+        removed = rng.integers(0, 5_000_000, 50_000).astype(np.uint32)
+        merged, st = ctx.merge_to_segment([ctx.encode(o, v) for o, v in zip(offs, vals)], ctx.tombstones(removed))
+        w_off, w_vals, _ = orc.merge_segments(offs, vals, np.sort(removed))
+        _segment_equals_oracle_encoding(merged, w_off, w_vals)
+        # (b) block-boundary lengths, a 70,000-posting list, sparse ids up to 2^32 - 1, a term that loses everything
+        lens = [255, 256, 257, 0, 512, 513, 1, 70_000, 0, 0, 3, 1024, 5]
+        lists = [sorted_unique(rng, n, 1 << 22) for n in lens]
+        lists[6] = np.array([0xFFFFFFFF], np.uint32)
+        lists[10] = np.array([7, 1 << 31, 0xFFFFFFFE], np.uint32)
+        lists[12] = np.array([100, 101, 102, 103, 104], np.uint32)
+        other = [x[::2].copy() for x in lists]                     # second segment: half of every list again (duplicates)
+        offs2 = [np.concatenate([[0], np.cumsum([x.size for x in ls])]).astype(np.uint64) for ls in (lists, other)]
+        vals2 = [np.concatenate(ls).astype(np.uint32) for ls in (lists, other)]
+        removed2 = np.array([100, 101, 102, 103, 104, 7], np.uint32)
+        merged2, _ = ctx.merge_to_segment([ctx.encode(o, v) for o, v in zip(offs2, vals2)], ctx.tombstones(removed2))
+        w_off2, w_vals2, _ = orc.merge_segments(offs2, vals2, np.sort(removed2))
+        assert w_off2[13] == w_off2[12]                            # the last term lost everything
+        _segment_equals_oracle_encoding(merged2, w_off2, w_vals2)
+        # (c) BASELINE config 3 in miniature (Zipf sizes, 16 segments)
+        offs3, vals3, removed3 = synth.merge_workload(20_000, 16, 120, 2_000_000)
+        merged3, _ = ctx.merge_to_segment([ctx.encode(o, v) for o, v in zip(offs3, vals3)], ctx.tombstones(removed3))
+        w_off3, w_vals3, _ = orc.merge_segments(offs3, vals3, removed3)
+        _segment_equals_oracle_encoding(merged3, w_off3, w_vals3)
+    finally:
+        ctx.set_option("encode.stream", 1)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 8, 33])
 def test_union_matches_prefix_search_dedupe(ctx, n):
     # inverted_index.go:274-292: append every matching term's values, sort, compact
