@@ -37,6 +37,15 @@ func NewCtx(device int) (*Ctx, error) {
 func (c *Ctx) Close()      { C.ii2_ctx_destroy(c.h) }
 func (c *Ctx) Device() int { return int(C.ii2_ctx_device(c.h)) }
 
+// Counters reports how often this context repeated a call on its second path because a bounded wait between workgroups of
+// one launch ran out (merges on the packing path; two-list ANDs / segment encodes without a look-back).  Results are identical
+// either way; a non-zero count on production hardware is worth a bug report.
+func (c *Ctx) Counters() (mergeRepeats, lookbackRepeats uint64) {
+	var out [2]C.uint64_t
+	C.ii2_ctx_counters(c.h, &out[0], 2)
+	return uint64(out[0]), uint64(out[1])
+}
+
 func (c *Ctx) err(what string, rc C.int) error {
 	return fmt.Errorf("gpu: %s: %s (%d)", what, C.GoString(C.ii2_last_error(c.h)), int(rc))
 }

@@ -308,6 +308,9 @@ int ii2_selftest(ii2_ctx *ctx);
  *   setop.small, union.rank                 short-list ANDs / ORs in one launch; ORs of a few medium lists by ranking
  *   merge.bitmap_tiles, merge.large_tile    bitmap tiles for dense terms (1: terms with >= 1 posting per 80 docs; N > 1: per N docs; 0: off)
  *                                           / input postings a doc-range tile of a large term aims at
+ *   intersect.and2                          dense 2-list ANDs: 1 one launch (look-back for the output offsets), 2 two kernels, 0 the n-list kernel
+ *   encode.stream                           merged segments encoded in one pass over the ids (1) or by the two-pass encoder (0)
+ *   merge.spin, intersect.and2_spin         polls a bounded inter-workgroup wait may take (tests shorten them; see ii2_ctx_counters)
  *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below
  * Every combination returns the same results; the tests run the kernels with the alternatives switched on and off. */
 int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);
@@ -322,6 +325,13 @@ int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches);
 /* One event pair around a whole run of calls: begin != 0 records the start event on the ctx stream, begin == 0 the
  * end event; ii2_profile_region_ms waits for the end event and returns the device time between the two — the time
  * the stream spent on everything enqueued in between, without a per-call event pair's idle time. */
+/* How often this context took a second path: out[0] = merges repeated through the parking + packing pass, out[1] = two-list ANDs
+ * repeated through the two-kernel form / segments encoded again by the two-pass encoder - in both cases because a BOUNDED WAIT
+ * between workgroups of one launch ran out.  Those launches (the merge's direct placement, the one-launch AND, the one-pass
+ * encoder) order their output by letting a workgroup wait for workgroups with smaller indices; that terminates because the
+ * hardware starts a launch's workgroups in index order, which HIP does not promise - hence the bound, and the repeat on a path
+ * without such waits (results identical).  n = number of words `out` holds (2 are written). */
+int ii2_ctx_counters(ii2_ctx *ctx, uint64_t *out, uint32_t n);
 int ii2_profile_region(ii2_ctx *ctx, int begin);
 int ii2_profile_region_ms(ii2_ctx *ctx, double *ms);
 

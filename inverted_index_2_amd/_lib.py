@@ -82,6 +82,7 @@ PROTOTYPES = {
     "ii2_gatherv_offsets": (C.c_int, [u64p, C.c_int, C.c_uint64, u64p]),
     "ii2_selftest": (C.c_int, [vp]),
     "ii2_set_option": (C.c_int, [vp, C.c_char_p, C.c_int64]),
+    "ii2_ctx_counters": (C.c_int, [vp, u64p, C.c_uint32]),
     "ii2_debug_read": (C.c_int, [vp, u64p, C.c_uint64]),
     "ii2_profile_read": (C.c_int, [vp, C.POINTER(C.c_double), u64p]),
     "ii2_profile_region": (C.c_int, [vp, C.c_int]),

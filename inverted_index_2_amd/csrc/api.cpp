@@ -1276,6 +1276,14 @@ int ii2_selftest(ii2_ctx *ctx) {
     return II2_OK;
 }
 
+int ii2_ctx_counters(ii2_ctx *ctx, uint64_t *out, uint32_t n) {
+    if (!ctx || !out) return II2_EINVAL;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (n > 0) out[0] = ctx->merge_fallbacks;
+    if (n > 1) out[1] = ctx->lb_fallbacks;
+    return II2_OK;
+}
+
 int ii2_debug_read(ii2_ctx *ctx, uint64_t *out, uint64_t n_words) {
     if (!ctx || !out || !ctx->d_debug) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
@@ -1295,6 +1303,7 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "merge.bitmap_tiles") ctx->opt_merge_bitmap = value;
     else if (k == "debug.merge_skip") ctx->opt_merge_skip = value;
     else if (k == "merge.direct") ctx->opt_merge_direct = value;
+    else if (k == "merge.spin") ctx->opt_merge_spin = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;

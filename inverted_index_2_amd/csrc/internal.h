@@ -33,6 +33,8 @@ struct ii2_ctx {
     int64_t opt_intersect_wgs = 0;      // tile-kernel workgroups per CU (0 = default)
     int64_t opt_merge_large_tile = 0;   // 0 = default (MERGE_CAP / 2)
     int64_t opt_merge_direct = 1;       // tiles place their survivors themselves when the output buffer surely fits (0: always park + pack)
+    int64_t opt_merge_spin = 0;         // bounded waits of the direct placement: polls (0 = default; tests shorten it)
+    uint64_t merge_fallbacks = 0;       // merges repeated through the parking + packing pass after a bounded wait ran out
     int64_t opt_merge_skip = 0;         // timing experiments: phases of the merge tile kernel left out (results wrong)
     int64_t opt_merge_bitmap = 1;       // single-term tiles whose doc range fits the LDS bitmap are merged by marking bits
     uint8_t *aux = nullptr;             // grow-only: merge per-tile arrays + parked survivors
@@ -357,7 +359,8 @@ struct MergeParams {
     uint32_t batch_q;             // batch id = weight prefix / batch_q
     uint32_t bitmap_tiles;        // 1: dense terms are cut into bitmap tiles
     uint32_t bitmap_sparsity;     // ... when they hold at least one posting per this many docs
-    uint32_t pad0;
+    uint32_t pad0;                // option debug.merge_skip (experiments / tests): phases left out, bit 6: the scanner never runs
+    uint32_t spin_limit;          // polls a wait of the direct placement may take (0: default)
     uint32_t direct;              // 1: tiles go to their final place from inside the tile kernel (ticket order + scanner); 0: parking + packing pass
     MergeSync *sync;              // (zeroed by the host)
     uint64_t *tile_off;           // [n_tiles_ub + 1] output offset of every tile: written by the scanner (direct) or by the scan before the packing pass

@@ -636,6 +636,7 @@ struct __align__(16) MergeSmem {
     uint32_t ab;                            // allocation inside the term's parking region
     uint32_t tk;                            // the tile this workgroup works on next (ticket)
     uint32_t pq_n;                          // parked tiles that still wait for their place in the output
+    uint32_t abort;                         // a bounded wait ran out somewhere: stop
     uint32_t pq_tile[MERGE_PQ], pq_cnt[MERGE_PQ];
     unsigned long long pq_slot[MERGE_PQ];
     unsigned long long pq_off;              // output offset of the queue's first tile
@@ -719,7 +720,9 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
     // Only those two scalars cross workgroups (relaxed device-scope accesses, no fences: the L2s of the eight XCDs are not
     // coherent with each other, and a release would write a whole L2 back); the parked ids stay inside their workgroup's CU.
     // Every wait is bounded.
+    const uint32_t spin_limit = p.spin_limit ? p.spin_limit : SPIN_LIMIT;
     if (p.direct && blockIdx.x == 0u) {
+        if (xskip & 64u) return;                  // (tests: a scanner that never runs - the workers' bounded waits must end the launch)
         // all eight waves: 512 tiles per step (one wave alone - 64 device-scope loads and as many write-through stores per
         // step - tops out below the rate at which a full machine counts tiles, and the workers then queue up behind it)
         uint32_t base = 0, spins = 0;
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
             if (K == 0u) it_zero++;
             lds_barrier();
             if (K == 0u) {
-                if (++spins > SPIN_LIMIT || __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (++spins > spin_limit || __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                     if (tid == 0) __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
@@ -808,11 +811,18 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
                 continue;
             }
             if (!block) return;
-            if (++spins > SPIN_LIMIT) { if (tid == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sm.pq_n = 0u; } continue; }
+            // a wait that runs out - mine, or (seen in the same round as my tile's offset) any other workgroup's or the scanner's -
+            // ends this workgroup's part of the launch: the queue is dropped, the tile loop below stops claiming tiles
+            if (tid == 0) sm.abort = (++spins > spin_limit || __hip_atomic_load(&sy->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1u : 0u;
+            lds_barrier();
+            if (sm.abort) {
+                if (tid == 0) { __hip_atomic_store(&sy->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); sm.pq_n = 0u; }
+                continue;
+            }
             __builtin_amdgcn_s_sleep(20);
         }
     };
-    if (tid == 0) { sm.pq_n = 0u; sm.tk = p.direct ? atomicAdd(&sy->ticket, 1u) : blockIdx.x; }
+    if (tid == 0) { sm.pq_n = 0u; sm.abort = 0u; sm.tk = p.direct ? atomicAdd(&sy->ticket, 1u) : blockIdx.x; }
     lds_barrier();
     const uint32_t n_workers = p.direct ? gridDim.x - 1u : gridDim.x;
     uint32_t tk_next = 0;                           // thread 0: the ticket after this one (claimed early: its latency hides behind the tile)
@@ -827,6 +837,7 @@ __global__ __launch_bounds__(MERGE_THREADS, 4) void k_merge_tiles(const MergeSeg
     };
     fetch_cuts();
     for (uint32_t tile = tile_nx; tile < n_tiles; tile = tile_nx) {
+        if (sm.abort) break;                       // (uniform: written before a barrier every thread has passed)
         const uint4 td = td_nx;
         const uint4 c0 = c0_nx;
         const uint2 c1 = c1_nx;

@@ -159,6 +159,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.n_tiles_dev = d_tt + T;                   // term_tile[T] = number of tiles
     p.npre = d_npre;
     p.pad0 = (uint32_t)ctx->opt_merge_skip;
+    p.spin_limit = ctx->opt_merge_spin > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_merge_spin, 0x7FFFFFFF) : 0u;
     HIP_TRY(ctx, launch_merge_tile_desc(d_ms, p, st));
     HIP_TRY(ctx, launch_merge_tile_runs(d_ms, p, st));
     p.out_counts = d_cnt;
@@ -198,7 +199,20 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint32_t n_tiles = (uint32_t)(ctx->h_mail[4] & 0xFFFFFFFFull);
     if (n_tiles > p.n_tiles_ub) return fail(ctx, II2_EHIP, "merge: internal error (tile bound exceeded)");
-    if (p.direct && (ctx->h_mail[3] & 0xFFFFFFFFull)) return fail(ctx, II2_EHIP, "merge: internal error (a bounded wait of the direct placement ran out)");
+    if (p.direct && (ctx->h_mail[3] & 0xFFFFFFFFull)) {
+        // A bounded wait of the direct placement ran out (its scanner workgroup and its workers did not run side by side: the
+        // scheme rests on workgroups starting in index order, which the hardware does and HIP does not promise).  Nothing is
+        // wrong with the inputs: the same merge again through the parking + packing pass, which has no waits between
+        // workgroups and rewrites every offset and id the failed attempt may have left in the caller's buffers.
+        ctx->merge_fallbacks++;
+        const int64_t keep = ctx->opt_merge_direct, keep_skip = ctx->opt_merge_skip;
+        ctx->opt_merge_direct = 0;
+        ctx->opt_merge_skip &= ~64ll;
+        const int rc2 = merge_core(ctx, k, views, n_terms, blocks_ub, postings_ub, tomb, d_out_off, d_out_values, out_cap, stats);
+        ctx->opt_merge_direct = keep;
+        ctx->opt_merge_skip = keep_skip;
+        return rc2;
+    }
     if (n_tiles == 0) ctx->h_mail[0] = 0;
     if (ctx->h_mail[0] > out_cap) return fail(ctx, II2_ECAPACITY, "merge: output buffer too small; nothing was written");
     if (stats) {

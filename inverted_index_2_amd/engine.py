@@ -114,6 +114,12 @@ class Context:
     def set_option(self, name: str, value: int) -> None:
         self._ck(self.lib.ii2_set_option(self.h, name.encode(), int(value)))
 
+    def counters(self):
+        """(merges repeated on the packing path, look-back launches repeated on their second path) - see ii2_ctx_counters."""
+        out = (C.c_uint64 * 2)()
+        self._ck(self.lib.ii2_ctx_counters(self.h, out, 2))
+        return int(out[0]), int(out[1])
+
     def profile_read(self):
         """(total device ms, launches) of the dominant kernel since the last read (option profile.events)."""
         ms, n = C.c_double(), C.c_uint64()

@@ -126,8 +126,10 @@ def test_and2_bounded_wait_runs_out(ctx):
     ctx.set_option("intersect.and2", 1)
     try:
         ctx.set_option("intersect.and2_spin", -1)
+        before = ctx.counters()[1]
         _, n = ctx.intersect(ls, out=out)                     # synchronous: repeated inside the call
         assert n == want.size and np.array_equal(out.download(n), want)
+        assert ctx.counters()[1] == before + 1
         ctx.intersect_async(ls, None, out, dcnt)              # asynchronous: poisoned count, reported at the next sync
         with pytest.raises(II2Error):
             ctx.sync()

@@ -173,6 +173,31 @@ def test_merged_segment_bytes_equal_the_oracles_encoding(ctx, stream):
         ctx.set_option("encode.stream", 1)
 
 
+def test_direct_placement_wait_runs_out_and_the_merge_is_repeated(ctx):
+    """The merge's direct placement (tiles move their survivors to their final place once a scanner workgroup has turned the
+    tiles' counts into offsets) rests on workgroups starting in index order.  Every wait is bounded: with a scanner that never
+    runs (option debug.merge_skip bit 6) and a short budget (merge.spin) the workers' waits run out, every workgroup leaves
+    promptly, and ii2_merge_segments repeats the call through the parking + packing pass - same offsets, same ids."""
+    offs, vals, removed = synth.merge_workload(30_000, 8, 150, 3_000_000)
+    segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+    tomb = ctx.tombstones(removed)
+    w_off, w_vals, w_terms = orc.merge_segments(offs, vals, removed)
+    before = ctx.counters()[0]
+    try:
+        ctx.set_option("merge.spin", 200)
+        ctx.set_option("debug.merge_skip", 64)
+        out_off, out_vals, st = ctx.merge(segs, tomb=tomb)
+    finally:
+        ctx.set_option("debug.merge_skip", 0)
+        ctx.set_option("merge.spin", 0)
+    assert ctx.counters()[0] == before + 1
+    assert np.array_equal(out_off.download(), w_off) and np.array_equal(out_vals.download(int(w_off[-1])), w_vals)
+    assert st.n_out == int(w_off[-1]) and st.n_terms_out == w_terms
+    out_off2, out_vals2, _ = ctx.merge(segs, tomb=tomb)                      # and the next call takes the direct placement again
+    assert ctx.counters()[0] == before + 1
+    assert np.array_equal(out_off2.download(), w_off) and np.array_equal(out_vals2.download(int(w_off[-1])), w_vals)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 8, 33])
 def test_union_matches_prefix_search_dedupe(ctx, n):
     # inverted_index.go:274-292: append every matching term's values, sort, compact
