@@ -159,6 +159,10 @@ func (c *Ctx) SelectAligned(seg *Segment, a *Alignment, s int, firstList uint64)
 
 // SelectAlignedAll builds the views of all the alignment's dictionaries in one call (one wait instead of one per view).
 func (c *Ctx) SelectAlignedAll(segs []*Segment, a *Alignment, firstList []uint64) ([]*Segment, error) {
+	// the C side writes a.K views: the slices must be exactly that long
+	if len(segs) == 0 || len(segs) != a.K || (len(firstList) != 0 && len(firstList) != a.K) {
+		return nil, fmt.Errorf("select: %d segments / %d first lists for an alignment of %d dictionaries", len(segs), len(firstList), a.K)
+	}
 	hs := make([]*C.ii2_seg, len(segs))
 	for i, s := range segs {
 		hs[i] = s.h
@@ -202,6 +206,9 @@ func (c *Ctx) AlignDicts(dicts []*Dictionary) (*Alignment, error) {
 		hs[i] = d.h
 	}
 	var a *C.ii2_align
+	if len(hs) == 0 {
+		return nil, fmt.Errorf("align: no dictionaries")
+	}
 	if rc := C.ii2_align_dicts(c.h, C.uint32_t(len(hs)), (**C.ii2_dict)(unsafe.Pointer(&hs[0])), &a); rc != 0 {
 		return nil, c.err("align", rc)
 	}
@@ -228,6 +235,9 @@ func (c *Ctx) MergeSmall(segs []*Segment, termBytes []byte, termOff, segFirst []
 	var nKept C.uint64_t
 	var out *C.ii2_seg
 	var st C.ii2_merge_stats
+	if len(hs) == 0 {
+		return nil, nil, fmt.Errorf("merge: no segments")
+	}
 	rc := C.ii2_merge_small(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), tb, u64ptr(termOff), u64ptr(segFirst),
 		u32ptr(removed), C.uint64_t(len(removed)), &out, u64ptr(kept), &nKept, &st)
 	if rc == C.II2_ERANGE {
@@ -258,6 +268,9 @@ func (c *Ctx) ReadSmall(segs []*Segment, termBytes []byte, termOff, segFirst, li
 	postOff = make([]uint64, len(termOff)+1)
 	values = make([]uint32, capValues+1)
 	var nUnion C.uint64_t
+	if len(hs) == 0 {
+		return nil, nil, nil, fmt.Errorf("read: no segments")
+	}
 	rc := C.ii2_read_small(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), tb, u64ptr(termOff), u64ptr(segFirst),
 		u64ptr(listFirst), u64ptr(rep), u64ptr(postOff), u32ptr(values), C.uint64_t(capValues), &nUnion)
 	if rc == C.II2_ERANGE {
@@ -282,6 +295,22 @@ func (c *Ctx) SegAllGather(local *Segment) (*Segment, error) {
 	return &Segment{out}, nil
 }
 
+// SegConcat is the same concatenation on one device: the lists of segs[0], then segs[1], ... as one segment.
+func (c *Ctx) SegConcat(segs []*Segment) (*Segment, error) {
+	if len(segs) == 0 {
+		return nil, fmt.Errorf("concat: no segments")
+	}
+	hs := make([]*C.ii2_seg, len(segs))
+	for i, s := range segs {
+		hs[i] = s.h
+	}
+	var out *C.ii2_seg
+	if rc := C.ii2_seg_concat(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), &out); rc != 0 {
+		return nil, c.err("concat", rc)
+	}
+	return &Segment{out}, nil
+}
+
 // MergeSegmentsToSeg merges k term-aligned resident segments (views from SelectAligned / SelectAlignedAll) into a new
 // resident segment, minus RemovedLists.Values() (ii2_tomb_create + ii2_merge_segments_to_seg): the general path behind
 // MergeSmall.  It returns nil when no posting survives (shard.go:219-225); the caller drops the emptied term slots.
@@ -299,6 +328,9 @@ func (c *Ctx) MergeSegmentsToSeg(segs []*Segment, removed []uint32) (*Segment, e
 	}
 	var out *C.ii2_seg
 	var st C.ii2_merge_stats
+	if len(hs) == 0 {
+		return nil, fmt.Errorf("merge: no segments")
+	}
 	if rc := C.ii2_merge_segments_to_seg(c.h, C.uint32_t(len(hs)), (**C.ii2_seg)(unsafe.Pointer(&hs[0])), tomb, &out, &st); rc != 0 {
 		return nil, c.err("merge", rc)
 	}

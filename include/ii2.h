@@ -282,10 +282,17 @@ int ii2_allgatherv_bytes(ii2_ctx *ctx, const void *d_local, uint64_t n_bytes, vo
 /* The exchange of MERGED SEGMENTS (what Shard.Merge writes, shard.go:207): every rank contributes the DV1 segment of its
  * term range and receives ONE segment holding all ranks' lists in rank order — the terms' global order when the ranks own
  * contiguous term ranges (shardKey ranges are contiguous, shard.go:362-378).  The postings travel encoded (about one byte
- * per posting for merged lists instead of four), as three byte-wise all-gathervs (list table, skip table, payload);
- * block numbers and byte offsets are shifted on arrival.  Every rank takes the same decision: II2_ERANGE on all ranks when
- * the concatenation exceeds one segment's limits.  With no communicator (one rank) *out is a copy of `local`. */
+ * per posting for merged lists instead of four): after one all-gather of the ranks' shapes, ONE grouped exchange moves the
+ * segment's arrays (list table, skip table, payload and the per-list counts / last docs / block owners) to every peer - a
+ * send and a receive per peer and array, every peer on its own xGMI link, no host wait until the segment is complete; block
+ * numbers, byte offsets and owners are shifted on arrival.  Every rank takes the same decision: II2_ERANGE on all ranks when
+ * the concatenation exceeds one segment's limits.  With no communicator (one rank) *out is a copy of `local`.  `local` must be
+ * a whole segment, not a view made by ii2_seg_select* (II2_EINVAL). */
 int ii2_seg_allgather(ii2_ctx *ctx, const ii2_seg *local, ii2_seg **out);
+/* The same concatenation on ONE device: the lists of segs[0], then those of segs[1], ... as one segment (what a rank holds after
+ * the exchange, made from segments it already has - e.g. the term-range chunks of a merge; also the one-GPU check of the
+ * exchange's arithmetic: same plan, same shifts).  Whole segments only; II2_ERANGE beyond one segment's limits. */
+int ii2_seg_concat(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, ii2_seg **out);
 /* Its arithmetic, host only: shape[3 r ..] = {n_lists, n_blocks, n_bytes} of rank r; list_off / block_off / byte_off
  * (world + 1 entries each) = where rank r's lists, blocks and payload bytes start in the concatenated segment.
  * II2_ERANGE when the totals exceed one segment's limits (2^31 lists or blocks, 4 GiB of payload). */
@@ -330,7 +337,8 @@ int ii2_profile_read(ii2_ctx *ctx, double *total_ms, uint64_t *launches);
  * between workgroups of one launch ran out.  Those launches (the merge's direct placement, the one-launch AND, the one-pass
  * encoder) order their output by letting a workgroup wait for workgroups with smaller indices; that terminates because the
  * hardware starts a launch's workgroups in index order, which HIP does not promise - hence the bound, and the repeat on a path
- * without such waits (results identical).  n = number of words `out` holds (2 are written). */
+ * without such waits (results identical).  out[2] = host waits (stream synchronisations) spent inside ii2_allgatherv* /
+ * ii2_seg_allgather / ii2_seg_concat so far.  n = number of words `out` holds (3 are written). */
 int ii2_ctx_counters(ii2_ctx *ctx, uint64_t *out, uint32_t n);
 int ii2_profile_region(ii2_ctx *ctx, int begin);
 int ii2_profile_region_ms(ii2_ctx *ctx, double *ms);

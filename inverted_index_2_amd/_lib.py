@@ -78,6 +78,7 @@ PROTOTYPES = {
     "ii2_allgatherv": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
     "ii2_allgatherv_bytes": (C.c_int, [vp, vp, C.c_uint64, vp, C.c_uint64, u64p]),
     "ii2_seg_allgather": (C.c_int, [vp, vp, vpp]),
+    "ii2_seg_concat": (C.c_int, [vp, C.c_uint32, vpp, vpp]),
     "ii2_seg_gather_plan": (C.c_int, [u64p, C.c_int, u64p, u64p, u64p]),
     "ii2_gatherv_offsets": (C.c_int, [u64p, C.c_int, C.c_uint64, u64p]),
     "ii2_selftest": (C.c_int, [vp]),

@@ -289,7 +289,7 @@ static int dict_create_unlocked(ii2_ctx *ctx, const uint8_t *term_bytes, const u
     d->device = ctx->device;
     d->n = n;
     const hipMemcpyKind kind = where == II2_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-    if (hipMalloc((void **)&d->d_off, (n + 1) * sizeof(uint64_t)) != hipSuccess || hipMalloc((void **)&d->d_key, (n + 1) * sizeof(uint64_t)) != hipSuccess)
+    if (ii2::dm_malloc_retry((void **)&d->d_off, (n + 1) * sizeof(uint64_t)) != hipSuccess || ii2::dm_malloc_retry((void **)&d->d_key, (n + 1) * sizeof(uint64_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "ii2_dict_create: allocation failed");
     uint64_t ends[2] = {0, 0};            // term_off[0], term_off[n]
     if (n) {
@@ -304,7 +304,7 @@ static int dict_create_unlocked(ii2_ctx *ctx, const uint8_t *term_bytes, const u
     if (ends[0] != 0) return fail(ctx, II2_EINVAL, "ii2_dict_create: term_off[0] must be 0");
     d->n_bytes = ends[1];
     if (d->n_bytes && !term_bytes) return fail(ctx, II2_EINVAL, "ii2_dict_create: term_bytes is NULL");
-    if (hipMalloc((void **)&d->d_bytes, d->n_bytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "ii2_dict_create: allocation failed");
+    if (ii2::dm_malloc_retry((void **)&d->d_bytes, d->n_bytes + 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "ii2_dict_create: allocation failed");
     if (d->n_bytes) HIP_TRY(ctx, hipMemcpyAsync(d->d_bytes, term_bytes, d->n_bytes, kind, st));
     uint32_t *d_bad = (uint32_t *)ctx->d_mail;
     uint32_t bad = 0;
@@ -362,8 +362,8 @@ static int align_dicts_unlocked(ii2_ctx *ctx, uint32_t k, const ii2_dict *const 
     HIP_TRY(ctx, hipMemcpyAsync(&n_union, d_hpre + n, sizeof n_union, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));                       // the one round trip: the union's size decides the result arrays
     a->n_union = n_union;
-    if (hipMalloc((void **)&a->d_uidx, n * sizeof(uint32_t)) != hipSuccess || hipMalloc((void **)&a->d_rep, ((size_t)n_union + 1) * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&a->d_sel, ((size_t)k * n_union + 1) * sizeof(int32_t)) != hipSuccess)
+    if (ii2::dm_malloc_retry((void **)&a->d_uidx, n * sizeof(uint32_t)) != hipSuccess || ii2::dm_malloc_retry((void **)&a->d_rep, ((size_t)n_union + 1) * sizeof(uint32_t)) != hipSuccess ||
+        ii2::dm_malloc_retry((void **)&a->d_sel, ((size_t)k * n_union + 1) * sizeof(int32_t)) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "ii2_align_dicts: result allocation failed");
     HIP_TRY(ctx, hipMemsetAsync(a->d_sel, 0xFF, (size_t)k * n_union * sizeof(int32_t), st));
     if (n_union) hipLaunchKernelGGL(k_align_number, dim3(grid_for(n)), dim3(256), 0, st, ad, (const uint32_t *)d_pos, (const uint32_t *)d_head, (const uint32_t *)d_hpre, n,
@@ -489,6 +489,7 @@ static int select_aligned_one(ii2_ctx *ctx, const ii2_seg *src, const ii2_align 
     }
     if (e == hipSuccess && wait) e = hipStreamSynchronize(st);
     if (e != hipSuccess) {
+        (void)hipStreamSynchronize(st);           // (earlier kernels of the batch may still be writing the arrays)
         dm_free(d_blk_off); dm_free(d_cnt); dm_free(d_last); dm_free(d_blk_list);
         ctx->err = std::string("ii2_seg_select_aligned: ") + hipGetErrorString(e);
         return II2_EHIP;

@@ -31,7 +31,7 @@ static int fail(ii2_ctx *ctx, int code, const char *msg) {
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t alloc(size_t bytes) { return ii2::dm_malloc_retry(&p, bytes ? bytes : 16); }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -46,7 +46,7 @@ int ii2_ws_reserve(ii2_ctx *ctx, size_t bytes) {
     ctx->ws = nullptr;
     ctx->ws_cap = 0;
     size_t want = align_up(bytes + bytes / 4, 1 << 20);
-    if (hipMalloc((void **)&ctx->ws, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "workspace allocation failed");
+    if (ii2::dm_malloc_retry((void **)&ctx->ws, want) != hipSuccess) return fail(ctx, II2_ENOMEM, "workspace allocation failed");
     ctx->ws_cap = want;
     return II2_OK;
 }
@@ -64,7 +64,7 @@ void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes) {
     ctx->pool[slot] = nullptr;
     ctx->pool_cap[slot] = 0;
     const size_t want = align_up(bytes + bytes / 8 + 256, 1 << 16);
-    if (hipMalloc((void **)&ctx->pool[slot], want) != hipSuccess) return nullptr;
+    if (ii2::dm_malloc_retry((void **)&ctx->pool[slot], want) != hipSuccess) return nullptr;
     ctx->pool_cap[slot] = want;
     return ctx->pool[slot];
 }
@@ -146,7 +146,7 @@ int ii2_ctx_create(int device, uint32_t flags, ii2_ctx **out) {
     dm_user(+1);
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess) {
+        ii2::dm_malloc_retry((void **)&ctx->d_mail, II2_MAIL_WORDS * sizeof(uint64_t)) != hipSuccess) {
         g_create_err = "context resource allocation failed";
         ii2_ctx_destroy(ctx);
         return II2_EHIP;
@@ -207,7 +207,7 @@ int ii2_dev_alloc(ii2_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return II2_EINVAL;
     std::lock_guard<std::mutex> g(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (hipMalloc(dptr, bytes ? bytes : 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "hipMalloc failed");
+    if (ii2::dm_malloc_retry(dptr, bytes ? bytes : 16) != hipSuccess) return fail(ctx, II2_ENOMEM, "hipMalloc failed");
     return II2_OK;
 }
 int ii2_dev_free(ii2_ctx *ctx, void *dptr) {
@@ -237,6 +237,7 @@ int ii2_copy_d2h(ii2_ctx *ctx, void *dst, const void *src, size_t bytes) {
 // ---- segments -----------------------------------------------------------------------------
 static void seg_release(ii2_seg *s) {
     if (!s) return;
+    if (s->born) (void)hipStreamSynchronize(s->born);     // never finished (an early exit): kernels of that call may still be writing its arrays
     if (s->in_slab) { delete s; return; }       // the store's slab holds every array (ii2_merge_small)
     // (devmem.cpp: the arrays go back to the size-class cache; no driver call, no device-wide wait)
     dm_free(s->d_blk_off);
@@ -288,6 +289,7 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
         HIP_TRY(ctx, hipMemcpyAsync(seg->h_spans.data(), d_sp, 3 * seg->n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    seg->born = nullptr;                                    // finished: from here on the caller's contract governs its lifetime
     return II2_OK;
 }
 
@@ -298,6 +300,7 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
     seg->device = ctx->device;
+    seg->born = ctx->stream;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
     const uint64_t nb_bound = n_postings / II2_DV1_BLOCK + n_lists + 1;
@@ -338,6 +341,7 @@ int ii2_seg_encode_dev_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_t *
     HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
     int rc = seg_finish(ctx, seg.get(), true);
     if (rc) return rc;
+    seg->born = nullptr;
     *out = seg.release();
     return II2_OK;
 }
@@ -354,6 +358,7 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
     seg->device = ctx->device;
+    seg->born = ctx->stream;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
     const uint64_t nb_bound = n_postings / II2_DV1_BLOCK + std::min<uint64_t>(n_nonempty, n_lists) + 1;
@@ -393,6 +398,7 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
     seg->n_bytes = nbytes;
     int rc = seg_finish(ctx, seg.get(), true);
     if (rc) return rc;
+    seg->born = nullptr;
     *out = seg.release();
     return II2_OK;
 }
@@ -450,6 +456,7 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
     seg->device = ctx->device;
+    seg->born = ctx->stream;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
     // the closing entries must agree with the stated array lengths: nothing below reads past those lengths
@@ -508,6 +515,7 @@ int ii2_seg_import(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (sum != n_postings) return fail(ctx, II2_EINVAL, "ii2_seg_import: n_postings differs from the number of postings the blocks hold");
     }
+    seg->born = nullptr;
     *out = seg.release();
     return II2_OK;
 }
@@ -579,7 +587,9 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
     seg->device = ctx->device;
+    seg->born = ctx->stream;
     seg->store = src->store;
+    seg->is_view = true;
     seg->d_skip = src->d_skip;
     seg->d_payload = src->d_payload;
     seg->n_lists = n_out;
@@ -591,6 +601,7 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     int rc = seg_finish(ctx, seg.get());
     if (rc) return rc;
+    seg->born = nullptr;
     *out = seg.release();
     return II2_OK;
 }
@@ -598,10 +609,11 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
 }  // extern "C"
 
 // an empty segment shell with room for the given shape (ii2_seg_allgather fills it): ctx->mu held
-int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, ii2_seg **out) {
+int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, ii2_seg **out, bool with_meta) {
     std::unique_ptr<ii2_seg, void (*)(ii2_seg *)> seg(new (std::nothrow) ii2_seg(), seg_release);
     if (!seg) return II2_ENOMEM;
     seg->device = ctx->device;
+    seg->born = ctx->stream;
     seg->n_lists = n_lists;
     seg->n_postings = n_postings;
     seg->n_blocks = n_blocks;
@@ -610,6 +622,8 @@ int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, 
         dm_alloc((void **)&seg->d_skip, (n_blocks + 1) * sizeof(ii2_skip)) != hipSuccess ||
         dm_alloc((void **)&seg->d_payload, n_bytes + 16) != hipSuccess)
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
+    if (with_meta) { if (int rcm = seg_alloc_meta(ctx, seg.get())) return rcm; }
+    seg->born = nullptr;
     *out = seg.release();
     return II2_OK;
 }
@@ -618,16 +632,14 @@ int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, 
 // number their blocks and bytes from 0: shift them, write the closing entries and derive the per-list arrays.  ctx->mu held
 int ii2_seg_rebase_internal(ii2_ctx *ctx, ii2_seg *seg, int world, const uint64_t *lo, const uint64_t *bo, const uint64_t *qo) {
     hipStream_t st = ctx->stream;
+    const bool have_meta = seg->d_blk_list != nullptr;           // the derived arrays travelled with the parts (ii2_seg_allgather)
     for (int r = 0; r < world; r++) {
-        HIP_TRY(ctx, launch_seg_rebase(seg->d_blk_off + lo[r], lo[r + 1] - lo[r], (uint32_t)bo[r], seg->d_skip + bo[r], bo[r + 1] - bo[r], (uint32_t)qo[r], st));
+        HIP_TRY(ctx, launch_seg_rebase(seg->d_blk_off + lo[r], lo[r + 1] - lo[r], (uint32_t)bo[r], seg->d_skip + bo[r], bo[r + 1] - bo[r], (uint32_t)qo[r],
+                                       have_meta ? seg->d_blk_list + bo[r] : nullptr, (uint32_t)lo[r], st));
     }
-    const uint32_t last_blk = (uint32_t)bo[world];
-    const ii2_skip last_skip = {0u, (uint32_t)qo[world]};
-    HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off + lo[world], &last_blk, sizeof last_blk, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(seg->d_skip + bo[world], &last_skip, sizeof last_skip, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(seg->d_payload + qo[world], 0, 16, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));            // (the two small sources above live on this stack frame)
-    return seg_finish(ctx, seg);
+    HIP_TRY(ctx, launch_seg_close(seg->d_blk_off + lo[world], (uint32_t)bo[world], seg->d_skip + bo[world], (uint32_t)qo[world], seg->d_payload + qo[world],
+                                  have_meta ? seg->d_blk_list + bo[world] : nullptr, st));
+    return seg_finish(ctx, seg, have_meta);                      // (one host wait: the segment is ready when this returns)
 }
 
 // host mirror of blk_off, fetched on first use (views built on the device do not have one)
@@ -662,7 +674,9 @@ int ii2_seg_adopt_view(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, uint32_
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     }
     seg->device = ctx->device;
+    seg->born = ctx->stream;
     seg->store = src->store;
+    seg->is_view = true;
     seg->d_skip = src->d_skip;
     seg->d_payload = src->d_payload;
     seg->n_lists = n_out;
@@ -673,6 +687,7 @@ int ii2_seg_adopt_view(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, uint32_
     seg->d_cnt = d_cnt;
     seg->d_last_doc = d_last_doc;
     seg->d_blk_list = d_blk_list;
+    seg->born = nullptr;
     *out = seg;
     return II2_OK;
 }
@@ -717,7 +732,7 @@ int ii2_tomb_create(ii2_ctx *ctx, const uint32_t *removed, uint64_t n, int where
     // bitmap, then its summary (1 bit per (1 << TOMB_SUM_SHIFT) docs) in the same allocation
     const uint64_t words_padded = (t->n_words + 4 + 3) & ~3ull;
     const uint64_t n_sum = (t->n_words >> TOMB_SUM_SHIFT) + 2;
-    if (hipMalloc((void **)&t->d_words, (words_padded + n_sum) * sizeof(uint32_t)) != hipSuccess) {
+    if (ii2::dm_malloc_retry((void **)&t->d_words, (words_padded + n_sum) * sizeof(uint32_t)) != hipSuccess) {
         delete t;
         return fail(ctx, II2_ENOMEM, "tombstone bitmap allocation failed");
     }
@@ -812,7 +827,7 @@ static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, con
     sp.d_count = d_count;
     if (!ctx->d_small) {
         const size_t bytes = ((size_t)SMALL_SET_POSTINGS + 16) * sizeof(uint32_t);
-        if (hipMalloc((void **)&ctx->d_small, bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "small set-operation scratch allocation failed");
+        if (ii2::dm_malloc_retry((void **)&ctx->d_small, bytes) != hipSuccess) return fail(ctx, II2_ENOMEM, "small set-operation scratch allocation failed");
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_small, 0, bytes, ctx->stream));
     }
     sp.sorted = ctx->d_small;
@@ -835,7 +850,7 @@ int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb) {
             ctx->d_lb = nullptr;
             ctx->lb_cap = 0;
             const size_t cap_wg = std::max<size_t>(4096, n_wg + n_wg / 4);
-            if (hipMalloc((void **)&ctx->d_lb, (8 + cap_wg + 2 * ((cap_wg + 63) / 64)) * sizeof(unsigned long long)) != hipSuccess)
+            if (ii2::dm_malloc_retry((void **)&ctx->d_lb, (8 + cap_wg + 2 * ((cap_wg + 63) / 64)) * sizeof(unsigned long long)) != hipSuccess)
                 return fail(ctx, II2_ENOMEM, "look-back records allocation failed");
             ctx->lb_cap = cap_wg;
         }
@@ -979,7 +994,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         dp.d_count = d_count;
         dp.debug = nullptr;
         if (ctx->opt_debug_stamps) {
-            if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
+            if (!ctx->d_debug && ii2::dm_malloc_retry((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
                 return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_debug, 0, (size_t)2048 * 8 * sizeof(unsigned long long), st));
             dp.debug = ctx->d_debug;
@@ -1032,7 +1047,7 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     p.d_count = d_count;
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
-        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
+        if (!ctx->d_debug && ii2::dm_malloc_retry((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }
@@ -1281,6 +1296,7 @@ int ii2_ctx_counters(ii2_ctx *ctx, uint64_t *out, uint32_t n) {
     std::lock_guard<std::mutex> g(ctx->mu);
     if (n > 0) out[0] = ctx->merge_fallbacks;
     if (n > 1) out[1] = ctx->lb_fallbacks;
+    if (n > 2) out[2] = ctx->comm_syncs;
     return II2_OK;
 }
 

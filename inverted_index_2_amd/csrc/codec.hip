@@ -254,19 +254,34 @@ hipError_t launch_list_spans(const uint32_t *blk_off, const ii2_skip *skip, cons
     return hipGetLastError();
 }
 
-// a gathered segment's part: block numbers of its lists and byte offsets of its blocks move up by what lies before it
+// a gathered segment's part: block numbers of its lists, byte offsets of its blocks and the blocks' owners move up by what lies
+// before it
 __global__ void k_seg_rebase(uint32_t *__restrict__ blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *__restrict__ skip, uint64_t n_blocks,
-                             uint32_t add_bytes) {
+                             uint32_t add_bytes, uint32_t *__restrict__ blk_list, uint32_t add_lists) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_lists) blk_off[i] += add_blocks;
-    if (i < n_blocks) skip[i].byte_off += add_bytes;
+    if (i < n_blocks) {
+        skip[i].byte_off += add_bytes;
+        if (blk_list) blk_list[i] += add_lists;
+    }
 }
 
 hipError_t launch_seg_rebase(uint32_t *blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *skip, uint64_t n_blocks, uint32_t add_bytes,
-                             hipStream_t s) {
+                             uint32_t *blk_list, uint32_t add_lists, hipStream_t s) {
     const uint64_t n = n_lists > n_blocks ? n_lists : n_blocks;
-    if (n == 0 || (add_blocks == 0 && add_bytes == 0)) return hipSuccess;
-    hipLaunchKernelGGL(k_seg_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blk_off, n_lists, add_blocks, skip, n_blocks, add_bytes);
+    if (n == 0 || (add_blocks == 0 && add_bytes == 0 && add_lists == 0)) return hipSuccess;
+    hipLaunchKernelGGL(k_seg_rebase, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, blk_off, n_lists, add_blocks, skip, n_blocks, add_bytes, blk_list, add_lists);
+    return hipGetLastError();
+}
+
+// the closing entries of a concatenated segment (written on the device: no host source has to outlive the call)
+__global__ void k_seg_close(uint32_t *blk_off_end, uint32_t n_blocks, ii2_skip *skip_end, uint32_t n_bytes, uint8_t *payload_end, uint32_t *blk_list_end) {
+    const uint32_t t = threadIdx.x;
+    if (t == 0) { *blk_off_end = n_blocks; skip_end->first_doc = 0u; skip_end->byte_off = n_bytes; if (blk_list_end) *blk_list_end = 0xFFFFFFFFu; }
+    if (t < 16u) payload_end[t] = 0;
+}
+hipError_t launch_seg_close(uint32_t *blk_off_end, uint32_t n_blocks, ii2_skip *skip_end, uint32_t n_bytes, uint8_t *payload_end, uint32_t *blk_list_end, hipStream_t s) {
+    hipLaunchKernelGGL(k_seg_close, dim3(1), dim3(64), 0, s, blk_off_end, n_blocks, skip_end, n_bytes, payload_end, blk_list_end);
     return hipGetLastError();
 }
 

@@ -143,6 +143,7 @@ static int gatherv_core(ii2_ctx *ctx, const void *d_local_v, uint64_t n_local, s
         return II2_EHIP;
     }
     if (hipStreamSynchronize(st) != hipSuccess) { say("sync failed"); return II2_EHIP; }
+    ctx->comm_syncs++;
     return II2_OK;
 }
 
@@ -178,14 +179,51 @@ int ii2_seg_gather_plan(const uint64_t *shape, int world, uint64_t *list_off, ui
     return II2_OK;
 }
 
+// Several arrays, every rank's byte counts already known on every rank (from the shapes): ONE grouped exchange - a send and a
+// receive per (peer, array), all peers together, each peer's copies on its own xGMI link - and NO host wait: the copies are
+// ordered on the context's stream like any kernel.  off[a] has world + 1 byte offsets into out[a].
+struct GatherPart { const uint8_t *local; uint8_t *out; const uint64_t *off; };
+static int gatherv_known(ii2_ctx *ctx, int n_parts, const GatherPart *parts, const char *who) {
+    const int world = ctx->comm ? ctx->world : 1, rank = ctx->comm ? ctx->rank : 0;
+    hipStream_t st = ctx->stream;
+    if (world > 1) {
+        ncclComm_t comm = (ncclComm_t)ctx->comm;
+        ncclResult_t gr = ncclGroupStart();
+        for (int r = 0; r < world && gr == ncclSuccess; r++) {
+            if (r == rank) continue;
+            for (int a = 0; a < n_parts && gr == ncclSuccess; a++) {
+                const uint64_t mine = parts[a].off[rank + 1] - parts[a].off[rank], theirs = parts[a].off[r + 1] - parts[a].off[r];
+                if (mine) gr = ncclSend(parts[a].local, mine, ncclUint8, r, comm, st);
+                if (gr == ncclSuccess && theirs) gr = ncclRecv(parts[a].out + parts[a].off[r], theirs, ncclUint8, r, comm, st);
+            }
+        }
+        const ncclResult_t ge = ncclGroupEnd();             // (the group is always closed)
+        if (gr != ncclSuccess || ge != ncclSuccess) {
+            ctx->err = std::string(who) + ": grouped send/recv: " + ncclGetErrorString(gr != ncclSuccess ? gr : ge);
+            return II2_ECOMM;
+        }
+    }
+    for (int a = 0; a < n_parts; a++) {
+        const uint64_t mine = parts[a].off[rank + 1] - parts[a].off[rank];
+        if (mine && hipMemcpyAsync(parts[a].out + parts[a].off[rank], parts[a].local, mine, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            ctx->err = std::string(who) + ": local copy failed";
+            return II2_EHIP;
+        }
+    }
+    return II2_OK;
+}
+
 int ii2_seg_allgather(ii2_ctx *ctx, const ii2_seg *local, ii2_seg **out) {
     if (!ctx || !local || !out || local->device != ctx->device) return II2_EINVAL;
     *out = nullptr;
     std::lock_guard<std::mutex> g(ctx->mu);
     if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return II2_EHIP; }
+    // a view made by ii2_seg_select* numbers its blocks inside its source's store (blk_off[0] != 0, the store's n_blocks and
+    // n_bytes): it is not a self-contained segment and cannot travel as one
+    if (local->is_view) { ctx->err = "ii2_seg_allgather: `local` is a view of another segment (ii2_seg_select*); only whole segments travel"; return II2_EINVAL; }
     const int world = ctx->comm ? ctx->world : 1;
     hipStream_t st = ctx->stream;
-    // 1. shapes: {lists, blocks, payload bytes, postings} of every rank
+    // 1. shapes: {lists, blocks, payload bytes, postings} of every rank - the only host round trip before the data moves
     uint64_t *h_x = ctx->h_mail + II2_MAIL_COMM, *d_x = ctx->d_mail + II2_MAIL_COMM;      // [0..3] mine, [4 .. 4 + 4 world) all
     static_assert(II2_MAIL_COMM + 4 + 4 * II2_MAX_RANKS <= II2_MAIL_WORDS, "mailbox too small for the segment shapes");
     h_x[0] = local->n_lists; h_x[1] = local->n_blocks; h_x[2] = local->n_bytes; h_x[3] = local->n_postings;
@@ -195,6 +233,7 @@ int ii2_seg_allgather(ii2_ctx *ctx, const ii2_seg *local, ii2_seg **out) {
         NCCL_TRY(ctx, ncclAllGather(d_x, d_x + 4, 4, ncclUint64, (ncclComm_t)ctx->comm, st));
         if (hipMemcpyAsync(h_x + 4, d_x + 4, (size_t)world * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) { ctx->err = "ii2_seg_allgather: shape download failed"; return II2_EHIP; }
+        ctx->comm_syncs++;
     }
     std::vector<uint64_t> shape(3 * world), lo(world + 1), bo(world + 1), qo(world + 1);
     uint64_t n_post = 0;
@@ -207,16 +246,66 @@ int ii2_seg_allgather(ii2_ctx *ctx, const ii2_seg *local, ii2_seg **out) {
         ctx->err = "ii2_seg_allgather: the concatenated segment exceeds the DV1 limits (2^31 lists / blocks, 4 GiB of payload)";
         return rc;
     }
-    // 2. the concatenated segment's arrays; every rank's part keeps its own numbering until step 4
+    // 2. the concatenated segment's arrays - the DV1 arrays and the three derived ones (posting counts, last docs, block owners:
+    // they travel too, so that the receiver does not decode every list's last block to get them back) - in ONE grouped
+    // exchange: six sends and six receives per peer, no host wait in between.  Every part keeps its own numbering until step 3.
     ii2_seg *seg = nullptr;
-    if (int rc = ii2_seg_alloc_internal(ctx, lo[world], n_post, bo[world], qo[world], &seg)) return rc;
-    std::vector<uint64_t> cnt(world);
-    int rc = gatherv_core(ctx, local->d_blk_off, local->n_lists * sizeof(uint32_t), 1, seg->d_blk_off, lo[world] * sizeof(uint32_t), cnt.data(), "ii2_seg_allgather (lists)");
-    if (!rc) rc = gatherv_core(ctx, local->d_skip, local->n_blocks * sizeof(ii2_skip), 1, seg->d_skip, bo[world] * sizeof(ii2_skip), cnt.data(), "ii2_seg_allgather (skip table)");
-    if (!rc) rc = gatherv_core(ctx, local->d_payload, local->n_bytes, 1, seg->d_payload, qo[world], cnt.data(), "ii2_seg_allgather (payload)");
-    // 3. + 4. block numbers and byte offsets of rank r's part move up by what the ranks before it hold; closing entries
+    if (int rc = ii2_seg_alloc_internal(ctx, lo[world], n_post, bo[world], qo[world], &seg, true)) return rc;
+    std::vector<uint64_t> lo4(world + 1), bo8(world + 1), bo4(world + 1);
+    for (int r = 0; r <= world; r++) { lo4[r] = lo[r] * sizeof(uint32_t); bo8[r] = bo[r] * sizeof(ii2_skip); bo4[r] = bo[r] * sizeof(uint32_t); }
+    const GatherPart parts[6] = {
+        {(const uint8_t *)local->d_blk_off, (uint8_t *)seg->d_blk_off, lo4.data()},
+        {(const uint8_t *)local->d_skip, (uint8_t *)seg->d_skip, bo8.data()},
+        {(const uint8_t *)local->d_payload, (uint8_t *)seg->d_payload, qo.data()},
+        {(const uint8_t *)local->d_cnt, (uint8_t *)seg->d_cnt, lo4.data()},
+        {(const uint8_t *)local->d_last_doc, (uint8_t *)seg->d_last_doc, lo4.data()},
+        {(const uint8_t *)local->d_blk_list, (uint8_t *)seg->d_blk_list, bo4.data()},
+    };
+    int rc = gatherv_known(ctx, 6, parts, "ii2_seg_allgather");
+    // 3. block numbers, byte offsets and block owners of rank r's part move up by what the ranks before it hold; closing entries
     if (!rc) rc = ii2_seg_rebase_internal(ctx, seg, world, lo.data(), bo.data(), qo.data());
-    if (rc) { ii2_seg_free(seg); return rc; }
+    if (rc) { (void)hipStreamSynchronize(st); ii2_seg_free(seg); return rc; }
+    ctx->comm_syncs++;
+    *out = seg;
+    return II2_OK;
+}
+
+int ii2_seg_concat(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *segs, ii2_seg **out) {
+    if (!ctx || !segs || !out || n == 0 || n > II2_MAX_RANKS) return II2_EINVAL;
+    *out = nullptr;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return II2_EHIP; }
+    std::vector<uint64_t> shape(3 * (size_t)n), lo(n + 1), bo(n + 1), qo(n + 1);
+    uint64_t n_post = 0;
+    for (uint32_t r = 0; r < n; r++) {
+        if (!segs[r] || segs[r]->device != ctx->device) { ctx->err = "ii2_seg_concat: segment is NULL or lives on another device"; return II2_EINVAL; }
+        if (segs[r]->is_view) { ctx->err = "ii2_seg_concat: a view of another segment (ii2_seg_select*) is not a whole segment"; return II2_EINVAL; }
+        shape[3 * r] = segs[r]->n_lists; shape[3 * r + 1] = segs[r]->n_blocks; shape[3 * r + 2] = segs[r]->n_bytes;
+        n_post += segs[r]->n_postings;
+    }
+    if (int rc = ii2_seg_gather_plan(shape.data(), (int)n, lo.data(), bo.data(), qo.data())) {
+        ctx->err = "ii2_seg_concat: the concatenated segment exceeds the DV1 limits (2^31 lists / blocks, 4 GiB of payload)";
+        return rc;
+    }
+    ii2_seg *seg = nullptr;
+    if (int rc = ii2_seg_alloc_internal(ctx, lo[n], n_post, bo[n], qo[n], &seg, true)) return rc;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipSuccess;
+    auto put = [&](void *dst, const void *src, uint64_t bytes) { if (e == hipSuccess && bytes) e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st); };
+    for (uint32_t r = 0; r < n; r++) {
+        const ii2_seg *s = segs[r];
+        put(seg->d_blk_off + lo[r], s->d_blk_off, s->n_lists * sizeof(uint32_t));
+        put(seg->d_skip + bo[r], s->d_skip, s->n_blocks * sizeof(ii2_skip));
+        put(seg->d_payload + qo[r], s->d_payload, s->n_bytes);
+        put(seg->d_cnt + lo[r], s->d_cnt, s->n_lists * sizeof(uint32_t));
+        put(seg->d_last_doc + lo[r], s->d_last_doc, s->n_lists * sizeof(uint32_t));
+        put(seg->d_blk_list + bo[r], s->d_blk_list, s->n_blocks * sizeof(uint32_t));
+    }
+    int rc = II2_OK;
+    if (e != hipSuccess) { ctx->err = std::string("ii2_seg_concat: copy failed: ") + hipGetErrorString(e); rc = II2_EHIP; }
+    if (!rc) rc = ii2_seg_rebase_internal(ctx, seg, (int)n, lo.data(), bo.data(), qo.data());
+    if (rc) { (void)hipStreamSynchronize(st); ii2_seg_free(seg); return rc; }
+    ctx->comm_syncs++;
     *out = seg;
     return II2_OK;
 }

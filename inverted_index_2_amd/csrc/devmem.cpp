@@ -9,7 +9,9 @@
 //
 // Contract (unchanged): a segment is freed only when no call that reads it is still running — the library's calls are
 // synchronous, so that is "after the call returned"; ii2_intersect_async users wait for their query first.  hipFree used to
-// enforce this by waiting for the device; the cache does not wait.
+// enforce this by waiting for the device; the cache does not wait — so the library's OWN early exits (a launch that failed
+// with earlier kernels of the call still enqueued) wait for their stream before they hand arrays back (seg_release of a
+// segment that was never finished, the error paths of ii2_seg_select_aligned and ii2_merge_small).
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -72,6 +74,18 @@ hipError_t dm_alloc(void **p, size_t bytes) {
     std::lock_guard<std::mutex> g(g_cache.mu);
     g_cache.live[*p] = key;
     return hipSuccess;
+}
+
+// hipMalloc for everything that is NOT a segment array (workspaces, staging pools, dictionaries, user buffers): when the driver
+// has no room, the idle segment arrays in the cache are the first thing to give back
+hipError_t dm_malloc_retry(void **p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        dm_trim(0);
+        e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 
 void dm_free(void *p) {

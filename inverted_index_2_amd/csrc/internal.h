@@ -73,6 +73,7 @@ struct ii2_ctx {
     uint32_t *d_small = nullptr;        // small set operations: ascending ids [8192] + the workgroup ticket (setop_small.hip)
     void *comm = nullptr;               // ncclComm_t
     int world = 1, rank = 0;
+    uint64_t comm_syncs = 0;            // host waits inside the exchange entry points (what a chunked exchange pays per chunk)
     int cu_count = 256;
 };
 
@@ -81,6 +82,7 @@ namespace ii2 {
 // device memory of segments: a size-class cache in front of hipMalloc / hipFree (devmem.cpp)
 hipError_t dm_alloc(void **p, size_t bytes);
 void dm_free(void *p);
+hipError_t dm_malloc_retry(void **p, size_t bytes);   // hipMalloc; on failure the cache's idle arrays go back to the driver and it tries once more
 void dm_trim(size_t keep_bytes);
 void dm_user(int delta);
 void dm_stats(uint64_t *live_bytes, uint64_t *idle_bytes);
@@ -101,7 +103,10 @@ struct ii2_seg_store {
 // read it, from any thread (the reference's readers share segments, segments.go:32-46).
 struct ii2_seg {
     int device = 0;
+    bool is_view = false;                    // made by ii2_seg_select*: blocks numbered inside another segment's store (not self-contained)
     bool in_slab = false;                    // every array below lives in store->slab (nothing to free one by one)
+    hipStream_t born = nullptr;              // stream of the call that is building the segment (cleared when it is finished): an unfinished segment's arrays may
+                                             // still be written by enqueued kernels, so releasing one waits for that stream first
     std::shared_ptr<ii2_seg_store> store;   // owns d_skip / d_payload
     uint64_t n_lists = 0, n_postings = 0, n_blocks = 0, n_bytes = 0;
     uint32_t *d_blk_off = nullptr;   // [n_lists+1]
@@ -130,7 +135,7 @@ struct ii2_tomb {
 };
 
 void ii2_comm_destroy_internal(ii2_ctx *ctx);
-int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, ii2_seg **out);   // ctx->mu held
+int ii2_seg_alloc_internal(ii2_ctx *ctx, uint64_t n_lists, uint64_t n_postings, uint64_t n_blocks, uint64_t n_bytes, ii2_seg **out, bool with_meta = false);   // ctx->mu held
 int ii2_seg_rebase_internal(ii2_ctx *ctx, ii2_seg *seg, int world, const uint64_t *lo, const uint64_t *bo, const uint64_t *qo);            // ctx->mu held
 void *ii2_pool_get(ii2_ctx *ctx, int slot, size_t bytes);      // grow-only ctx buffer `slot`, at least `bytes` (nullptr: out of memory); ctx->mu held
 uint64_t *ii2_mapped_mail(ii2_ctx *ctx, uint32_t word);
@@ -319,7 +324,8 @@ hipError_t launch_validate_seg(const uint32_t *blk_off, uint64_t n_lists, const 
                                uint32_t *bad, hipStream_t s);
 hipError_t launch_list_spans(const uint32_t *blk_off, const ii2_skip *skip, const uint32_t *last_doc, uint64_t n_lists, uint32_t *spans, hipStream_t s);
 hipError_t launch_seg_rebase(uint32_t *blk_off, uint64_t n_lists, uint32_t add_blocks, ii2_skip *skip, uint64_t n_blocks, uint32_t add_bytes,
-                             hipStream_t s);
+                             uint32_t *blk_list, uint32_t add_lists, hipStream_t s);
+hipError_t launch_seg_close(uint32_t *blk_off_end, uint32_t n_blocks, ii2_skip *skip_end, uint32_t n_bytes, uint8_t *payload_end, uint32_t *blk_list_end, hipStream_t s);
 hipError_t launch_sum_u32(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
 hipError_t launch_max_u32(const uint32_t *v, uint64_t n, uint32_t *out, hipStream_t s);
 

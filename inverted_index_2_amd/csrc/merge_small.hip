@@ -377,6 +377,7 @@ static int small_core(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, cons
     *n_kept = 0;
     const uint64_t n = seg_first[k];
     if (seg_first[0] != 0) return fail(ctx, II2_EINVAL, "ii2_merge_small: seg_first[0] must be 0");
+    if (n && term_off[n] && !term_bytes) return fail(ctx, II2_EINVAL, "ii2_merge_small: term_bytes is NULL");
     if (n > SM_T || n_removed > SM_R) return fail(ctx, II2_ERANGE, "ii2_merge_small: too many terms or removed ids for the one-launch merge");
     uint64_t n_post = 0;
     for (uint32_t s = 0; s < k; s++) {
@@ -392,7 +393,7 @@ static int small_core(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, cons
     // staging blocks (made once per context): the upload, the download
     if (!ctx->h_small_in) {
         if (hipHostMalloc((void **)&ctx->h_small_in, sizeof(SmallIn)) != hipSuccess || hipHostMalloc((void **)&ctx->h_small_out, sizeof(SmallOut)) != hipSuccess ||
-            hipMalloc((void **)&ctx->d_small_in, sizeof(SmallIn)) != hipSuccess || hipMalloc((void **)&ctx->d_small_out, sizeof(SmallOut)) != hipSuccess)
+            ii2::dm_malloc_retry((void **)&ctx->d_small_in, sizeof(SmallIn)) != hipSuccess || ii2::dm_malloc_retry((void **)&ctx->d_small_out, sizeof(SmallOut)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "ii2_merge_small: staging allocation failed");
     }
     SmallIn *hi = (SmallIn *)ctx->h_small_in;
@@ -441,13 +442,13 @@ static int small_core(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, cons
     // (a read also takes the merged ids: at most as many as the lists hold)
     if (e == hipSuccess) e = hipMemcpyAsync(ho, ctx->d_small_out, offsetof(SmallOut, values) + (raw ? n_post * sizeof(uint32_t) : 0), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { dm_free(slab); ctx->err = std::string("ii2_merge_small: ") + hipGetErrorString(e); return II2_EHIP; }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(st); dm_free(slab); ctx->err = std::string("ii2_merge_small: ") + hipGetErrorString(e); return II2_EHIP; }
     if (ho->error) { dm_free(slab); return fail(ctx, II2_ERANGE, "ii2_merge_small: the lists hold more postings than the one-launch merge takes"); }
     if (stats) { stats->n_in = ho->n_in; stats->n_out = ho->n_out; stats->n_terms_out = ho->n_terms_out; stats->n_tiles = 1; }
+    if (raw && ho->n_out > cap) return fail(ctx, II2_ECAPACITY, "ii2_read_small: the values buffer is too small; nothing was written");
     *n_kept = ho->n_terms_out;
     for (uint64_t j = 0; j < ho->n_terms_out; j++) kept[j] = ho->kept[j];
     if (raw) {
-        if (ho->n_out > cap) return fail(ctx, II2_ECAPACITY, "ii2_read_small: the values buffer is too small; nothing was written");
         for (uint64_t j = 0; j <= ho->n_terms_out; j++) post_off[j] = ho->blk_off[j];
         if (ho->n_out) std::memcpy(values, ho->values, ho->n_out * sizeof(uint32_t));
         return II2_OK;

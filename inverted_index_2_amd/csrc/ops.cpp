@@ -29,7 +29,7 @@ static size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+    hipError_t alloc(size_t bytes) { return ii2::dm_malloc_retry(&p, bytes ? bytes : 16); }
     template <class T> T *as() const { return (T *)p; }
 };
 
@@ -58,7 +58,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     std::memset(&p, 0, sizeof p);
     // the views travel through a pinned staging block (the call ends with a stream sync, so the next call may reuse it)
     if (!ctx->h_segs) {
-        if (hipHostMalloc((void **)&ctx->h_segs, sizeof(MergeSegs)) != hipSuccess || hipMalloc((void **)&ctx->d_segs, sizeof(MergeSegs)) != hipSuccess)
+        if (hipHostMalloc((void **)&ctx->h_segs, sizeof(MergeSegs)) != hipSuccess || ii2::dm_malloc_retry((void **)&ctx->d_segs, sizeof(MergeSegs)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "merge: staging allocation failed");
     }
     MergeSegs *hs = (MergeSegs *)ctx->h_segs;
@@ -100,7 +100,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
         buf = nullptr;
         bcap = 0;
         const size_t want = align_up(bytes + bytes / 8, 1 << 20);
-        if (hipMalloc((void **)&buf, want) != hipSuccess) return false;
+        if (ii2::dm_malloc_retry((void **)&buf, want) != hipSuccess) return false;
         bcap = want;
         return true;
     };
@@ -168,7 +168,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.d_total = ctx->d_mail;                    // [0] total, [2] surviving terms
     p.debug = nullptr;
     if (ctx->opt_debug_stamps) {
-        if (!ctx->d_debug && hipMalloc((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
+        if (!ctx->d_debug && ii2::dm_malloc_retry((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }

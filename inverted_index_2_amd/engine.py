@@ -115,10 +115,11 @@ class Context:
         self._ck(self.lib.ii2_set_option(self.h, name.encode(), int(value)))
 
     def counters(self):
-        """(merges repeated on the packing path, look-back launches repeated on their second path) - see ii2_ctx_counters."""
-        out = (C.c_uint64 * 2)()
-        self._ck(self.lib.ii2_ctx_counters(self.h, out, 2))
-        return int(out[0]), int(out[1])
+        """(merges repeated on the packing path, look-back launches repeated on their second path, host waits inside the exchange
+        entry points) - see ii2_ctx_counters."""
+        out = (C.c_uint64 * 3)()
+        self._ck(self.lib.ii2_ctx_counters(self.h, out, 3))
+        return int(out[0]), int(out[1]), int(out[2])
 
     def profile_read(self):
         """(total device ms, launches) of the dominant kernel since the last read (option profile.events)."""
@@ -409,6 +410,13 @@ class Context:
         counts = (C.c_uint64 * max(world, 1))()
         self._ck(self.lib.ii2_allgatherv_bytes(self.h, _ptr(local), n_bytes, _ptr(out), out.nbytes, counts))
         return [int(c) for c in counts]
+
+    def seg_concat(self, segs: Sequence["Segment"]) -> "Segment":
+        """The lists of segs[0], then segs[1], ... as one segment on this device (ii2_seg_concat)."""
+        arr = (C.c_void_p * len(segs))(*[s.h for s in segs])
+        h = C.c_void_p()
+        self._ck(self.lib.ii2_seg_concat(self.h, len(segs), arr, C.byref(h)))
+        return Segment(self, h)
 
     def seg_allgather(self, local: "Segment") -> "Segment":
         """Every rank's merged segment, concatenated in rank order into one segment (the postings travel DV1-encoded)."""

@@ -159,6 +159,46 @@ def test_segment_allgather_with_one_rank_is_a_copy(ctx):
     assert np.array_equal(b.download(777), (np.arange(777) % 251).astype(np.uint8))
 
 
+def test_segments_concatenate_like_the_exchange_would(ctx):
+    """ii2_seg_concat is the exchange's arithmetic on one device (ii2_seg_gather_plan + copies + the shift of block numbers, byte
+    offsets and block owners that ii2_seg_allgather applies to the parts it receives): three segments - one of them empty, one
+    with empty lists at its ends - must concatenate into, byte for byte, the encoding of the concatenated lists; views are refused."""
+    rng = np.random.default_rng(21)
+    parts = []
+    for n_lists, max_len in ((40, 900), (0, 0), (25, 3000), (7, 5)):
+        lens = rng.integers(0, max_len + 1, n_lists)
+        if n_lists:
+            lens[0] = 0; lens[-1] = 0
+        lists = [sorted_unique(rng, int(n), 1 << 24) for n in lens]
+        po = np.concatenate([[0], np.cumsum([x.size for x in lists])]).astype(np.uint64)
+        flat = np.concatenate(lists + [np.empty(0, np.uint32)]).astype(np.uint32)
+        parts.append((po, flat))
+    segs = [ctx.encode(po, flat) for po, flat in parts]
+    before = ctx.counters()[2]
+    cat = ctx.seg_concat(segs)
+    assert ctx.counters()[2] == before + 1                      # one host wait for the whole concatenation
+    po_all = np.concatenate([[0]] + [po[1:] + sum(int(q[0][-1]) for q in parts[:i]) for i, (po, _) in enumerate(parts)]).astype(np.uint64)
+    flat_all = np.concatenate([f for _, f in parts]).astype(np.uint32)
+    oblk, oskip, opayload = orc.dv1_encode(po_all, flat_all)
+    blk, skip, payload = cat.export()
+    assert np.array_equal(blk, oblk) and np.array_equal(skip["first_doc"][:-1], oskip["first_doc"][:-1]) and np.array_equal(skip["byte_off"], oskip["byte_off"])
+    assert np.array_equal(payload, opayload)
+    gpo, gv = cat.decode()
+    assert np.array_equal(gpo, po_all) and np.array_equal(gv, flat_all)
+    # the derived arrays travelled and were shifted too: a query against a list of the last part finds it
+    li = parts[0][0].size - 1 + parts[2][0].size - 1 + 3
+    a = flat_all[int(po_all[li]):int(po_all[li + 1])]
+    out, n = ctx.intersect([(cat, li), (cat, li)])
+    assert n == a.size and np.array_equal(out.download(n), a)
+    merged, _ = ctx.merge_to_segment([cat, cat])                # and the merge reads it like any other segment
+    mpo, mv = merged.decode()
+    assert np.array_equal(mpo, po_all) and np.array_equal(mv, flat_all)
+    from inverted_index_2_amd.engine import II2Error
+    view = ctx.select(segs[0], np.arange(3, 10, dtype=np.int64))
+    with pytest.raises(II2Error):
+        ctx.seg_concat([view, segs[2]])
+
+
 def test_freed_segment_arrays_are_reused_not_returned_to_the_driver(ctx):
     """devmem.cpp: a freed segment's device arrays wait in a size-class cache; making the same segment again takes them out
     of it instead of allocating (ii2_devmem_stats: live bytes come back to the same value, idle bytes do not grow)."""
