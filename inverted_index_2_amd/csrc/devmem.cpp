@@ -67,9 +67,10 @@ hipError_t dm_alloc(void **p, size_t bytes) {
     }
     hipError_t e = hipMalloc(p, cls);
     if (e != hipSuccess) {                               // make room: give the idle arrays back and try once more
+        (void)hipGetLastError();
         dm_trim(0);
         e = hipMalloc(p, cls);
-        if (e != hipSuccess) return e;
+        if (e != hipSuccess) { (void)hipGetLastError(); return e; }
     }
     std::lock_guard<std::mutex> g(g_cache.mu);
     g_cache.live[*p] = key;
@@ -84,6 +85,7 @@ hipError_t dm_malloc_retry(void **p, size_t bytes) {
         (void)hipGetLastError();
         dm_trim(0);
         e = hipMalloc(p, bytes);
+        if (e != hipSuccess) (void)hipGetLastError();      // (the runtime keeps a failed call's error for the next hipGetLastError: a later launch check would report it)
     }
     return e;
 }

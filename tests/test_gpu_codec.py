@@ -222,3 +222,39 @@ def test_freed_segment_arrays_are_reused_not_returned_to_the_driver(ctx):
         assert np.array_equal(v, np.concatenate(lists))
         seg.free()
         assert stats() == (live0, idle0)
+
+
+def test_idle_segment_arrays_go_back_to_the_driver_when_another_allocation_needs_the_room(ctx):
+    """The cache keeps freed segment arrays; every OTHER device allocation of the library (user buffers, workspaces, staging
+    pools, dictionaries) goes through a helper that, when hipMalloc fails, gives the idle arrays back and tries once more.
+    Fill HBM with ii2_dev_alloc until it fails: by then the cache must be empty (ii2_devmem_stats), and once the big buffers
+    are released the library works as before."""
+    import ctypes as C
+    from inverted_index_2_amd.engine import II2Error
+    rng = np.random.default_rng(4)
+    lists = [np.unique(rng.integers(0, 1 << 26, 400_000)).astype(np.uint32) for _ in range(8)]
+
+    def idle():
+        live, idl = C.c_uint64(), C.c_uint64()
+        ctx.lib.ii2_devmem_stats(C.byref(live), C.byref(idl))
+        return idl.value
+    ctx.encode_lists(lists).free()
+    assert idle() > 0                                            # arrays are waiting in the cache
+    hogs, chunk = [], 16 << 30
+    try:
+        for _ in range(64):                                      # 288 GB of HBM: fails long before 64 x 16 GB
+            try:
+                hogs.append(ctx.empty(chunk, np.uint8))
+            except II2Error as e:
+                assert e.code == -2                              # II2_ENOMEM
+                break
+        else:
+            pytest.skip("the device took 1 TB of allocations: nothing to test here")
+        assert idle() == 0                                       # the failing attempt gave the cache back before it gave up
+    finally:
+        for h in hogs:
+            h.free()
+    seg = ctx.encode_lists(lists)
+    _, v = seg.decode()
+    assert np.array_equal(v, np.concatenate(lists))
+    seg.free()
