@@ -1009,8 +1009,8 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
     // one block of the long list per candidate, one after the other: split its blocks over several tiles
     uint32_t sub = 1;
     if (n >= 2 && G == 1 && (per_block_span >= 8192.0 || (nblk0 == 1 && views[n - 1].nblk >= 64)) && ctx->opt_intersect_g <= 0) {
-        const uint32_t want_tiles = 4u * (uint32_t)ctx->cu_count;
-        if (nblk0 < want_tiles) sub = std::min<uint32_t>(16u, (want_tiles + nblk0 - 1u) / nblk0);
+        const uint32_t want_tiles = (ctx->opt_intersect_subtiles > 0 ? (uint32_t)ctx->opt_intersect_subtiles : 4u) * (uint32_t)ctx->cu_count;
+        if (nblk0 < want_tiles) sub = std::min<uint32_t>(ctx->opt_intersect_submax > 0 ? (uint32_t)ctx->opt_intersect_submax : 16u, (want_tiles + nblk0 - 1u) / nblk0);
     }
     p.G = G;
     // the pipelined gallop pays when a driver block faces many blocks of a long list (candidates then hit distinct blocks)
@@ -1331,6 +1331,8 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "intersect.map_docs") ctx->opt_intersect_map_docs = value;
     else if (k == "intersect.dense") ctx->opt_intersect_dense = value;
     else if (k == "intersect.dense_bpw") ctx->opt_dense_bpw = value;
+    else if (k == "intersect.subtiles") ctx->opt_intersect_subtiles = value;
+    else if (k == "intersect.submax") ctx->opt_intersect_submax = value;
     else if (k == "intersect.and2") ctx->opt_intersect_and2 = value;      // 0: n-list kernel, 1: one launch (look-back), 2: two kernels
     else if (k == "intersect.and2_spin") ctx->opt_and2_spin = value;
     else if (k == "encode.stream") ctx->opt_encode_stream = value;        // 1: one-pass encoder behind a merge (default), 0: two-pass, -1: forced fallback (tests)

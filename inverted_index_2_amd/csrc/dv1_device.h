@@ -334,6 +334,36 @@ __device__ __forceinline__ uint32_t skip_upper_bound(const ii2_skip *__restrict_
     return lo;
 }
 
+// first index i in [lo, hi) with get(i) > x, for an ascending sequence that is close to uniform between vlo (a lower bound of
+// get(lo)) and vhi (an upper bound of get(hi - 1)): a linear guess, a doubling walk away from it until x is bracketed, then
+// bisection inside the bracket — a handful of dependent loads instead of log2(hi - lo).  Exact for any ascending input.
+template <class Get>
+__device__ __forceinline__ uint32_t upper_bound_guess(Get get, uint32_t lo, uint32_t hi, uint32_t x, uint32_t vlo, uint32_t vhi) {
+    if (lo >= hi) return lo;
+    if (hi - lo > 4u && vhi > vlo) {
+        const uint64_t rel = x > vlo ? (uint64_t)(x - vlo) : 0ull;
+        uint64_t g64 = (uint64_t)lo + rel * (uint64_t)(hi - lo) / ((uint64_t)(vhi - vlo) + 1ull);
+        uint32_t g = g64 >= hi ? hi - 1u : (uint32_t)g64;
+        if (get(g) <= x) {                                  // answer in (g, hi]: walk up
+            uint32_t a = g + 1u, step = 1u;
+            while (a < hi) {
+                const uint32_t pr = a + step - 1u < hi ? a + step - 1u : hi - 1u;
+                if (get(pr) <= x) { a = pr + 1u; step <<= 1; } else { hi = pr; break; }
+            }
+            lo = a;                                         // get(i) <= x for i < lo; get(hi) > x or hi is the end
+        } else {                                            // answer in [lo, g]: walk down
+            uint32_t b = g, step = 1u;
+            while (b > lo) {
+                const uint32_t pr = b - lo > step ? b - step : lo;
+                if (get(pr) > x) { b = pr; step <<= 1; } else { lo = pr + 1u; break; }
+            }
+            hi = b;
+        }
+    }
+    while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (get(mid) <= x) lo = mid + 1u; else hi = mid; }
+    return lo;
+}
+
 __device__ __forceinline__ unsigned varint_len(uint32_t v) {
     return v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u;
 }

@@ -53,6 +53,8 @@ struct ii2_ctx {
     int64_t opt_union_stream = 1;       // ... and, for 2-4 lists paced by a long dense one, through the streaming kernel
     int64_t opt_union_dense = 1;        // unions of lists that are dense together go through the byte-map tiles (OR)
     int64_t opt_intersect_bitmap = 1;   // per-list bitmaps for very dense tiles
+    int64_t opt_intersect_subtiles = 0; // tiny sparse drivers: tiles per CU their blocks are split into (0 = default)
+    int64_t opt_intersect_submax = 0;   // ... and the most slices one driver block is cut into (0 = default)
     int64_t opt_intersect_dense = 1;    // dense 2..4-list queries go to the wave-streaming kernels (intersect_dense.hip)
     int64_t opt_dense_bpw = 0;          // driver blocks per wave there (0 = default)
     int64_t opt_encode_stream = 1;      // merged segments are encoded in one pass over the ids (encode_stream.hip)

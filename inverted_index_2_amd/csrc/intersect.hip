@@ -684,7 +684,14 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                                 uint32_t a = 0, e = bh - bl;
                                 while (a < e) { const uint32_t mid = a + ((e - a) >> 1); if (fd[mid] <= c) a = mid + 1u; else e = mid; }
                                 ub = bl + a;
-                            } else ub = skip_upper_bound(L.skip, bl, bh, c);
+                            } else {
+                                // a long list (thousands of blocks in the tile's doc range) against a handful of candidates: a plain
+                                // bisection of its skip table in HBM is a dozen dependent round trips per candidate (~20 us a list, the
+                                // largest part of a tile's life on BASELINE configs[4]); posting lists are close to uniform over a
+                                // tile's range, so a linear guess + a short walk finds the block in two to four
+                                auto get = [&](uint32_t jj) { return L.skip[jj].first_doc; };
+                                ub = upper_bound_guess(get, bl, bh, c, D[0], D[1]);
+                            }
                             if (ub > bl) blk = ub - 1u;
                         }
                         if (NFIX == 0u && bh - bl >= 16u) {       // many blocks in range: candidates mostly hit distinct ones
