@@ -116,13 +116,31 @@ def cores_available():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
 
 
+def kernel_sources_hash():
+    """sha256 over the library's kernel and host sources (csrc/): what a PMC summary under profiles/ was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "inverted_index_2_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(name):
     """HBM bytes per pass from the PMC passes kept under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the same
-    workload, scripts/pmc_run.sh) — a recorded figure, not a counter of this run; the JSON says so (`traffic_source`)."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_%s.json" % name)
+    workload, scripts/r04_profiles.sh) — a recorded figure, not a counter of this run; the JSON says so (`traffic_source`).
+    Every summary carries the hash of the sources it was measured on (`source_hash`): when the sources have changed since,
+    the figure is stale and the line reports null (with the reason) instead of a number that no longer describes the kernels."""
+    path = os.path.join(ROOT, "profiles", "r04_pmc_%s.json" % name)
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_pass_corrected"], os.path.relpath(path, ROOT)
+            d = json.load(f)
+        rel = os.path.relpath(path, ROOT)
+        if d.get("source_hash") != kernel_sources_hash():
+            return None, "%s is stale: taken on sources %s, this tree is %s" % (rel, d.get("source_hash"), kernel_sources_hash())
+        return d["hbm_bytes_per_pass_corrected"], rel
     except (OSError, KeyError, ValueError):
         return None, None
 
@@ -411,6 +429,37 @@ def bench_intersect(job):
         tomb_t.free()
         ctx.intersect(lists, tomb=None, out=out)       # leave the headline result in `out`
 
+    # the same two lists as a UNION (PrefixSearch's append + sort + compact over the lists of the matching terms,
+    # inverted_index.go:274-292): ii2_union's streaming path (the dense kernel with OR semantics), numpy-checked
+    if tomb is None and world == 1:
+        try:
+            u_out = ctx.empty(int(a.size + b.size) + 16)
+            _, n_u = ctx.union(lists, out=u_out)
+            ok_u = n_u == np.union1d(a, b).size and bool(np.array_equal(u_out.download(min(n_u, 1 << 22)), np.union1d(a, b)[: 1 << 22]))
+            ctx.set_option("profile.events", 1)
+            ctx.profile_read()
+            u_steps = max(5, min(args.steps, 20))
+            t0u = time.perf_counter()
+            for _ in range(u_steps):
+                ctx.union(lists, out=u_out)
+            u_wall = (time.perf_counter() - t0u) / u_steps
+            u_ms, u_n = ctx.profile_read()
+            ctx.set_option("profile.events", 0)
+            u_dev = u_ms / max(u_n, 1) * 1e-3
+            alg_u = info.n_bytes + 8 * info.n_blocks + 4 * n_u
+            res["union"] = {"value": n_in / u_dev, "unit": "postings/s", "result_ids": int(n_u), "kernel_avg_us": u_dev * 1e6,
+                            "wall_us_per_call": u_wall * 1e6, "calls_timed": int(u_n),
+                            "roofline": {"bound": "hbm", "achieved": alg_u / u_dev / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": alg_u / u_dev / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": int(alg_u), "traffic": None},
+                            "what": "ii2_union of the headline's two lists (synchronous call: it returns the count, one stream wait); device "
+                                    "time from an event pair per call, wall time beside it",
+                            "check": "equals numpy's union (count; first 4M ids compared)" if ok_u else "MISMATCH"}
+            if not ok_u:
+                job.rc = 5
+            u_out.free()
+        except Exception as e:  # noqa: BLE001 — the headline stands on its own
+            res["union"] = {"error": repr(e)}
+
     # the exchange step, once, after the timed region: rank-order concatenation of the results
     if world > 1:
         def exchange():
@@ -567,6 +616,38 @@ def bench_merge(job):
     }
     if cpu is not None:
         res["cpu_baseline"] = cpu
+    # Shard.Merge's REAL output (shard.go:207 -> file/writer.go:32-59): the merged terms as an encoded segment —
+    # ii2_merge_segments_to_seg = the same merge + the one-pass DV1 encoder (encode_stream.hip).  Checked: the segment decodes to the
+    # raw merge (which the oracle checked above); byte-for-byte equality with the oracle's encoding is tests/test_gpu_configs.py.
+    try:
+        mseg, st_s = ctx.merge_to_segment(segs, tomb)
+        minfo = mseg.info
+        po_s, v_s = mseg.decode()
+        ok_s = int(st_s.n_out) == int(st.n_out) and bool(np.array_equal(po_s, out_off.download())) and \
+            bool(np.array_equal(v_s, out_vals.download(int(st.n_out))))
+        del po_s, v_s
+        mseg.free()
+        job.sync_all()
+        t0s = time.perf_counter()
+        for _ in range(steps):
+            sgi, _ = ctx.merge_to_segment(segs, tomb)
+            sgi.free()
+        job.sync_all()
+        seg_s = (time.perf_counter() - t0s) / steps
+        enc_in = sum(sg.info.n_bytes for sg in segs) + 8 * sum(sg.info.n_blocks for sg in segs) + 4 * k * (T + 1)
+        alg_s = enc_in + args.docs // 8 + int(minfo.n_bytes) + 8 * int(minfo.n_blocks) + 4 * (T + 1)     # SURVEY §8 d, enc_bytes(out) form
+        res["to_segment"] = {
+            "value": n_in / seg_s, "unit": "postings/s", "ms_per_step": seg_s * 1e3, "steps": steps,
+            "ratio_to_raw_merge": seg_s / (dt / steps), "out_payload_bytes": int(minfo.n_bytes), "out_blocks": int(minfo.n_blocks),
+            "roofline": {"bound": "hbm", "achieved": alg_s / seg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_s / seg_s / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": int(alg_s), "traffic": None,
+                         "timing": "wall clock per ii2_merge_segments_to_seg call (two host waits inside: the merge's counts, the encoder's byte count)"},
+            "what": "the drop-in Shard.Merge path: merge + one-pass DV1 encode of the merged terms into a ready segment",
+            "check": "decodes to the oracle-checked raw merge" if ok_s else "MISMATCH"}
+        if not ok_s:
+            job.rc = 5
+    except Exception as e:  # noqa: BLE001
+        res["to_segment"] = {"error": repr(e)}
     # end to end with the term alignment on the device: every segment keeps only the terms it really holds
     # (its own dictionary of 8-byte big-endian term ids); ii2_align_terms merges the k dictionaries, ii2_seg_select_aligned
     # builds the aligned views, then the same merge runs on them
@@ -678,11 +759,22 @@ def bench_merge_strong(job):
     impl = "ii2_seg_allgather on one rank (a device copy)"
     if world > 1:
         job.init_comm(xctx)
-        impl = ("ii2_seg_allgather: ncclAllGather of the shapes + three grouped ncclSend/ncclRecv exchanges (list table, skip table, "
-                "payload) per chunk over xGMI" if job.comm == "ii2" else "torch.distributed.all_gather of the padded DV1 arrays (ii2_comm_init failed on some rank)")
+        impl = ("ii2_seg_allgather: ncclAllGather of the shapes + ONE grouped ncclSend/ncclRecv exchange of the segment's six arrays "
+                "per chunk over xGMI, two host waits per chunk" if job.comm == "ii2" else "torch.distributed.all_gather of the padded DV1 arrays (ii2_comm_init failed on some rank)")
 
-    def exchange(seg):
-        """One chunk's merged segment to every rank; returns (bytes this rank received, own part intact)."""
+    # where this rank's lists sit inside a gathered segment: after the lists of the ranks before it (every chunk holds one
+    # list slot per term of the rank's chunk, so the counts are known without asking)
+    chunk_lists = [[0] * world for _ in range(n_chunks)]
+    if world > 1:
+        mine_l = job.torch.tensor([b2 - a for a, b2 in zip(cuts[:-1], cuts[1:])], dtype=job.torch.int64, device=job.dev)
+        all_l = [job.torch.zeros_like(mine_l) for _ in range(world)]
+        job.dist.all_gather(all_l, mine_l)
+        chunk_lists = [[int(all_l[r][c].item()) for r in range(world)] for c in range(n_chunks)]
+
+    def exchange(seg, ci=0, check=False):
+        """One chunk's merged segment to every rank; returns (bytes this rank received, own part intact).  check: the
+        gathered segment's slice of THIS rank's lists is decoded and compared with the chunk's own decode - offsets, ids and
+        therefore the block numbers and byte offsets the receiver shifted (outside the timed passes: it moves the ids to the host)."""
         if seg is None:
             seg_bytes = 0
         else:
@@ -693,10 +785,23 @@ def bench_merge_strong(job):
         if world == 1 or job.comm == "ii2":
             if seg is None:          # a chunk in which nothing survived still takes part in the collective
                 seg = empty_seg
+            s0 = xctx.counters()[2]
+            tq = time.perf_counter()
             g = xctx.seg_allgather(seg)
+            if os.environ.get("BENCH_TRACE"):
+                print("rank %d: seg_allgather %.2f ms, %d host waits" % (rank, (time.perf_counter() - tq) * 1e3, xctx.counters()[2] - s0), file=sys.stderr, flush=True)
             ginf = g.info
             got = int(ginf.n_bytes + 8 * ginf.n_blocks + 4 * ginf.n_lists)
             ok = ginf.n_postings >= seg.info.n_postings and ginf.n_lists >= seg.info.n_lists
+            if check and ok and seg is not empty_seg:
+                first = sum(chunk_lists[ci][:rank]) if world > 1 else 0
+                n_l = int(seg.info.n_lists)
+                gpo, gv = g.decode()
+                mpo, mv = seg.decode()
+                gpo = gpo.astype(np.int64)
+                lo_p, hi_p = int(gpo[first]), int(gpo[first + n_l])
+                ok = bool(np.array_equal(gpo[first:first + n_l + 1] - lo_p, mpo.astype(np.int64)) and np.array_equal(gv[lo_p:hi_p], mv))
+                del gpo, gv, mpo, mv
             g.free()
             return got, bool(ok)
         # fallback (the library communicator failed somewhere): the three arrays through torch's communicator, padded
@@ -731,15 +836,15 @@ def bench_merge_strong(job):
             print("rank %d: merge_to_segment %.2f ms (worker %d)" % (rank, (time.perf_counter() - tq) * 1e3, ci % n_workers), file=sys.stderr, flush=True)
         return sg
 
-    def one_pass(with_exchange):
+    def one_pass(with_exchange, check=False):
         """All chunks of this rank: merged to segments by the workers, handed to the exchange thread in term order."""
         pending, merged = [], []
         futs = [wpool.submit(merge_chunk, ci, vw) for ci, vw in enumerate(views)]
-        for f in futs:
+        for ci, f in enumerate(futs):
             sg = f.result()
             merged.append(sg)
             if with_exchange:
-                pending.append(pool.submit(exchange, sg))
+                pending.append(pool.submit(exchange, sg, ci, check))
         tq = time.perf_counter()
         got = [f.result() for f in pending]
         tr = time.perf_counter()
@@ -771,7 +876,13 @@ def bench_merge_strong(job):
     if not chk_ok:
         print(f"rank {rank}: the chunked merge-to-segment path differs from the raw merge", file=sys.stderr, flush=True)
         job.rc = 5
-    one_pass(True)                                            # warm-up: staging buffers and, N > 1, the communicator's channels
+    # warm-up (staging buffers and, N > 1, the communicator's channels) - and the exchange's content check: every gathered
+    # segment's slice of this rank's lists decodes to the chunk that was sent.  The first collective of the run: under the watchdog.
+    warm = job.guarded("the merge's first segment exchange", lambda: one_pass(True, check=True))
+    warm_ok = all(ok for _, ok in warm)
+    if not warm_ok:
+        print(f"rank {rank}: a gathered segment does not hold this rank's chunk", file=sys.stderr, flush=True)
+        job.rc = 4
     job.sync_all()
     t_a = time.perf_counter()
     for _ in range(steps):
@@ -814,7 +925,8 @@ def bench_merge_strong(job):
                              "what": "one ii2_merge_segments call per rank over its whole range (u32 CSR out), no exchange"},
         "exchange": {"impl": impl, "bytes_received_per_rank_per_step": recv_bytes // max(steps, 1),
                      "bytes_if_raw_u32": 4 * n_out_total,
-                     "check": ("chunks decode to the raw merge; every gathered segment holds this rank's part" if (exch_ok and chk_ok)
+                     "check": ("chunks decode to the raw merge; this rank's slice of every gathered segment decodes to the chunk it sent "
+                               "(offsets and ids, checked once before the timed passes)" if (exch_ok and chk_ok and warm_ok)
                                else "MISMATCH on rank %d" % rank)},
     }
     if not exch_ok:
@@ -854,6 +966,22 @@ def c5_lists(D, world, rank):
         parts.append(core)
         lists.append(np.unique(np.concatenate(parts)).astype(np.uint32))
     return lists, (lo, hi)
+
+
+def c5_roofline(info, n_out, step_s, D, world):
+    """SURVEY §8 d: the intersection's algorithmic bytes are the WHOLE encoded lists + skip tables + the result ("a galloping
+    kernel that skips blocks may touch fewer bytes; report touched bytes separately, keep this formula for the roofline").  For
+    this query the formula says little about the kernel: it gallops - 10,000 result ids out of 833M postings - and touches a few
+    percent of the bytes; `touched_bytes` (FETCH_SIZE + WRITE_SIZE of one query, profiles/r04_pmc_c5.json) is what moves."""
+    alg = int(info.n_bytes + 8 * info.n_blocks + 4 * n_out)
+    touched, src = (None, None)
+    if D == 1_000_000_000 and world == 1:
+        touched, src = pmc_traffic("c5")
+    return {"bound": "latency (dependent block fetches; see DESIGN.md §4.1b) - the HBM formula is kept as SURVEY §8 d prescribes",
+            "achieved": alg / step_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / step_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg, "touched_bytes": touched, "touched_bytes_source": src,
+            "touched_frac_of_algorithmic": (touched / alg) if touched else None,
+            "touched_GBps": (touched / step_s / 1e9) if touched else None}
 
 
 def bench_c5(job):
@@ -907,6 +1035,7 @@ def bench_c5(job):
                    "generate_s": round(gen_s, 1)},
         "rank0_device_us_per_query": dev_s / steps * 1e6,
         "rank0_encoded_bytes": int(info.n_bytes + 8 * info.n_blocks),
+        "roofline": c5_roofline(info, n_out, dev_s / steps, D, world),
         "check": "every rank's result equals the oracle's on its doc range (rank 0: %d ids, oracle %.2f s)" % (n_out, oracle_s),
     }
     if world > 1:
