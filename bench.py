@@ -61,8 +61,11 @@ def parse():
     ap.add_argument("--merge-mean", type=float, default=1000.0)
     ap.add_argument("--merge-steps", type=int, default=0, help="timed merges (0: min(steps, 10))")
     ap.add_argument("--cold-pairs", type=int, default=4)
-    ap.add_argument("--strong-chunks", type=int, default=4, help="merge_strong: chunks a rank's term range is merged and exchanged in")
-    ap.add_argument("--strong-workers", type=int, default=2,
+    ap.add_argument("--strong-chunks", type=int, default=3, help="merge_strong: chunks a rank's term range is merged and exchanged in")
+    ap.add_argument("--strong-last-share", type=float, default=0.5,
+                    help="merge_strong: cost share of a rank's LAST chunk relative to the others (its exchange is the only one no later "
+                         "merge hides)")
+    ap.add_argument("--strong-workers", type=int, default=3,
                     help="merge_strong: chunks merged side by side, one context (stream + scratch) each - the reference's "
                          "InvertedIndex.Merge(…, concurrency) fan-out (inverted_index.go:62-109) on one GPU")
     ap.add_argument("--c5-docs", type=int, default=1_000_000_000, help="c5: doc-id universe of the whole index (config 5: 1B)")
@@ -747,7 +750,9 @@ def bench_merge_strong(job):
     del offs
     n_chunks = max(1, min(args.strong_chunks, t1 - t0))
     cum = np.concatenate([[0.0], np.cumsum(sharding.merge_cost_weights(per_term, encode=True))])
-    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * c / n_chunks)) for c in range(1, n_chunks)] + [t1 - t0]
+    shares = np.array([1.0] * (n_chunks - 1) + [min(max(args.strong_last_share, 0.05), 1.0)]) if n_chunks > 1 else np.array([1.0])
+    bounds = np.cumsum(shares) / shares.sum()
+    cuts = [0] + [int(np.searchsorted(cum, cum[-1] * bounds[c - 1])) for c in range(1, n_chunks)] + [t1 - t0]
     cuts = [max(a, b) for a, b in zip(cuts, np.maximum.accumulate(cuts))]
     views = []
     for a, b2 in zip(cuts[:-1], cuts[1:]):
