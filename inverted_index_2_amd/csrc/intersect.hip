@@ -696,37 +696,36 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         }
                         if (NFIX == 0u && bh - bl >= 16u) {       // many blocks in range: candidates mostly hit distinct ones
                         // Every live lane fetches the skip entries of ITS block at once (one round trip for the wave instead of
-                        // one per block), and the payload of the next distinct block is in flight while the current one is
-                        // decoded out of registers: a random HBM access costs ~2 us, a block decode a fraction of that.
+                        // one per block).  Then FOUR candidates' blocks per round, one per row of 16 lanes (round 4): a wave that
+                        // decodes one block at a time for one candidate is a chain of dependent fetch + decode steps - thirteen of
+                        // them per wave against the second-shortest list of BASELINE configs[4], two against each longer one -
+                        // and the tile's whole life is that chain.  A row walks its block 16 bytes per lane (any gap width) and
+                        // only looks for its candidate: nothing is written to LDS.
                         ii2_skip ea = {0u, 0u}, eb = {0u, 0u};
                         if (blk != NONE) { ea = L.skip[blk]; eb = L.skip[blk + 1u]; }
                         unsigned long long pending = __ballot(blk != NONE);
-                        GallopBlock cb, nb;
-                        cb.cur = NONE;
-                        if (pending) gallop_fetch(cb, L.payload, blk, ea, eb, __ffsll((long long)pending) - 1);
+                        const uint32_t rw = (uint32_t)l >> 4;
                         while (pending) {
-                            const unsigned long long rest = pending & ~__ballot(blk == cb.cur);
-                            nb.cur = NONE;
-                            if (rest) gallop_fetch(nb, L.payload, blk, ea, eb, __ffsll((long long)rest) - 1);
-                            const uint32_t cnt = decode_block_wave4(RegBytes5{cb.w[0], cb.w[1], cb.w[2], cb.w[3], cb.w[4], cb.q0}, cb.q0, cb.q1, cb.first,
-                                                                    [&](uint32_t ix, uint32_t id0, uint32_t id1, uint32_t id2, uint32_t id3, uint32_t mask) {
-                                                                        if (mask & 1u) { wbuf[ix] = id0; ix++; }
-                                                                        if (mask & 2u) { wbuf[ix] = id1; ix++; }
-                                                                        if (mask & 4u) { wbuf[ix] = id2; ix++; }
-                                                                        if (mask & 8u) { wbuf[ix] = id3; ix++; }
-                                                                    });
-                            __threadfence_block();
-                            if (blk == cb.cur) {
-                                uint32_t a = 0, e = cnt;
-                                while (a < e) {
-                                    const uint32_t mid = (a + e) >> 1;
-                                    if (wbuf[mid] < c) a = mid + 1u; else e = mid;
-                                }
-                                if (a < cnt && wbuf[a] == c) hit[pi] = (uint8_t)(j + 1u);
+                            int src[4];
+                            unsigned long long m = pending;
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; g4++) {
+                                src[g4] = m ? __ffsll((long long)m) - 1 : -1;
+                                if (m) m &= m - 1ull;
                             }
-                            __threadfence_block();
-                            pending = rest;
-                            cb = nb;
+                            const int sr = rw == 0u ? src[0] : rw == 1u ? src[1] : rw == 2u ? src[2] : src[3];
+                            const bool rowv = sr >= 0;
+                            const int ss = rowv ? sr : 0;
+                            const uint32_t rc = (uint32_t)__shfl((int)c, ss, 64);
+                            const uint32_t rq0 = (uint32_t)__shfl((int)ea.byte_off, ss, 64), rq1 = (uint32_t)__shfl((int)eb.byte_off, ss, 64);
+                            const uint32_t rf = (uint32_t)__shfl((int)ea.first_doc, ss, 64);
+                            bool found = false;
+                            decode_rows16_any(L.payload, rq0, rq1, rf, rowv, [&](uint32_t, uint32_t id) { found = found || id == rc; });
+                            const unsigned long long fm = __ballot(found);
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; g4++)
+                                if (l == src[g4] && ((fm >> (16 * g4)) & 0xFFFFull) != 0ull) hit[pi] = (uint8_t)(j + 1u);
+                            pending = m;
                         }
                         } else {       // the dense two-list instantiation keeps the plain loop: it sits at its register limit
                         unsigned long long pending = __ballot(blk != NONE);
