@@ -634,7 +634,13 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         if (pi < c0 || pi >= c1) hit[pi] = 0;
                     __syncthreads();
                 }
-                for (uint32_t j = 1; j < n; j++) {
+                // Split driver blocks with four or more lists (round 4): the second-shortest list is tested first, as before -
+                // it is what thins the candidates out - and then ALL the longer lists at once: every (surviving candidate,
+                // list) pair is one test, the tests of a tile share their rounds of dependent loads (block search, skip
+                // entries, payload) instead of taking them list after list.  A candidate that would have died at the third
+                // list is still tested against the others - a few wasted blocks against five fewer chains of round trips.
+                const bool combine = SUBT && NFIX == 0u && n >= 4u;
+                for (uint32_t j = 1; j < (combine ? 2u : n); j++) {
                     const ListView L = p.lists[j];
                     const uint32_t bl = D[2 + 4 * j], bh = D[3 + 4 * j];
                     // the first docs of the blocks in range go to LDS in one coalesced fetch: a candidate's binary search
@@ -749,6 +755,65 @@ __global__ __launch_bounds__(256, 5) void k_isect_tiles(IntersectParams p) {
                         }
                         }
                     }
+                    __syncthreads();
+                }
+                if (combine) {
+                    uint16_t *al = reinterpret_cast<uint16_t *>(fd);                  // surviving candidates (the staging area is free: nothing is staged here)
+                    uint32_t *okc = fd + 128u;                                        // per survivor: lists that hold it (a split driver block: <= 256 candidates)
+                    uint32_t *na_p = okc + 256u;
+                    static_assert(128u + 256u + 1u <= FDCAP, "survivor list + counters fit the staging area");
+                    if (tid == 0) *na_p = 0u;
+                    __syncthreads();
+                    for (uint32_t pi = (uint32_t)tid; pi < ncand; pi += 256u)
+                        if (hit[pi] == 2u) { const uint32_t z = atomicAdd(na_p, 1u); al[z] = (uint16_t)pi; okc[z] = 0u; }
+                    __syncthreads();
+                    const uint32_t na = *na_p, nl = n > 2u ? n - 2u : 1u, ntest = na * nl;
+                    const uint32_t rw = (uint32_t)l >> 4;
+                    for (uint32_t t0 = 0; t0 < ntest; t0 += 256u) {
+                        const uint32_t t = t0 + 4u * (uint32_t)l + (uint32_t)wv;           // dealt out to the four waves test by test: a handful of tests must not all land in one wave
+                        const bool tv = t < ntest;
+                        const uint32_t ai = tv ? t / nl : 0u, jj = 2u + (tv ? t % nl : 0u);
+                        const uint32_t c = tv ? cand[al[ai]] : 0u;
+                        const ii2_skip *__restrict__ sk = p.lists[jj].skip;
+                        const uint8_t *pay = p.lists[jj].payload;
+                        const uint32_t bl = D[2 + 4 * jj], bh = D[3 + 4 * jj];
+                        uint32_t blk = NONE;
+                        if (tv && bl < bh) {
+                            auto get = [&](uint32_t x) { return sk[x].first_doc; };
+                            const uint32_t ub = upper_bound_guess(get, bl, bh, c, D[0], D[1]);
+                            if (ub > bl) blk = ub - 1u;
+                        }
+                        ii2_skip ea = {0u, 0u}, eb = {0u, 0u};
+                        if (blk != NONE) { ea = sk[blk]; eb = sk[blk + 1u]; }
+                        const unsigned long long pay64 = (unsigned long long)(uintptr_t)pay;
+                        unsigned long long pending = __ballot(blk != NONE);
+                        while (pending) {
+                            int src[4];
+                            unsigned long long m = pending;
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; g4++) {
+                                src[g4] = m ? __ffsll((long long)m) - 1 : -1;
+                                if (m) m &= m - 1ull;
+                            }
+                            const int sr = rw == 0u ? src[0] : rw == 1u ? src[1] : rw == 2u ? src[2] : src[3];
+                            const bool rowv = sr >= 0;
+                            const int ss = rowv ? sr : 0;
+                            const uint32_t rc = (uint32_t)__shfl((int)c, ss, 64);
+                            const uint32_t rq0 = (uint32_t)__shfl((int)ea.byte_off, ss, 64), rq1 = (uint32_t)__shfl((int)eb.byte_off, ss, 64);
+                            const uint32_t rf = (uint32_t)__shfl((int)ea.first_doc, ss, 64);
+                            const uint8_t *rp = (const uint8_t *)(uintptr_t)(unsigned long long)__shfl((long long)pay64, ss, 64);
+                            bool found = false;
+                            decode_rows16_any(rp, rq0, rq1, rf, rowv, [&](uint32_t, uint32_t id) { found = found || id == rc; });
+                            const unsigned long long fm = __ballot(found);
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; g4++)
+                                if (l == src[g4] && ((fm >> (16 * g4)) & 0xFFFFull) != 0ull) atomicAdd(&okc[ai], 1u);
+                            pending = m;
+                        }
+                    }
+                    __syncthreads();
+                    for (uint32_t z = (uint32_t)tid; z < na; z += 256u)
+                        if (okc[z] == nl) hit[al[z]] = (uint8_t)n;
                     __syncthreads();
                 }
                 // finalise + count: wave w owns candidates [w*Q, (w+1)*Q)

@@ -177,3 +177,28 @@ def test_rare_term_against_long_lists(ctx, n_rare):
     rare = np.union1d(sorted_unique(rng, n_rare, U), rng.choice(np.intersect1d(long1, long2), min(n_rare, 40), replace=False)).astype(np.uint32)
     _check(ctx, [rare, long1])
     _check(ctx, [long2, rare, long1], removed=rare[::3].copy())
+
+
+@pytest.mark.parametrize("n_lists", [4, 6, 8])
+def test_rare_term_against_many_long_lists_all_at_once(ctx, n_lists):
+    """Four or more lists with a tiny sparse driver (split driver blocks): after the second-shortest list, every (surviving
+    candidate, longer list) pair is tested in ONE stage (intersect.hip, `combine`).  Built so that the stage has work that the
+    list-after-list form would have skipped: the second list holds every driver id (nothing is thinned out), the longer lists
+    each drop a different part of them, some ids survive everything, and one list is so short in the tile's range that a
+    candidate finds no block."""
+    rng = np.random.default_rng(900 + n_lists)
+    U = 60_000_000
+    rare = sorted_unique(rng, 1500, U)
+    second = np.union1d(rare, sorted_unique(rng, 20_000, U)).astype(np.uint32)             # a superset of the driver
+    longs = []
+    for i in range(n_lists - 2):
+        keep = rare[rng.random(rare.size) < 0.7]                                            # each longer list keeps ~70 % of the driver ...
+        keep = np.union1d(keep, rare[::5])                                                  # ... and all of them every fifth id
+        base = sorted_unique(rng, 300_000 * (i + 1), U) if i else _gap_list(rng, 1_500_000, [1, 5, 20, 60], [.25, .25, .25, .25])
+        longs.append(np.union1d(base, keep).astype(np.uint32))
+    longs[-1] = longs[-1][longs[-1] >= rare[40]]                                            # no block of this list before the 40th candidate
+    lists = [rare, second] + longs
+    _check(ctx, lists)
+    _check(ctx, lists[::-1], removed=rare[::15].copy())
+    got = orc.intersect(lists)
+    assert 100 < got.size < rare.size
