@@ -27,6 +27,8 @@ _typed = False
 
 _host = None
 HOST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libii2_host.so")
+# (sanitizer runs of the CPU-only file-layer tests load an instrumented build instead: make -C csrc host_asan / host_tsan)
+HOST_LIB_PATH = os.environ.get("II2_HOST_LIB", HOST_LIB_PATH)
 
 
 def _lib_typed():
