@@ -30,26 +30,6 @@ constexpr uint32_t ES_WG = 4u * ES_WAVE;                     // ids per workgrou
 constexpr uint32_t ES_STAGE = ES_WAVE * 5u + 32u;            // a wave's bytes at worst (five per id) + read-ahead of the copy-out
 constexpr uint32_t ES_WAVE_LDS = ((ES_STAGE > ES_WAVE * 4u ? ES_STAGE : ES_WAVE * 4u) + 15u) & ~15u;   // bytes: the stage, or (before it) one u32 per position
 
-// first index i in [0, n) with a[i] > x (a non-decreasing), searched 64 ways per round by the whole wave
-__device__ __forceinline__ uint64_t es_upper_bound(const uint64_t *__restrict__ a, uint64_t n, uint64_t x) {
-    const uint64_t l = (uint64_t)lane_id();
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-        const uint64_t sp = hi - lo;
-        const uint64_t st = (sp + 63u) >> 6;
-        const uint64_t pos = lo + l * st;
-        const bool in = pos < hi;
-        const uint64_t f = in ? a[pos] : 0ull;
-        const uint32_t cnt = (uint32_t)__popcll(__ballot(in && f <= x));     // probes ascend: the matches are a prefix
-        const uint32_t nin = (uint32_t)__popcll(__ballot(in));
-        if (st == 1u) return cnt < nin ? lo + cnt : hi;
-        const uint64_t nlo = cnt ? lo + (uint64_t)(cnt - 1u) * st + 1u : lo;
-        hi = cnt < nin ? lo + (uint64_t)cnt * st : hi;
-        lo = nlo;
-    }
-    return lo;
-}
-
 // inclusive prefix maximum over the 64 lanes of a wave (lanes without a source see 0)
 __device__ __forceinline__ uint32_t es_wave_incl_max(uint32_t x) {
     uint32_t y;
