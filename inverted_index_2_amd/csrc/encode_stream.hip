@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
         for (uint32_t i = 4u * (uint32_t)l; i < ES_WAVE; i += 256u) *reinterpret_cast<uint4 *>(&own[i]) = make_uint4(0, 0, 0, 0);
         l0 = p.part[(uint64_t)g * 4u + wv];
         const uint64_t P1 = P0 + nloc;
+        const uint64_t ls0 = p.post_off[l0];                    // where the list that holds P0 began (requested with the loop's first round)
         for (uint64_t i = (uint64_t)l;; i += 64u) {
             const uint64_t li = l0 + 1ull + i;
             const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
@@ -124,23 +125,24 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
             if (__ballot(!in) != 0ull) break;
         }
         prev0 = wave_shift_up1(v[ES_PER_LANE - 1u], before_wave);
-        // ---- the list my first id belongs to: the last list that started at or before it
+        // ---- the list my first id belongs to: the last list that started at or before it.  Where it started is where its mark
+        //      lies (no load: this is on the way to the publish every later workgroup waits for); which block it began with is
+        //      asked for now and needed after the wait
         {
             const uint4 *o4 = reinterpret_cast<const uint4 *>(&own[i0]);
             const uint4 a = o4[0], b = o4[1], c = o4[2], d = o4[3];
             ownv[0] = a.x; ownv[1] = a.y; ownv[2] = a.z; ownv[3] = a.w; ownv[4] = b.x; ownv[5] = b.y; ownv[6] = b.z; ownv[7] = b.w;
             ownv[8] = c.x; ownv[9] = c.y; ownv[10] = c.z; ownv[11] = c.w; ownv[12] = d.x; ownv[13] = d.y; ownv[14] = d.z; ownv[15] = d.w;
         }
-        uint32_t mx = 0;
+        uint32_t mp = 0;                          // 1 + wave position of the last list start among my ids
 #pragma unroll
-        for (uint32_t j = 0; j < ES_PER_LANE; j++) mx = ownv[j] > mx ? ownv[j] : mx;      // (list numbers ascend with the position)
-        const uint32_t incl = es_wave_incl_max(mx);
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) mp = ownv[j] ? i0 + j + 1u : mp;
+        const uint32_t incl = es_wave_incl_max(mp);
         uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
         if (l == 0) before = 0u;
-        my_list = before;
-        const uint64_t ls = p.post_off[l0 + my_list];
+        my_list = before ? own[before - 1u] : 0u;
         my_blk = p.blk_off[l0 + my_list];
-        my_pos = (uint32_t)(P0 + i0 - ls);               // (a list holds < 2^32 ids)
+        my_pos = before ? i0 - (before - 1u) : (uint32_t)(P0 + i0 - ls0);               // (a list holds < 2^32 ids)
         // ---- walk A: position in the list, block starts, gaps, varint lengths
         uint32_t pos = my_pos, pr = prev0;
 #pragma unroll
