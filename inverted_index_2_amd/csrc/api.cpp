@@ -383,8 +383,15 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
     ctx->lb_pending = 0;                           // (this call looks at its own result below)
     if (ctx->opt_encode_stream < 0) lb.spin = 0xFFFFFFFFu;      // tests: a wait runs out, the two-pass encoder takes over
     uint64_t *d_res = ctx->d_mail + 8;
+    unsigned long long *d_dbg = nullptr;
+    if (ctx->opt_debug_stamps == 3) {              // diagnostics: the encoder's cycle counters
+        if (!ctx->d_debug && ii2::dm_malloc_retry((void **)&ctx->d_debug, (size_t)2048 * 8 * sizeof(unsigned long long)) != hipSuccess)
+            return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_debug, 0, (size_t)2048 * 8 * sizeof(unsigned long long), st));
+        d_dbg = ctx->d_debug;
+    }
     HIP_TRY(ctx, launch_enc_stream(d_post_off, d_values, seg->d_blk_off, n_lists, n_postings, seg->d_skip, seg->d_payload, cap, seg->d_blk_list,
-                                   d_part, d_res, lb, st));
+                                   d_part, d_res, lb, d_dbg, st));
     HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_res, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

@@ -27,8 +27,14 @@ namespace ii2 {
 constexpr uint32_t ES_PER_LANE = 16;
 constexpr uint32_t ES_WAVE = 64u * ES_PER_LANE;              // ids per wave (1024)
 constexpr uint32_t ES_WG = 4u * ES_WAVE;                     // ids per workgroup
-constexpr uint32_t ES_STAGE = ES_WAVE * 5u + 32u;            // a wave's bytes at worst (five per id) + read-ahead of the copy-out
+// A wave's bytes at worst.  Ids ascend inside a list, so a list has at most 15 gaps of five bytes (>= 2^28) and a block's first id
+// takes none: the fullest 1024 ids are the 15-id tail of one list and 63 lists of 16 (4800 bytes), not 5 x 1024 - which is what
+// lets EIGHT workgroups share a CU's LDS instead of seven.  (Ids that do not ascend can exceed it: the wave then reports the same
+// failure as a payload that does not fit and the two-pass encoder, which has no stage, takes over.)
+constexpr uint32_t ES_STAGE_BYTES = 4864u;
+constexpr uint32_t ES_STAGE = ES_STAGE_BYTES + 32u;          // + read-ahead of the copy-out
 constexpr uint32_t ES_WAVE_LDS = ((ES_STAGE > ES_WAVE * 4u ? ES_STAGE : ES_WAVE * 4u) + 15u) & ~15u;   // bytes: the stage, or (before it) one u32 per position
+static_assert(4u * ES_WAVE_LDS + 64u <= 20480u, "eight workgroups per CU");
 
 // inclusive prefix maximum over the 64 lanes of a wave (lanes without a source see 0)
 __device__ __forceinline__ uint32_t es_wave_incl_max(uint32_t x) {
@@ -72,7 +78,36 @@ struct EncStreamParams {
     const uint32_t *part;        // [waves] list that holds every wave's first position (k_enc_partition)
     uint64_t *d_result;          // [0] payload bytes (all ones: a bounded wait ran out or the payload did not fit), [1] blocks
     LookBack lb;
+    unsigned long long *debug;   // optional per-workgroup cycle counters [2048][8] (option debug.stamps: diagnostics)
 };
+
+// sum of the eight 3-bit fields of x (each <= 5)
+__device__ __forceinline__ uint32_t es_sum3(uint32_t x) {
+    const uint32_t t = (x & 007070707u) + ((x >> 3) & 007070707u);      // four 6-bit fields, each <= 10
+    return ((t * 0x41041u) >> 18) & 63u;                                // field 3 of t x (1 + 2^6 + 2^12 + 2^18) = their sum (<= 40)
+}
+// bytes of the varints before id j (0..16) of a lane: lo / hi = 3 bits per id, ids 0-7 / 8-15
+__device__ __forceinline__ uint32_t es_bytes_before(uint32_t lo, uint32_t hi, uint32_t j) {
+    const uint32_t mlo = j >= 8u ? lo : lo & ((1u << (3u * j)) - 1u);
+    const uint32_t mhi = j >= 8u ? hi & ((1u << (3u * (j - 8u))) - 1u) : 0u;
+    return es_sum3(mlo) + es_sum3(mhi);
+}
+
+// list that holds output position pos: the last one that starts at or before it and is not empty.  `guess` is not after it
+// (post_off[guess] <= pos); exact unless empty lists lie between - then a doubling walk and a bisection.
+__device__ __forceinline__ uint64_t es_owner(const uint64_t *__restrict__ post_off, uint64_t n_lists, uint64_t guess, uint64_t pos) {
+    uint64_t lo = guess;
+    if (post_off[lo + 1u] > pos) return lo;
+    uint64_t step = 1u, hi = lo + 1u;                  // post_off[hi] <= pos so far
+    for (;;) {
+        lo = hi;
+        hi = lo + step < n_lists ? lo + step : n_lists;      // (post_off[n_lists] = n > pos)
+        if (post_off[hi] > pos) break;
+        step <<= 1;
+    }
+    while (hi - lo > 1u) { const uint64_t mid = lo + ((hi - lo) >> 1); if (post_off[mid] <= pos) lo = mid; else hi = mid; }
+    return lo;
+}
 
 __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
     __shared__ __align__(16) uint8_t lds[4][ES_WAVE_LDS];
@@ -85,19 +120,33 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
     const uint64_t P0 = ((uint64_t)g * 4u + wv) * ES_WAVE;           // my wave's first output position
     const bool work = P0 < p.n;                                       // wave-uniform
     const uint32_t nloc = work ? (uint32_t)(p.n - P0 < ES_WAVE ? p.n - P0 : ES_WAVE) : 0u;
-    uint32_t *own = reinterpret_cast<uint32_t *>(lds[wv]);
-    uint8_t *st = lds[wv];
+    uint32_t *lm = reinterpret_cast<uint32_t *>(lds[wv]);            // [64] bit j of word i: a list starts at the wave's position 16 i + j
+    uint8_t *st = lds[wv];                                           // (afterwards: the wave's bytes)
     if (threadIdx.x == 0) wg_err = 0u;
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+    const bool stamps = p.debug != nullptr;
+#define II2_STAMP(i)                                                    \
+    if (stamps) {                                                       \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memtime();    \
+        tacc[i] += tn_ - tprev;                                         \
+        tprev = tn_;                                                    \
+    }
+    if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
     uint32_t v[ES_PER_LANE];
     uint32_t prev0 = 0;                      // the id before my first one
     uint64_t l0 = 0;                         // list that holds position P0
+    uint32_t blk_l0 = 0;                     // ... and its first block
     uint32_t lens_lo = 0, lens_hi = 0;       // 3 bits per id: bytes of its varint (0: a block's first id)
-    uint32_t starts = 0;                     // bit j: my id j is a block's first
+    uint32_t L = 0;                          // bit j: a list starts at my id j
+    uint32_t cont = 0;                       // bit j: my id j starts a block inside a list (at most one)
+    uint32_t cont_first = 0;                 // ... that id
     uint32_t lane_bytes = 0;
-    uint32_t my_list = 0;                    // list of my first id (relative to l0) ...
-    uint32_t my_pos = 0, my_blk = 0;         // ... its position in that list, and the list's first block
-    uint32_t ownv[ES_PER_LANE];
+    uint32_t my_pos = 0;                     // position of my first id in its list
+    uint32_t starts_before = 0;              // lists that start in the wave's run before my first id
+    bool any_list_start = false;             // wave-uniform: a list starts inside the wave's run
     const uint32_t i0 = ES_PER_LANE * (uint32_t)l;
     if (work) {
         // ---- my 16 ids (guarded at the array's end) and the one before them
@@ -111,102 +160,134 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
             for (uint32_t j = 0; j < ES_PER_LANE; j++) v[j] = i0 + j < nloc ? p.values[P0 + i0 + j] : 0u;
         }
         const uint32_t before_wave = P0 ? p.values[P0 - 1u] : 0u;
-        // ---- lists: the one that holds P0, then every non-empty list that starts inside (P0, P0 + nloc)
-        for (uint32_t i = 4u * (uint32_t)l; i < ES_WAVE; i += 256u) *reinterpret_cast<uint4 *>(&own[i]) = make_uint4(0, 0, 0, 0);
+        lm[l] = 0u;
         l0 = p.part[(uint64_t)g * 4u + wv];
+        II2_STAMP(0)          // ids, the id before, the wave's first list
+        // ---- lists: the one that holds P0, then every non-empty list that starts inside (P0, P0 + nloc) leaves a bit at its
+        //      first position.  (Their skip entries and owners are written at the end, by the same lanes: walk C.)
         const uint64_t P1 = P0 + nloc;
         const uint64_t ls0 = p.post_off[l0];                    // where the list that holds P0 began (requested with the loop's first round)
+        blk_l0 = p.blk_off[l0];
         for (uint64_t i = (uint64_t)l;; i += 64u) {
             const uint64_t li = l0 + 1ull + i;
             const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
             const uint64_t s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;          // (both requested together)
             const bool in = s < P1;
-            if (in && s1 > s) own[(uint32_t)(s - P0)] = (uint32_t)(li - l0);      // (several empty lists may share s: the non-empty one owns it)
+            if (in && s1 > s) {                                  // (several empty lists may share s: the non-empty one owns it)
+                const uint32_t rel = (uint32_t)(s - P0);
+                atomicOr(&lm[rel >> 4], 1u << (rel & 15u));
+            }
             if (__ballot(!in) != 0ull) break;
         }
-        prev0 = wave_shift_up1(v[ES_PER_LANE - 1u], before_wave);
-        // ---- the list my first id belongs to: the last list that started at or before it.  Where it started is where its mark
-        //      lies (no load: this is on the way to the publish every later workgroup waits for); which block it began with is
-        //      asked for now and needed after the wait
-        {
-            const uint4 *o4 = reinterpret_cast<const uint4 *>(&own[i0]);
-            const uint4 a = o4[0], b = o4[1], c = o4[2], d = o4[3];
-            ownv[0] = a.x; ownv[1] = a.y; ownv[2] = a.z; ownv[3] = a.w; ownv[4] = b.x; ownv[5] = b.y; ownv[6] = b.z; ownv[7] = b.w;
-            ownv[8] = c.x; ownv[9] = c.y; ownv[10] = c.z; ownv[11] = c.w; ownv[12] = d.x; ownv[13] = d.y; ownv[14] = d.z; ownv[15] = d.w;
+        prev0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[ES_PER_LANE - 1u], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (l == 0) prev0 = before_wave;
+        // ---- where my first id stands in its list: behind the last list start before it, or behind the wave's first list's
+        L = lm[l];
+        any_list_start = __ballot(L != 0u) != 0ull;
+        const uint32_t valid = nloc == ES_WAVE ? 0xFFFFu : i0 >= nloc ? 0u : nloc - i0 >= 16u ? 0xFFFFu : (1u << (nloc - i0)) - 1u;
+        const uint32_t mp = L ? i0 + 32u - (uint32_t)__clz((int)L) : 0u;            // 1 + wave position of my last list start
+        uint32_t before = 0u;
+        if (any_list_start) {
+            const uint32_t incl = es_wave_incl_max(mp);
+            before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            if (l == 0) before = 0u;
+            const uint32_t nl = (uint32_t)__popc(L);
+            starts_before = wave_incl_scan(nl) - nl;
         }
-        uint32_t mp = 0;                          // 1 + wave position of the last list start among my ids
-#pragma unroll
-        for (uint32_t j = 0; j < ES_PER_LANE; j++) mp = ownv[j] ? i0 + j + 1u : mp;
-        const uint32_t incl = es_wave_incl_max(mp);
-        uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        if (l == 0) before = 0u;
-        my_list = before ? own[before - 1u] : 0u;
-        my_blk = p.blk_off[l0 + my_list];
-        my_pos = before ? i0 - (before - 1u) : (uint32_t)(P0 + i0 - ls0);               // (a list holds < 2^32 ids)
-        // ---- walk A: position in the list, block starts, gaps, varint lengths
-        uint32_t pos = my_pos, pr = prev0;
+        my_pos = before ? i0 - (before - 1u) : (uint32_t)(P0 + i0 - ls0);           // (a list holds < 2^32 ids)
+        // a block starts every 256 ids of a list: inside my 16 at most once, and only before my first list start
+        const uint32_t jc = (0u - my_pos) & 255u;
+        const uint32_t below_first = L ? (L & (0u - L)) - 1u : 0xFFFFu;
+        cont = (jc < 16u ? 1u << jc : 0u) & below_first & valid;
+        if (cont) cont_first = p.values[P0 + i0 + jc];           // (asked for now, needed after the wait)
+        const uint32_t keep = valid & ~(L | cont);               // ids that are written as a gap
+        II2_STAMP(1)          // list starts marked and read back
+        // ---- walk A: gaps and varint lengths
+        uint32_t pr = prev0;
 #pragma unroll
         for (uint32_t j = 0; j < ES_PER_LANE; j++) {
-            pos = ownv[j] ? 0u : pos;
-            const bool valid = i0 + j < nloc;
-            const bool start = (pos & 255u) == 0u;
-            const uint32_t len = (!valid || start) ? 0u : es_varint_len(v[j] - pr);
-            if (valid && start) starts |= 1u << j;
-            if (j < 8u) lens_lo |= len << (3u * j); else lens_hi |= len << (3u * (j - 8u));
-            lane_bytes += len;
+            const uint32_t gap = v[j] - pr;
             pr = v[j];
-            pos++;
+            const uint32_t len = es_varint_len(gap) & (uint32_t)__builtin_amdgcn_sbfe((int)keep, j, 1u);
+            if (j < 8u) lens_lo |= len << (3u * j); else lens_hi |= len << (3u * (j - 8u));
         }
+        lane_bytes = es_sum3(lens_lo) + es_sum3(lens_hi);
     }
+    II2_STAMP(2)              // walk A
     const uint32_t incl_b = wave_incl_scan(lane_bytes);
     const uint32_t wave_bytes = wave_bcast(incl_b, 63);
     const uint32_t lane_off = incl_b - lane_bytes;
     if (l == 0) wcnt[wv] = wave_bytes;
     lds_barrier();
+    II2_STAMP(3)              // the other waves' walk A
     const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
     const uint32_t total = c0 + c1 + c2 + c3;
     const uint32_t before_w = wv == 0u ? 0u : wv == 1u ? c0 : wv == 2u ? c0 + c1 : c0 + c1 + c2;
-    if (threadIdx.x == 0) lb_publish(p.lb, g, total);
+    const bool big = c0 > ES_STAGE_BYTES || c1 > ES_STAGE_BYTES || c2 > ES_STAGE_BYTES || c3 > ES_STAGE_BYTES;      // (only ids that do not ascend)
+    if (threadIdx.x == 0) {
+        if (big) {                                  // the failure first, and at the memory before the amount is on its way:
+            lb_fail(p.lb);                          // whoever sums my amount in also finds the error word set
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        lb_publish(p.lb, g, total);
+    }
     if (wv == 1u && lb_is_leader(g, gridDim.x)) {
         if (!lb_group_publish(p.lb, g, total) && l == 0) { wg_err = 1u; lb_fail(p.lb); }
     }
-    // ---- walk B: my varints into the wave's LDS stage (over the list numbers, which every lane has read by now)
-    if (work && wave_bytes != 0u) {
+    // ---- walk B: my varints into the wave's LDS stage (over the list-start bits, which every lane has read by now)
+    if (work && wave_bytes != 0u && !big) {
+        const uint32_t x = lens_lo | lens_hi;
         uint32_t q = lane_off;
         uint32_t pr = prev0;
+        if (__ballot((x & 066666666u) != 0u) == 0ull) {          // the usual wave: one byte per gap
 #pragma unroll
-        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
-            const uint32_t len = j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
-            uint32_t gap = v[j] - pr;
-            pr = v[j];
-            if (__ballot(len > 1u) == 0ull) {                // the usual step: one byte per gap
+            for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+                const uint32_t len = j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
+                const uint32_t gap = v[j] - pr;
+                pr = v[j];
                 if (len) st[q] = (uint8_t)gap;
                 q += len;
-            } else {
+            }
+        } else {
+            const bool four = __ballot((x & 044444444u) != 0u) != 0ull;                      // a varint of 4 or 5 bytes somewhere in the wave
+            const bool three = four || __ballot((x & (x >> 1) & 011111111u) != 0u) != 0ull;  // ... of 3
 #pragma unroll
-                for (uint32_t k = 0; k < 5u; k++) {
-                    if (k < len) st[q + k] = (uint8_t)((gap & 0x7Fu) | (k + 1u < len ? 0x80u : 0u));
-                    gap >>= 7;
+            for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+                const uint32_t len = j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
+                uint32_t gap = v[j] - pr;
+                pr = v[j];
+                if (len) st[q] = (uint8_t)((gap & 0x7Fu) | (len > 1u ? 0x80u : 0u));
+                if (len > 1u) st[q + 1u] = (uint8_t)(((gap >> 7) & 0x7Fu) | (len > 2u ? 0x80u : 0u));
+                if (three) {
+                    if (len > 2u) st[q + 2u] = (uint8_t)(((gap >> 14) & 0x7Fu) | (len > 3u ? 0x80u : 0u));
+                    if (four) {
+                        if (len > 3u) st[q + 3u] = (uint8_t)(((gap >> 21) & 0x7Fu) | (len > 4u ? 0x80u : 0u));
+                        if (len > 4u) st[q + 4u] = (uint8_t)(gap >> 28);
+                    }
                 }
                 q += len;
             }
         }
     }
+    II2_STAMP(4)              // publish, walk B
     // ---- where the workgroup's bytes begin
     if (wv == 0u) {
         unsigned long long pre = 0ull;
-        const bool ok = lb_prefix(p.lb, g, gridDim.x, total, &pre);
+        uint32_t polls = 0;
+        const bool ok = lb_prefix(p.lb, g, gridDim.x, total, &pre, stamps ? &polls : nullptr);
+        tacc[7] = polls;
         if (l == 0) {
             wg_off = ok ? pre : 0ull;
             if (!ok) { wg_err = 1u; lb_fail(p.lb); }
         }
     }
     lds_barrier();
+    II2_STAMP(5)              // the offset (wave 0: look-back; the others: waiting for it)
     const bool err = wg_err != 0u;
     const unsigned long long base = wg_off + before_w;           // global byte offset of my wave's first byte
     const bool fits = wg_off + total <= p.payload_cap;
     if (g == gridDim.x - 1u && threadIdx.x == 0) {              // the last workgroup: totals, the closing skip entry, the padding
-        const bool bad = err || lb_failed(p.lb) || !fits;
+        const bool bad = err || big || lb_failed(p.lb) || !fits;
         const unsigned long long nbytes = wg_off + total;
         p.d_result[0] = bad ? ~0ull : nbytes;
         const uint64_t nblk = p.blk_off[p.n_lists];
@@ -218,25 +299,7 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
             for (uint32_t k = 0; k < 16u; k++) p.payload[nbytes + k] = 0;
         }
     }
-    if (!work || err || !fits) return;
-    // ---- walk C: the skip entries and owners of the blocks whose first ids I hold
-    if (__ballot(starts != 0u) != 0ull) {
-        uint32_t pos = my_pos, lst = my_list, blk0 = my_blk, q = lane_off;
-#pragma unroll
-        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
-            if (ownv[j]) { blk0 += (pos + 255u) >> 8; pos = 0u; lst = ownv[j]; }      // the list before mine ends here: its blocks lie before my first
-            if ((starts >> j) & 1u) {
-                const uint32_t b = blk0 + (pos >> 8);
-                ii2_skip e;
-                e.first_doc = v[j];
-                e.byte_off = (uint32_t)(base + q);
-                p.skip[b] = e;
-                p.blk_list[b] = (uint32_t)(l0 + lst);
-            }
-            q += j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
-            pos++;
-        }
-    }
+    if (!work || err || !fits || big) return;
     // ---- the wave's bytes leave as aligned 16-byte stores (LDS reads at any byte offset: five words + alignbyte), ragged ends byte by byte
     if (wave_bytes != 0u) {
         uint8_t *dst = p.payload + base;
@@ -252,18 +315,66 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
         const uint32_t tail0 = head + body;
         if (tail0 + (uint32_t)l < wave_bytes) dst[tail0 + l] = st[tail0 + l];
     }
+    // ---- walk C, blocks that start inside a list: the lane that holds the first id knows everything but the list's number -
+    //      the wave's first list unless a list started before it in the wave's run (then: that many lists on, empty ones skipped)
+    if (cont) {
+        const uint32_t jc = (uint32_t)__builtin_ctz(cont);
+        const uint64_t pos = P0 + i0 + jc;
+        uint64_t lst = l0;
+        uint32_t b0 = blk_l0;
+        if (starts_before) {
+            lst = es_owner(p.post_off, p.n_lists, l0 + starts_before, pos);
+            b0 = p.blk_off[lst];
+        }
+        const uint32_t b = b0 + ((my_pos + jc) >> 8);
+        ii2_skip e;
+        e.first_doc = cont_first;
+        e.byte_off = (uint32_t)(base + lane_off + es_bytes_before(lens_lo, lens_hi, jc));
+        p.skip[b] = e;
+        p.blk_list[b] = (uint32_t)lst;
+    }
+    // ---- walk C, blocks that start a list: lane i takes list l0 + 1 + i again (as in the marking loop) - its first block is
+    //      blk_off[list], its first id values[post_off[list]], and the byte offset comes from the lane that holds that position
+    if (any_list_start) {
+        const uint64_t P1 = P0 + nloc;
+        for (uint64_t i = (uint64_t)l;; i += 64u) {
+            const uint64_t li = l0 + 1ull + i;
+            const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
+            const uint64_t s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;
+            const bool in = s < P1;
+            const bool mine = in && s1 > s;
+            const uint32_t rel = mine ? (uint32_t)(s - P0) : 0u;
+            const int src = (int)((rel >> 4) << 2);
+            const uint32_t o_off = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lane_off);      // (all lanes: the sources must be active)
+            const uint32_t o_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lens_lo);
+            const uint32_t o_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lens_hi);
+            if (mine) {
+                const uint32_t b = p.blk_off[li];
+                ii2_skip e;
+                e.first_doc = p.values[s];
+                e.byte_off = (uint32_t)(base + o_off + es_bytes_before(o_lo, o_hi, rel & 15u));
+                p.skip[b] = e;
+                p.blk_list[b] = (uint32_t)li;
+            }
+            if (__ballot(!in) != 0ull) break;
+        }
+    }
+    II2_STAMP(6)              // flush, skip entries
+    if (stamps && l == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&p.debug[(uint64_t)(blockIdx.x % 2048u) * 8u + i], tacc[i]);
+#undef II2_STAMP
 }
 
 hipError_t launch_enc_stream(const uint64_t *post_off, const uint32_t *values, const uint32_t *blk_off, uint64_t n_lists, uint64_t n,
                              ii2_skip *skip, uint8_t *payload, uint64_t payload_cap, uint32_t *blk_list, uint32_t *part, uint64_t *d_result,
-                             const LookBack &lb, hipStream_t s) {
+                             const LookBack &lb, unsigned long long *debug, hipStream_t s) {
     if (n == 0) return hipSuccess;
     const uint64_t waves = (n + ES_WAVE - 1u) / ES_WAVE;
     hipLaunchKernelGGL(k_enc_partition, dim3((unsigned)((waves + 255u) / 256u)), dim3(256), 0, s, post_off, n_lists, n, part);
     EncStreamParams p;
     p.part = part;
     p.post_off = post_off; p.values = values; p.blk_off = blk_off; p.n_lists = n_lists; p.n = n;
-    p.skip = skip; p.payload = payload; p.blk_list = blk_list; p.payload_cap = payload_cap; p.d_result = d_result; p.lb = lb;
+    p.skip = skip; p.payload = payload; p.blk_list = blk_list; p.payload_cap = payload_cap; p.d_result = d_result; p.lb = lb; p.debug = debug;
     const uint64_t grid = (n + ES_WG - 1u) / ES_WG;
     hipLaunchKernelGGL(k_enc_stream, dim3((unsigned)grid), dim3(256), 0, s, p);
     return hipGetLastError();

@@ -310,7 +310,7 @@ hipError_t launch_enc_write(const uint64_t *post_off, const uint32_t *blk_off, u
                             ii2_skip *skip, uint8_t *payload, uint64_t n_postings, uint32_t *blk_list, hipStream_t s);
 hipError_t launch_enc_stream(const uint64_t *post_off, const uint32_t *values, const uint32_t *blk_off, uint64_t n_lists, uint64_t n,
                              ii2_skip *skip, uint8_t *payload, uint64_t payload_cap, uint32_t *blk_list, uint32_t *part, uint64_t *d_result,
-                             const LookBack &lb, hipStream_t s);      // part: [4 * enc_stream_workgroups(n)] scratch
+                             const LookBack &lb, unsigned long long *debug, hipStream_t s);      // part: [4 * enc_stream_workgroups(n)] scratch
 uint64_t enc_stream_workgroups(uint64_t n);
 hipError_t launch_enc_list_meta(const uint64_t *post_off, const uint32_t *values, uint64_t n_lists, uint32_t *cnt, uint32_t *last_doc, hipStream_t s);
 hipError_t launch_dec_block_counts(const ii2_skip *skip, const uint8_t *payload, uint64_t n_blocks, uint32_t *counts, hipStream_t s);

@@ -76,7 +76,8 @@ __device__ __forceinline__ bool lb_group_publish(const LookBack &lb, uint32_t g,
 // is normally one or two groups back) - the first version read 64 + 2 x 64 records per poll and its polls alone were as much
 // traffic as the payload of k_enc_stream.
 constexpr uint32_t LB_WINDOW = 16;
-__device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32_t n_wg, unsigned long long own, unsigned long long *prefix) {
+__device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32_t n_wg, unsigned long long own, unsigned long long *prefix,
+                                          uint32_t *polls = nullptr) {
     const uint32_t l = (uint32_t)lane_id(), G = g / LB_GROUP, gi = g % LB_GROUP;
     const uint32_t limit = lb_limit(lb);
     if (lb.spin == 0xFFFFFFFFu && g == 1u) return false;
@@ -99,6 +100,7 @@ __device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32
         bool have_ga = !inr, have_gp = false;
         bool next = false;
         for (;;) {
+            if (polls) ++*polls;                // (diagnostics)
             if (!have_a) a = lb_ld(&lb.agg[(size_t)G * LB_GROUP + l]);
             if (!have_b) b = lb_ld(&lb.agg[(size_t)(G - 1u) * LB_GROUP + l]);
             if (inr && !have_gp) gp = lb_ld(&lb.grp[2 * (size_t)j + 1]);

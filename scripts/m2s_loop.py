@@ -6,7 +6,11 @@ import numpy as np
 from inverted_index_2_amd import Context, synth
 T, k, steps, check = 1_000_000, 16, 5, 0
 ctx = Context(0)
+want_stamps = False
 for kv in sys.argv[1:]:
+    if kv == "stamps":
+        want_stamps = True
+        continue
     key, v = kv.split("=")
     if key == "terms": T = int(v)
     elif key == "segments": k = int(v)
@@ -44,3 +48,17 @@ ctx.sync()
 seg_ms = (time.perf_counter() - t0) / steps * 1e3
 print("postings_in", n_in, "out", int(st.n_out), "raw merge ms", round(raw_ms, 3), "to segment ms", round(seg_ms, 3), "ratio", round(seg_ms / raw_ms, 3),
       "out bytes", int(info.n_bytes), "blocks", int(info.n_blocks), flush=True)
+if want_stamps:          # where an encoder wave's cycles go (option debug.stamps = 3)
+    import ctypes as C
+    ctx.set_option("debug.stamps", 3)
+    s3, _ = ctx.merge_to_segment(segs, tomb)
+    ctx.sync()
+    buf = (C.c_uint64 * (2048 * 8))()
+    ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, 2048 * 8))
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).sum(axis=0).astype(np.float64)
+    polls, a[7] = a[7], 0.0
+    names = ["first loads", "list starts", "walk A", "other waves", "publish + walk B", "offset", "skip entries + flush", "-"]
+    print("encoder cycles per phase (all waves): " + ", ".join(f"{n} {100 * x / a.sum():.1f}%" for n, x in zip(names, a) if x), flush=True)
+    print("cycles per wave:", a.sum() / (-(-int(st.n_out) // 1024)), "polls per look-back:", polls / (-(-int(st.n_out) // 4096)), flush=True)
+    s3.free()
+    ctx.set_option("debug.stamps", 0)
