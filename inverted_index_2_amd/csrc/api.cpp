@@ -371,7 +371,7 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
         return fail(ctx, II2_ENOMEM, "segment allocation failed");
     if (int rcm = seg_alloc_meta(ctx, seg.get())) return rcm;
     const size_t tmpb = scan_temp_bytes((size_t)n_lists + 1);
-    const size_t n_part = 4 * (size_t)enc_stream_workgroups(n_postings);
+    const size_t n_part = (size_t)((n_postings + 1023) / 1024) + 1;       // one word per 1024 output positions (k_enc_partition)
     if (int rcw = ii2_ws_reserve(ctx, align_up((n_lists + 1) * sizeof(uint32_t)) + align_up(tmpb) + align_up(n_part * sizeof(uint32_t)) + 4096)) return rcw;
     uint32_t *d_nblk = ws_take<uint32_t>(ctx, n_lists + 1);
     void *d_scan_tmp = ws_take<uint8_t>(ctx, tmpb);

@@ -26,7 +26,8 @@ namespace ii2 {
 
 constexpr uint32_t ES_PER_LANE = 16;
 constexpr uint32_t ES_WAVE = 64u * ES_PER_LANE;              // ids per wave (1024)
-constexpr uint32_t ES_WG = 4u * ES_WAVE;                     // ids per workgroup
+constexpr uint32_t ES_TILES = 2;                             // tiles (1024 consecutive ids) a wave encodes behind one wait
+constexpr uint32_t ES_WG = 4u * ES_TILES * ES_WAVE;          // ids per workgroup
 // A wave's bytes at worst.  Ids ascend inside a list, so a list has at most 15 gaps of five bytes (>= 2^28) and a block's first id
 // takes none: the fullest 1024 ids are the 15-id tail of one list and 63 lists of 16 (4800 bytes), not 5 x 1024 - which is what
 // lets EIGHT workgroups share a CU's LDS instead of seven.  (Ids that do not ascend can exceed it: the wave then reports the same
@@ -109,7 +110,224 @@ __device__ __forceinline__ uint64_t es_owner(const uint64_t *__restrict__ post_o
     return lo;
 }
 
-__global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
+// One tile = 1024 consecutive output positions, 16 per lane, as one wave holds it between its phases.
+struct EsTile {
+    uint32_t v[ES_PER_LANE];
+    uint64_t P0;                 // the tile's first output position
+    uint64_t l0;                 // list that holds it ...
+    uint32_t blk_l0;             // ... and that list's first block
+    uint32_t nloc;               // ids of the tile (0: past the end)
+    uint32_t prev0;              // the id before my first one
+    uint32_t lens_lo, lens_hi;   // 3 bits per id: bytes of its varint (0: a block's first id)
+    uint32_t L;                  // bit j: a list starts at my id j
+    uint32_t cont;               // bit j: my id j starts a block inside a list (at most one)
+    uint32_t cont_first;         // ... that id
+    uint32_t my_pos;             // position of my first id in its list
+    uint32_t starts_before;      // lists that start in the tile before my first id
+    uint32_t lane_bytes, lane_off, bytes;       // my bytes, the bytes of the lanes before me, the tile's
+    bool any_list_start;         // (wave-uniform) a list starts inside the tile
+};
+struct EsListLoads { uint64_t s, s1, ls0; };
+
+// my 16 ids (guarded at the array's end), the id before the tile, the tile's first list: all requested, nothing waited for
+__device__ __forceinline__ void es_tile_begin(const EncStreamParams &p, EsTile &T, uint64_t P0, uint32_t *lm) {
+    const uint32_t i0 = ES_PER_LANE * (uint32_t)lane_id();
+    T.P0 = P0;
+    T.nloc = P0 < p.n ? (uint32_t)(p.n - P0 < ES_WAVE ? p.n - P0 : ES_WAVE) : 0u;
+    T.lens_lo = T.lens_hi = T.L = T.cont = T.cont_first = T.my_pos = T.starts_before = T.lane_bytes = 0u;
+    T.any_list_start = false;
+    T.l0 = 0; T.blk_l0 = 0; T.prev0 = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < ES_PER_LANE; j++) T.v[j] = 0u;
+    if (T.nloc == 0u) return;
+    if (T.nloc == ES_WAVE) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.values + P0 + i0);
+        const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
+        T.v[0] = a.x; T.v[1] = a.y; T.v[2] = a.z; T.v[3] = a.w; T.v[4] = b.x; T.v[5] = b.y; T.v[6] = b.z; T.v[7] = b.w;
+        T.v[8] = c.x; T.v[9] = c.y; T.v[10] = c.z; T.v[11] = c.w; T.v[12] = d.x; T.v[13] = d.y; T.v[14] = d.z; T.v[15] = d.w;
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) T.v[j] = i0 + j < T.nloc ? p.values[P0 + i0 + j] : 0u;
+    }
+    T.prev0 = P0 ? p.values[P0 - 1u] : 0u;           // (lane 0's; the other lanes' comes from their neighbour)
+    lm[lane_id()] = 0u;
+    T.l0 = p.part[P0 / ES_WAVE];
+}
+// the first 64 lists behind the tile's first one (lane i: list l0 + 1 + i), and where that first one began
+__device__ __forceinline__ EsListLoads es_tile_lists_ask(const EncStreamParams &p, EsTile &T) {
+    EsListLoads r{~0ull, 0ull, 0ull};
+    if (T.nloc == 0u) return r;
+    const uint64_t li = T.l0 + 1ull + (uint64_t)lane_id();
+    r.s = li <= p.n_lists ? p.post_off[li] : ~0ull;
+    r.s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;
+    r.ls0 = p.post_off[T.l0];
+    T.blk_l0 = p.blk_off[T.l0];
+    return r;
+}
+// every non-empty list that starts inside the tile leaves a bit at its first position; from the bits: where my first id stands
+// in its list, the block starts among my ids, the varint lengths (walk A)
+__device__ __forceinline__ void es_tile_lists(const EncStreamParams &p, EsTile &T, const EsListLoads &r, uint32_t *lm) {
+    if (T.nloc == 0u) return;
+    const int l = lane_id();
+    const uint32_t i0 = ES_PER_LANE * (uint32_t)l;
+    const uint64_t P0 = T.P0, P1 = P0 + T.nloc;
+    {
+        uint64_t s = r.s, s1 = r.s1;
+        for (uint64_t i = (uint64_t)l;;) {
+            const bool in = s < P1;
+            if (in && s1 > s) {                                  // (several empty lists may share s: the non-empty one owns it)
+                const uint32_t rel = (uint32_t)(s - P0);
+                atomicOr(&lm[rel >> 4], 1u << (rel & 15u));
+            }
+            if (__ballot(!in) != 0ull) break;
+            i += 64u;
+            const uint64_t li = T.l0 + 1ull + i;
+            s = li <= p.n_lists ? p.post_off[li] : ~0ull;
+            s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;
+        }
+    }
+    const uint32_t before_wave = T.prev0;
+    T.prev0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)T.v[ES_PER_LANE - 1u], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    if (l == 0) T.prev0 = before_wave;
+    // ---- where my first id stands in its list: behind the last list start before it, or behind the tile's first list's
+    const uint32_t L = lm[l];
+    T.L = L;
+    T.any_list_start = __ballot(L != 0u) != 0ull;
+    const uint32_t nloc = T.nloc;
+    const uint32_t valid = nloc == ES_WAVE ? 0xFFFFu : i0 >= nloc ? 0u : nloc - i0 >= 16u ? 0xFFFFu : (1u << (nloc - i0)) - 1u;
+    const uint32_t mp = L ? i0 + 32u - (uint32_t)__clz((int)L) : 0u;            // 1 + tile position of my last list start
+    uint32_t before = 0u;
+    if (T.any_list_start) {
+        const uint32_t incl = es_wave_incl_max(mp);
+        before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (l == 0) before = 0u;
+        const uint32_t nl = (uint32_t)__popc(L);
+        T.starts_before = wave_incl_scan(nl) - nl;
+    }
+    T.my_pos = before ? i0 - (before - 1u) : (uint32_t)(P0 + i0 - r.ls0);       // (a list holds < 2^32 ids)
+    // a block starts every 256 ids of a list: inside my 16 at most once, and only before my first list start
+    const uint32_t jc = (0u - T.my_pos) & 255u;
+    const uint32_t below_first = L ? (L & (0u - L)) - 1u : 0xFFFFu;
+    T.cont = (jc < 16u ? 1u << jc : 0u) & below_first & valid;
+    if (T.cont) T.cont_first = p.values[P0 + i0 + jc];         // (asked for now, needed after the wait)
+    const uint32_t keep = valid & ~(L | T.cont);               // ids that are written as a gap
+    // ---- walk A: gaps and varint lengths
+    uint32_t pr = T.prev0;
+#pragma unroll
+    for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+        const uint32_t gap = T.v[j] - pr;
+        pr = T.v[j];
+        const uint32_t len = es_varint_len(gap) & (uint32_t)__builtin_amdgcn_sbfe((int)keep, j, 1u);
+        if (j < 8u) T.lens_lo |= len << (3u * j); else T.lens_hi |= len << (3u * (j - 8u));
+    }
+    T.lane_bytes = es_sum3(T.lens_lo) + es_sum3(T.lens_hi);
+}
+// walk B: my varints into the wave's LDS stage
+__device__ __forceinline__ void es_tile_stage(const EsTile &T, uint8_t *st) {
+    if (T.bytes == 0u) return;
+    const uint32_t x = T.lens_lo | T.lens_hi;
+    uint32_t q = T.lane_off;
+    uint32_t pr = T.prev0;
+    if (__ballot((x & 066666666u) != 0u) == 0ull) {          // the usual tile: one byte per gap
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+            const uint32_t len = j < 8u ? (T.lens_lo >> (3u * j)) & 7u : (T.lens_hi >> (3u * (j - 8u))) & 7u;
+            const uint32_t gap = T.v[j] - pr;
+            pr = T.v[j];
+            if (len) st[q] = (uint8_t)gap;
+            q += len;
+        }
+    } else {
+        const bool four = __ballot((x & 044444444u) != 0u) != 0ull;                      // a varint of 4 or 5 bytes somewhere in the tile
+        const bool three = four || __ballot((x & (x >> 1) & 011111111u) != 0u) != 0ull;  // ... of 3
+#pragma unroll
+        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
+            const uint32_t len = j < 8u ? (T.lens_lo >> (3u * j)) & 7u : (T.lens_hi >> (3u * (j - 8u))) & 7u;
+            const uint32_t gap = T.v[j] - pr;
+            pr = T.v[j];
+            if (len) st[q] = (uint8_t)((gap & 0x7Fu) | (len > 1u ? 0x80u : 0u));
+            if (len > 1u) st[q + 1u] = (uint8_t)(((gap >> 7) & 0x7Fu) | (len > 2u ? 0x80u : 0u));
+            if (three) {
+                if (len > 2u) st[q + 2u] = (uint8_t)(((gap >> 14) & 0x7Fu) | (len > 3u ? 0x80u : 0u));
+                if (four) {
+                    if (len > 3u) st[q + 3u] = (uint8_t)(((gap >> 21) & 0x7Fu) | (len > 4u ? 0x80u : 0u));
+                    if (len > 4u) st[q + 4u] = (uint8_t)(gap >> 28);
+                }
+            }
+            q += len;
+        }
+    }
+}
+// the tile's bytes leave as aligned 16-byte stores (LDS reads at any byte offset: five words + alignbyte), ragged ends byte by
+// byte; then the skip entries and owners of the blocks that start in the tile (walk C).  base = global byte offset of the tile
+__device__ __forceinline__ void es_tile_flush(const EncStreamParams &p, const EsTile &T, const uint8_t *st, unsigned long long base) {
+    if (T.nloc == 0u) return;
+    const int l = lane_id();
+    const uint32_t i0 = ES_PER_LANE * (uint32_t)l;
+    if (T.bytes != 0u) {
+        uint8_t *dst = p.payload + base;
+        const uint32_t mis = (uint32_t)((uintptr_t)dst & 15u);
+        const uint32_t head = mis ? (16u - mis < T.bytes ? 16u - mis : T.bytes) : 0u;      // bytes before the first aligned chunk
+        if ((uint32_t)l < head) dst[l] = st[l];
+        const uint32_t body = (T.bytes - head) & ~15u;
+        const LdsBytes16 src{st};
+        for (uint32_t o = 16u * (uint32_t)l; o < body; o += 1024u) {
+            const uint4 w = src(head + o);
+            *reinterpret_cast<uint4 *>(dst + head + o) = w;
+        }
+        const uint32_t tail0 = head + body;
+        if (tail0 + (uint32_t)l < T.bytes) dst[tail0 + l] = st[tail0 + l];
+    }
+    // ---- blocks that start inside a list: the lane that holds the first id knows everything but the list's number - the
+    //      tile's first list unless a list started before it in the tile (then: that many lists on, empty ones skipped)
+    if (T.cont) {
+        const uint32_t jc = (uint32_t)__builtin_ctz(T.cont);
+        const uint64_t pos = T.P0 + i0 + jc;
+        uint64_t lst = T.l0;
+        uint32_t b0 = T.blk_l0;
+        if (T.starts_before) {
+            lst = es_owner(p.post_off, p.n_lists, T.l0 + T.starts_before, pos);
+            b0 = p.blk_off[lst];
+        }
+        const uint32_t b = b0 + ((T.my_pos + jc) >> 8);
+        ii2_skip e;
+        e.first_doc = T.cont_first;
+        e.byte_off = (uint32_t)(base + T.lane_off + es_bytes_before(T.lens_lo, T.lens_hi, jc));
+        p.skip[b] = e;
+        p.blk_list[b] = (uint32_t)lst;
+    }
+    // ---- blocks that start a list: lane i takes list l0 + 1 + i again (as in the marking loop) - its first block is
+    //      blk_off[list], its first id values[post_off[list]], and the byte offset comes from the lane that holds that position
+    if (T.any_list_start) {
+        const uint64_t P1 = T.P0 + T.nloc;
+        for (uint64_t i = (uint64_t)l;; i += 64u) {
+            const uint64_t li = T.l0 + 1ull + i;
+            const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
+            const uint64_t s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;
+            const bool in = s < P1;
+            const bool mine = in && s1 > s;
+            const uint32_t rel = mine ? (uint32_t)(s - T.P0) : 0u;
+            const int src = (int)((rel >> 4) << 2);
+            const uint32_t o_off = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)T.lane_off);      // (all lanes: the sources must be active)
+            const uint32_t o_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)T.lens_lo);
+            const uint32_t o_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)T.lens_hi);
+            if (mine) {
+                const uint32_t b = p.blk_off[li];
+                ii2_skip e;
+                e.first_doc = p.values[s];
+                e.byte_off = (uint32_t)(base + o_off + es_bytes_before(o_lo, o_hi, rel & 15u));
+                p.skip[b] = e;
+                p.blk_list[b] = (uint32_t)li;
+            }
+            if (__ballot(!in) != 0ull) break;
+        }
+    }
+}
+
+// A wave encodes TWO consecutive tiles behind ONE wait: what a workgroup waits for is the slowest of the few hundred workgroups
+// started just before it (their loads, not their arithmetic - ~4 polls of 1.5 us with one tile per wave), and the second tile's
+// bytes need no second wait.  The stage is used by the tiles one after the other.
+template <bool STAMPS> __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
     __shared__ __align__(16) uint8_t lds[4][ES_WAVE_LDS];
     __shared__ uint32_t wcnt[4];
     __shared__ unsigned long long wg_off;
@@ -117,15 +335,13 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
     const int l = lane_id();
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t g = blockIdx.x;
-    const uint64_t P0 = ((uint64_t)g * 4u + wv) * ES_WAVE;           // my wave's first output position
-    const bool work = P0 < p.n;                                       // wave-uniform
-    const uint32_t nloc = work ? (uint32_t)(p.n - P0 < ES_WAVE ? p.n - P0 : ES_WAVE) : 0u;
-    uint32_t *lm = reinterpret_cast<uint32_t *>(lds[wv]);            // [64] bit j of word i: a list starts at the wave's position 16 i + j
-    uint8_t *st = lds[wv];                                           // (afterwards: the wave's bytes)
+    const uint64_t P0 = ((uint64_t)g * 4u + wv) * (ES_TILES * ES_WAVE);           // my wave's first output position
+    uint32_t *lm = reinterpret_cast<uint32_t *>(lds[wv]);            // [2][64] bit j of word i: a list starts at the tile's position 16 i + j
+    uint8_t *st = lds[wv];                                           // (afterwards: a tile's bytes)
     if (threadIdx.x == 0) wg_err = 0u;
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = 0;
-    const bool stamps = p.debug != nullptr;
+    const bool stamps = STAMPS && p.debug != nullptr;
 #define II2_STAMP(i)                                                    \
     if (stamps) {                                                       \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
@@ -135,95 +351,29 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
     }
     if (stamps) tprev = __builtin_amdgcn_s_memtime();
 
-    uint32_t v[ES_PER_LANE];
-    uint32_t prev0 = 0;                      // the id before my first one
-    uint64_t l0 = 0;                         // list that holds position P0
-    uint32_t blk_l0 = 0;                     // ... and its first block
-    uint32_t lens_lo = 0, lens_hi = 0;       // 3 bits per id: bytes of its varint (0: a block's first id)
-    uint32_t L = 0;                          // bit j: a list starts at my id j
-    uint32_t cont = 0;                       // bit j: my id j starts a block inside a list (at most one)
-    uint32_t cont_first = 0;                 // ... that id
-    uint32_t lane_bytes = 0;
-    uint32_t my_pos = 0;                     // position of my first id in its list
-    uint32_t starts_before = 0;              // lists that start in the wave's run before my first id
-    bool any_list_start = false;             // wave-uniform: a list starts inside the wave's run
-    const uint32_t i0 = ES_PER_LANE * (uint32_t)l;
-    if (work) {
-        // ---- my 16 ids (guarded at the array's end) and the one before them
-        if (nloc == ES_WAVE) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(p.values + P0 + i0);
-            const uint4 a = src[0], b = src[1], c = src[2], d = src[3];
-            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w; v[12] = d.x; v[13] = d.y; v[14] = d.z; v[15] = d.w;
-        } else {
-#pragma unroll
-            for (uint32_t j = 0; j < ES_PER_LANE; j++) v[j] = i0 + j < nloc ? p.values[P0 + i0 + j] : 0u;
-        }
-        const uint32_t before_wave = P0 ? p.values[P0 - 1u] : 0u;
-        lm[l] = 0u;
-        l0 = p.part[(uint64_t)g * 4u + wv];
-        II2_STAMP(0)          // ids, the id before, the wave's first list
-        // ---- lists: the one that holds P0, then every non-empty list that starts inside (P0, P0 + nloc) leaves a bit at its
-        //      first position.  (Their skip entries and owners are written at the end, by the same lanes: walk C.)
-        const uint64_t P1 = P0 + nloc;
-        const uint64_t ls0 = p.post_off[l0];                    // where the list that holds P0 began (requested with the loop's first round)
-        blk_l0 = p.blk_off[l0];
-        for (uint64_t i = (uint64_t)l;; i += 64u) {
-            const uint64_t li = l0 + 1ull + i;
-            const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
-            const uint64_t s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;          // (both requested together)
-            const bool in = s < P1;
-            if (in && s1 > s) {                                  // (several empty lists may share s: the non-empty one owns it)
-                const uint32_t rel = (uint32_t)(s - P0);
-                atomicOr(&lm[rel >> 4], 1u << (rel & 15u));
-            }
-            if (__ballot(!in) != 0ull) break;
-        }
-        prev0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[ES_PER_LANE - 1u], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        if (l == 0) prev0 = before_wave;
-        // ---- where my first id stands in its list: behind the last list start before it, or behind the wave's first list's
-        L = lm[l];
-        any_list_start = __ballot(L != 0u) != 0ull;
-        const uint32_t valid = nloc == ES_WAVE ? 0xFFFFu : i0 >= nloc ? 0u : nloc - i0 >= 16u ? 0xFFFFu : (1u << (nloc - i0)) - 1u;
-        const uint32_t mp = L ? i0 + 32u - (uint32_t)__clz((int)L) : 0u;            // 1 + wave position of my last list start
-        uint32_t before = 0u;
-        if (any_list_start) {
-            const uint32_t incl = es_wave_incl_max(mp);
-            before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            if (l == 0) before = 0u;
-            const uint32_t nl = (uint32_t)__popc(L);
-            starts_before = wave_incl_scan(nl) - nl;
-        }
-        my_pos = before ? i0 - (before - 1u) : (uint32_t)(P0 + i0 - ls0);           // (a list holds < 2^32 ids)
-        // a block starts every 256 ids of a list: inside my 16 at most once, and only before my first list start
-        const uint32_t jc = (0u - my_pos) & 255u;
-        const uint32_t below_first = L ? (L & (0u - L)) - 1u : 0xFFFFu;
-        cont = (jc < 16u ? 1u << jc : 0u) & below_first & valid;
-        if (cont) cont_first = p.values[P0 + i0 + jc];           // (asked for now, needed after the wait)
-        const uint32_t keep = valid & ~(L | cont);               // ids that are written as a gap
-        II2_STAMP(1)          // list starts marked and read back
-        // ---- walk A: gaps and varint lengths
-        uint32_t pr = prev0;
-#pragma unroll
-        for (uint32_t j = 0; j < ES_PER_LANE; j++) {
-            const uint32_t gap = v[j] - pr;
-            pr = v[j];
-            const uint32_t len = es_varint_len(gap) & (uint32_t)__builtin_amdgcn_sbfe((int)keep, j, 1u);
-            if (j < 8u) lens_lo |= len << (3u * j); else lens_hi |= len << (3u * (j - 8u));
-        }
-        lane_bytes = es_sum3(lens_lo) + es_sum3(lens_hi);
+    EsTile A, B;
+    es_tile_begin(p, A, P0, lm);
+    es_tile_begin(p, B, P0 + ES_WAVE, lm + 64);
+    II2_STAMP(0)              // ids, the ids before, the tiles' first lists
+    const EsListLoads ra = es_tile_lists_ask(p, A);
+    const EsListLoads rb = es_tile_lists_ask(p, B);
+    es_tile_lists(p, A, ra, lm);
+    es_tile_lists(p, B, rb, lm + 64);
+    II2_STAMP(1)              // list starts, walk A
+    {
+        const uint32_t ia = wave_incl_scan(A.lane_bytes), ib = wave_incl_scan(B.lane_bytes);
+        A.bytes = wave_bcast(ia, 63); B.bytes = wave_bcast(ib, 63);
+        A.lane_off = ia - A.lane_bytes; B.lane_off = ib - B.lane_bytes;
     }
-    II2_STAMP(2)              // walk A
-    const uint32_t incl_b = wave_incl_scan(lane_bytes);
-    const uint32_t wave_bytes = wave_bcast(incl_b, 63);
-    const uint32_t lane_off = incl_b - lane_bytes;
-    if (l == 0) wcnt[wv] = wave_bytes;
+    const bool wave_big = A.bytes > ES_STAGE_BYTES || B.bytes > ES_STAGE_BYTES;           // (only ids that do not ascend)
+    if (l == 0) wcnt[wv] = (A.bytes + B.bytes) | (wave_big ? 0x80000000u : 0u);
     lds_barrier();
-    II2_STAMP(3)              // the other waves' walk A
-    const uint32_t c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+    II2_STAMP(3)              // the other waves
+    const uint32_t r0 = wcnt[0], r1 = wcnt[1], r2 = wcnt[2], r3 = wcnt[3];
+    const uint32_t c0 = r0 & 0x7FFFFFFFu, c1 = r1 & 0x7FFFFFFFu, c2 = r2 & 0x7FFFFFFFu, c3 = r3 & 0x7FFFFFFFu;
     const uint32_t total = c0 + c1 + c2 + c3;
     const uint32_t before_w = wv == 0u ? 0u : wv == 1u ? c0 : wv == 2u ? c0 + c1 : c0 + c1 + c2;
-    const bool big = c0 > ES_STAGE_BYTES || c1 > ES_STAGE_BYTES || c2 > ES_STAGE_BYTES || c3 > ES_STAGE_BYTES;      // (only ids that do not ascend)
+    const bool big = ((r0 | r1 | r2 | r3) & 0x80000000u) != 0u;
     if (threadIdx.x == 0) {
         if (big) {                                  // the failure first, and at the memory before the amount is on its way:
             lb_fail(p.lb);                          // whoever sums my amount in also finds the error word set
@@ -234,47 +384,13 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
     if (wv == 1u && lb_is_leader(g, gridDim.x)) {
         if (!lb_group_publish(p.lb, g, total) && l == 0) { wg_err = 1u; lb_fail(p.lb); }
     }
-    // ---- walk B: my varints into the wave's LDS stage (over the list-start bits, which every lane has read by now)
-    if (work && wave_bytes != 0u && !big) {
-        const uint32_t x = lens_lo | lens_hi;
-        uint32_t q = lane_off;
-        uint32_t pr = prev0;
-        if (__ballot((x & 066666666u) != 0u) == 0ull) {          // the usual wave: one byte per gap
-#pragma unroll
-            for (uint32_t j = 0; j < ES_PER_LANE; j++) {
-                const uint32_t len = j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
-                const uint32_t gap = v[j] - pr;
-                pr = v[j];
-                if (len) st[q] = (uint8_t)gap;
-                q += len;
-            }
-        } else {
-            const bool four = __ballot((x & 044444444u) != 0u) != 0ull;                      // a varint of 4 or 5 bytes somewhere in the wave
-            const bool three = four || __ballot((x & (x >> 1) & 011111111u) != 0u) != 0ull;  // ... of 3
-#pragma unroll
-            for (uint32_t j = 0; j < ES_PER_LANE; j++) {
-                const uint32_t len = j < 8u ? (lens_lo >> (3u * j)) & 7u : (lens_hi >> (3u * (j - 8u))) & 7u;
-                uint32_t gap = v[j] - pr;
-                pr = v[j];
-                if (len) st[q] = (uint8_t)((gap & 0x7Fu) | (len > 1u ? 0x80u : 0u));
-                if (len > 1u) st[q + 1u] = (uint8_t)(((gap >> 7) & 0x7Fu) | (len > 2u ? 0x80u : 0u));
-                if (three) {
-                    if (len > 2u) st[q + 2u] = (uint8_t)(((gap >> 14) & 0x7Fu) | (len > 3u ? 0x80u : 0u));
-                    if (four) {
-                        if (len > 3u) st[q + 3u] = (uint8_t)(((gap >> 21) & 0x7Fu) | (len > 4u ? 0x80u : 0u));
-                        if (len > 4u) st[q + 4u] = (uint8_t)(gap >> 28);
-                    }
-                }
-                q += len;
-            }
-        }
-    }
-    II2_STAMP(4)              // publish, walk B
+    if (!big) es_tile_stage(A, st);
+    II2_STAMP(4)              // publish, walk B of the first tile
     // ---- where the workgroup's bytes begin
     if (wv == 0u) {
         unsigned long long pre = 0ull;
         uint32_t polls = 0;
-        const bool ok = lb_prefix(p.lb, g, gridDim.x, total, &pre, stamps ? &polls : nullptr);
+        const bool ok = STAMPS ? lb_prefix(p.lb, g, gridDim.x, total, &pre, &polls) : lb_prefix(p.lb, g, gridDim.x, total, &pre);
         tacc[7] = polls;
         if (l == 0) {
             wg_off = ok ? pre : 0ull;
@@ -299,67 +415,12 @@ __global__ __launch_bounds__(256) void k_enc_stream(EncStreamParams p) {
             for (uint32_t k = 0; k < 16u; k++) p.payload[nbytes + k] = 0;
         }
     }
-    if (!work || err || !fits || big) return;
-    // ---- the wave's bytes leave as aligned 16-byte stores (LDS reads at any byte offset: five words + alignbyte), ragged ends byte by byte
-    if (wave_bytes != 0u) {
-        uint8_t *dst = p.payload + base;
-        const uint32_t mis = (uint32_t)((uintptr_t)dst & 15u);
-        const uint32_t head = mis ? (16u - mis < wave_bytes ? 16u - mis : wave_bytes) : 0u;      // bytes before the first aligned chunk
-        if ((uint32_t)l < head) dst[l] = st[l];
-        const uint32_t body = (wave_bytes - head) & ~15u;
-        const LdsBytes16 src{st};
-        for (uint32_t o = 16u * (uint32_t)l; o < body; o += 1024u) {
-            const uint4 w = src(head + o);
-            *reinterpret_cast<uint4 *>(dst + head + o) = w;
-        }
-        const uint32_t tail0 = head + body;
-        if (tail0 + (uint32_t)l < wave_bytes) dst[tail0 + l] = st[tail0 + l];
-    }
-    // ---- walk C, blocks that start inside a list: the lane that holds the first id knows everything but the list's number -
-    //      the wave's first list unless a list started before it in the wave's run (then: that many lists on, empty ones skipped)
-    if (cont) {
-        const uint32_t jc = (uint32_t)__builtin_ctz(cont);
-        const uint64_t pos = P0 + i0 + jc;
-        uint64_t lst = l0;
-        uint32_t b0 = blk_l0;
-        if (starts_before) {
-            lst = es_owner(p.post_off, p.n_lists, l0 + starts_before, pos);
-            b0 = p.blk_off[lst];
-        }
-        const uint32_t b = b0 + ((my_pos + jc) >> 8);
-        ii2_skip e;
-        e.first_doc = cont_first;
-        e.byte_off = (uint32_t)(base + lane_off + es_bytes_before(lens_lo, lens_hi, jc));
-        p.skip[b] = e;
-        p.blk_list[b] = (uint32_t)lst;
-    }
-    // ---- walk C, blocks that start a list: lane i takes list l0 + 1 + i again (as in the marking loop) - its first block is
-    //      blk_off[list], its first id values[post_off[list]], and the byte offset comes from the lane that holds that position
-    if (any_list_start) {
-        const uint64_t P1 = P0 + nloc;
-        for (uint64_t i = (uint64_t)l;; i += 64u) {
-            const uint64_t li = l0 + 1ull + i;
-            const uint64_t s = li <= p.n_lists ? p.post_off[li] : ~0ull;
-            const uint64_t s1 = li < p.n_lists ? p.post_off[li + 1ull] : 0ull;
-            const bool in = s < P1;
-            const bool mine = in && s1 > s;
-            const uint32_t rel = mine ? (uint32_t)(s - P0) : 0u;
-            const int src = (int)((rel >> 4) << 2);
-            const uint32_t o_off = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lane_off);      // (all lanes: the sources must be active)
-            const uint32_t o_lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lens_lo);
-            const uint32_t o_hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)lens_hi);
-            if (mine) {
-                const uint32_t b = p.blk_off[li];
-                ii2_skip e;
-                e.first_doc = p.values[s];
-                e.byte_off = (uint32_t)(base + o_off + es_bytes_before(o_lo, o_hi, rel & 15u));
-                p.skip[b] = e;
-                p.blk_list[b] = (uint32_t)li;
-            }
-            if (__ballot(!in) != 0ull) break;
-        }
-    }
-    II2_STAMP(6)              // flush, skip entries
+    if (A.nloc == 0u || err || !fits || big) return;
+    es_tile_flush(p, A, st, base);
+    II2_STAMP(6)              // first tile: flush, skip entries
+    es_tile_stage(B, st);
+    es_tile_flush(p, B, st, base + A.bytes);
+    II2_STAMP(2)              // second tile: walk B, flush, skip entries
     if (stamps && l == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&p.debug[(uint64_t)(blockIdx.x % 2048u) * 8u + i], tacc[i]);
 #undef II2_STAMP
@@ -376,7 +437,8 @@ hipError_t launch_enc_stream(const uint64_t *post_off, const uint32_t *values, c
     p.post_off = post_off; p.values = values; p.blk_off = blk_off; p.n_lists = n_lists; p.n = n;
     p.skip = skip; p.payload = payload; p.blk_list = blk_list; p.payload_cap = payload_cap; p.d_result = d_result; p.lb = lb; p.debug = debug;
     const uint64_t grid = (n + ES_WG - 1u) / ES_WG;
-    hipLaunchKernelGGL(k_enc_stream, dim3((unsigned)grid), dim3(256), 0, s, p);
+    if (debug) hipLaunchKernelGGL(k_enc_stream<true>, dim3((unsigned)grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(k_enc_stream<false>, dim3((unsigned)grid), dim3(256), 0, s, p);
     return hipGetLastError();
 }
 uint64_t enc_stream_workgroups(uint64_t n) { return (n + ES_WG - 1u) / ES_WG; }
