@@ -72,10 +72,10 @@ __device__ __forceinline__ bool lb_group_publish(const LookBack &lb, uint32_t g,
 // ONE WAVE (all 64 lanes) of workgroup g: the amounts of all workgroups before g.  A group's last workgroup also publishes the
 // group's inclusive prefix (`own` = its own amount).  Returns false when a wait ran out.
 // Polls are uncached loads, one fabric transaction each, and a launch may have hundreds of thousands of workgroups: a record
-// that has been seen ready is not read again, and the groups are looked at 16 at a time (the nearest one that carries a prefix
+// that has been seen ready is not read again, and the groups are looked at 32 at a time (the nearest one that carries a prefix
 // is normally one or two groups back) - the first version read 64 + 2 x 64 records per poll and its polls alone were as much
 // traffic as the payload of k_enc_stream.
-constexpr uint32_t LB_WINDOW = 16;
+constexpr uint32_t LB_WINDOW = 32;
 __device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32_t n_wg, unsigned long long own, unsigned long long *prefix,
                                           uint32_t *polls = nullptr) {
     const uint32_t l = (uint32_t)lane_id(), G = g / LB_GROUP, gi = g % LB_GROUP;
