@@ -390,8 +390,9 @@ template <bool STAMPS> __global__ __launch_bounds__(256) void k_enc_stream(EncSt
     if (wv == 0u) {
         unsigned long long pre = 0ull;
         uint32_t polls = 0;
-        const bool ok = STAMPS ? lb_prefix(p.lb, g, gridDim.x, total, &pre, &polls) : lb_prefix(p.lb, g, gridDim.x, total, &pre);
-        tacc[7] = polls;
+        uint32_t pm = 0;
+        const bool ok = STAMPS ? lb_prefix(p.lb, g, gridDim.x, total, &pre, &polls, &pm) : lb_prefix(p.lb, g, gridDim.x, total, &pre);
+        tacc[7] = polls | ((unsigned long long)pm << 32);
         if (l == 0) {
             wg_off = ok ? pre : 0ull;
             if (!ok) { wg_err = 1u; lb_fail(p.lb); }

@@ -77,7 +77,7 @@ __device__ __forceinline__ bool lb_group_publish(const LookBack &lb, uint32_t g,
 // traffic as the payload of k_enc_stream.
 constexpr uint32_t LB_WINDOW = 32;
 __device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32_t n_wg, unsigned long long own, unsigned long long *prefix,
-                                          uint32_t *polls = nullptr) {
+                                          uint32_t *polls = nullptr, uint32_t *polls_members = nullptr) {
     const uint32_t l = (uint32_t)lane_id(), G = g / LB_GROUP, gi = g % LB_GROUP;
     const uint32_t limit = lb_limit(lb);
     if (lb.spin == 0xFFFFFFFFu && g == 1u) return false;
@@ -110,6 +110,7 @@ __device__ __forceinline__ bool lb_prefix(const LookBack &lb, uint32_t g, uint32
             have_gp = inr && (have_gp || lb_ready(lb, gp));
             have_ga = have_ga || lb_ready(lb, ga);
             const bool mem_ok = __ballot(!have_a || !have_b) == 0ull;
+            if (polls_members && !mem_ok) ++*polls_members;      // (diagnostics)
             if (!groups_done) {
                 const unsigned long long gav = __ballot(have_ga);
                 const unsigned long long gpv = __ballot(have_gp);

@@ -55,10 +55,11 @@ if want_stamps:          # where an encoder wave's cycles go (option debug.stamp
     ctx.sync()
     buf = (C.c_uint64 * (2048 * 8))()
     ctx._ck(ctx.lib.ii2_debug_read(ctx.h, buf, 2048 * 8))
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).sum(axis=0).astype(np.float64)
-    polls, a[7] = a[7], 0.0
+    raw = np.frombuffer(buf, dtype=np.uint64).reshape(2048, 8).sum(axis=0)
+    a = raw.astype(np.float64)
+    polls, pm, a[7] = float(int(raw[7]) & 0xFFFFFFFF), float(int(raw[7]) >> 32), 0.0
     names = ["first loads", "list starts", "walk A", "other waves", "publish + walk B", "offset", "skip entries + flush", "-"]
     print("encoder cycles per phase (all waves): " + ", ".join(f"{n} {100 * x / a.sum():.1f}%" for n, x in zip(names, a) if x), flush=True)
-    print("cycles per wave:", a.sum() / (-(-int(st.n_out) // 1024)), "polls per look-back:", polls / (-(-int(st.n_out) // 4096)), flush=True)
+    print("cycles per wave:", a.sum() / (-(-int(st.n_out) // 1024)), "polls per look-back:", polls / (-(-int(st.n_out) // 8192)), "of them with a member's amount missing:", pm / (-(-int(st.n_out) // 8192)), flush=True)
     s3.free()
     ctx.set_option("debug.stamps", 0)
