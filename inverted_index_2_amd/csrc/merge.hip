@@ -247,6 +247,13 @@ __device__ __forceinline__ uint2 blocks_of_range(const ii2_skip *__restrict__ sk
 // range tile holds less than one block per list: decoding the straddling blocks whole was more than half of its decode work).
 constexpr uint32_t CUT_INSIDE = 1u << 31;
 
+// lane 15's x of my group of 16 lanes (grp = lane / 16): four scalar reads and a select instead of a trip through the LDS crossbar
+__device__ __forceinline__ uint32_t row_last(uint32_t x, uint32_t grp) {
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)x, 15), b = (uint32_t)__builtin_amdgcn_readlane((int)x, 31);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)x, 47), d = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+    return grp == 0u ? a : grp == 1u ? b : grp == 2u ? c : d;
+}
+
 // cut0[s * n_tiles_ub + tile] / cut1[...]: where list s's part of the tile begins and ends (tiles that take whole lists: the
 // lists' first block and the block after their last).  A tile's end is the next tile's beginning, so the cut at a tile's lower
 // bound is computed once and handed to the tile(s) before it as their end.  A thread per (list, tile) - neighbouring lanes hold
@@ -288,6 +295,16 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
         }
     }
     // (block a of segment s: two lanes share a walk when both agree; lanes of a wave may belong to two lists)
+    // The walk, shared: a group of 16 lanes decodes 256 bytes of a block into LDS - per byte the doc-id sum up to and including it
+    // (non-decreasing; at a varint's last byte: the posting's doc id) and the last-byte marks - and EVERY lane whose bound falls
+    // into that block then finds its crossing by itself, all bounds at once: bisection over the 256 sums for the first byte at
+    // or above its bound (that byte lies in the first posting >= the bound), the last mark before it is where that posting
+    // starts and holds the doc id before it.  (The first version took the bounds one after the other, each with a 16-way
+    // compare of every lane's sums and a dozen shuffles: ~900 instructions per block and step against ~300.)
+    __shared__ uint32_t sh_doc[4][4][256];       // [wave][group][byte]
+    __shared__ uint32_t sh_end[4][4][16];        // [wave][group][piece] bit q: byte q of the piece ends a posting
+    __shared__ uint2 sh_last[4][4];              // [wave][group] {payload offset behind the step's last posting end, its doc id}
+    const uint32_t wv = threadIdx.x >> 6;
     const unsigned long long blk_id = ((unsigned long long)s << 32) | a;
     for (unsigned long long need = __ballot(walk); need != 0ull;) {
         // up to four different blocks, one per group of 16 lanes, each with the lanes whose bounds fall into it (they are
@@ -303,16 +320,24 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
                 need &= ~bm[g];
             } else (void)__shfl((long long)blk_id, 0, 64);       // (every lane takes part in every shuffle)
         }
+        // my role as a member of group grp: its block
         const int src = grp == 0u ? lead[0] : grp == 1u ? lead[1] : grp == 2u ? lead[2] : lead[3];
-        unsigned long long pend = grp == 0u ? bm[0] : grp == 1u ? bm[1] : grp == 2u ? bm[2] : bm[3];      // my group's bounds still to be found
+        const unsigned long long gmask = grp == 0u ? bm[0] : grp == 1u ? bm[1] : grp == 2u ? bm[2] : bm[3];
         const uint32_t w_start = (uint32_t)__shfl((int)start, src, 64), w_len = (uint32_t)__shfl((int)len, src, 64);
-        const uint32_t w_first = (uint32_t)__shfl((int)first, src, 64), w_a = (uint32_t)__shfl((int)a, src, 64);
+        const uint32_t w_first = (uint32_t)__shfl((int)first, src, 64);
         const uint8_t *w_pay = ms->segs[(uint32_t)__shfl((int)s, src, 64)].payload;
-        const uint32_t np = pend ? (w_len + 15u) >> 4 : 0u;
+        const uint32_t np = gmask ? (w_len + 15u) >> 4 : 0u;
+        // my role as the owner of a bound: which group walks my block (if any, this round)
+        const bool b0 = (bm[0] >> l) & 1ull, b1 = (bm[1] >> l) & 1ull, b2 = (bm[2] >> l) & 1ull, b3 = (bm[3] >> l) & 1ull;
+        bool asking = b0 || b1 || b2 || b3;
+        const uint32_t og = b0 ? 0u : b1 ? 1u : b2 ? 2u : 3u;
+        uint32_t prev_start = start, prev_doc = first;          // the posting end before my step: the block's beginning so far
         uint32_t docbase = w_first;                             // sum of all gap bits before the step's first piece
-        for (uint32_t pb = 0; __ballot(pend != 0ull && pb < np) != 0ull; pb += 16u) {       // (wave-uniform: a group that is done idles)
+        for (uint32_t pb = 0;; pb += 16u) {
+            const unsigned long long askmask = __ballot(asking);
+            if (__ballot((askmask & gmask) != 0ull && pb < np) == 0ull) break;       // (wave-uniform: a group that is done idles)
             const uint32_t pc = pb + hl;
-            const bool pv = pend != 0ull && pc < np;
+            const bool pv = (askmask & gmask) != 0ull && pc < np;
             uint32_t val[16], tmask = 0, w[4] = {0, 0, 0, 0}, prev = 0;
 #pragma unroll
             for (int q = 0; q < 16; q++) val[q] = 0;
@@ -343,55 +368,62 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
                 }
                 if (rem < 16u) tmask &= (1u << rem) - 1u;
             }
-            uint32_t incl = val[15];
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 16); if (hl >= (uint32_t)d) incl += y; }
+            uint32_t incl = val[15];                              // prefix sum inside the group of 16 lanes = a DPP row
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
             const uint32_t base = docbase + incl - val[15];
-            // the group's bounds, in ascending order, against this step's 16 pieces: a bound that is not found here waits for
-            // the next step (and so do the bounds above it)
-            bool more = pend != 0ull;
-            while (__ballot(more) != 0ull) {                     // (wave-uniform)
-                const int bl = more ? __ffsll((long long)pend) - 1 : 0;
-                const uint32_t xb = (uint32_t)__shfl((int)x, bl, 64);
-                uint32_t cm = 0;
-#pragma unroll
-                for (int q = 0; q < 16; q++) cm |= (base + val[q] >= xb) ? 1u << q : 0u;
-                cm &= tmask;
-                const bool hit = more && pv && cm != 0u;
-                const uint32_t hits = (uint32_t)(__ballot(hit) >> (16u * grp)) & 0xFFFFu;
-                uint4 r = make_uint4(0, 0, 0, 0);
-                if (hit) {
-                    // the first posting >= x ends at byte q of my piece: its varint back to front (the byte before its first one
-                    // ends the posting before, or is the 0 in front of the block's first byte), most significant group first
-                    const int q = __ffs((int)cm) - 1;
-                    uint32_t gap = 0, nbytes = 0;
-                    for (int j = q; j > q - 5; j--) {
-                        const uint32_t wj = j < 0 ? prev : j < 4 ? w[0] : j < 8 ? w[1] : j < 12 ? w[2] : w[3];
-                        const uint32_t c = (wj >> (8u * ((uint32_t)j & 3u))) & 0xFFu;
-                        if (j != q && !(c & 0x80u)) break;
-                        gap = (gap << 7) | (c & 0x7Fu);
-                        nbytes++;
-                    }
-                    uint32_t vq = val[0];
-#pragma unroll
-                    for (int t = 1; t < 16; t++) vq = t == q ? val[t] : vq;
-                    r = make_uint4((w_a - 1u) | CUT_INSIDE, w_start + off + (uint32_t)q + 1u - nbytes, base + vq - gap, 0u);
+            // ---- the step's 256 bytes in LDS (a piece past the block's end: all ones - never below a bound, and past `valid`)
+            {
+                uint4 *d4 = reinterpret_cast<uint4 *>(&sh_doc[wv][grp][16u * hl]);
+                const uint32_t f = pv ? 0u : 0xFFFFFFFFu;
+                d4[0] = make_uint4((base + val[0]) | f, (base + val[1]) | f, (base + val[2]) | f, (base + val[3]) | f);
+                d4[1] = make_uint4((base + val[4]) | f, (base + val[5]) | f, (base + val[6]) | f, (base + val[7]) | f);
+                d4[2] = make_uint4((base + val[8]) | f, (base + val[9]) | f, (base + val[10]) | f, (base + val[11]) | f);
+                d4[3] = make_uint4((base + val[12]) | f, (base + val[13]) | f, (base + val[14]) | f, (base + val[15]) | f);
+                sh_end[wv][grp][hl] = tmask;
+                // the step's last posting end, for the bounds that go on to the next step: the highest lane of the group with a mark
+                const uint32_t marks = (uint32_t)(__ballot(tmask != 0u) >> (16u * grp)) & 0xFFFFu;
+                if (marks != 0u && hl == 31u - (uint32_t)__clz((int)marks)) {
+                    const uint32_t q = 31u - (uint32_t)__clz((int)tmask);
+                    sh_last[wv][grp] = make_uint2(w_start + off + q + 1u, sh_doc[wv][grp][16u * hl + q]);
                 }
-                const int hsrc = hits ? __ffs((int)hits) - 1 : 0;
-                const uint4 res = make_uint4((uint32_t)__shfl((int)r.x, hsrc, 16), (uint32_t)__shfl((int)r.y, hsrc, 16), (uint32_t)__shfl((int)r.z, hsrc, 16), 0u);
-                // the groups' answers go to the lanes that asked
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const uint32_t rx = (uint32_t)__shfl((int)res.x, 16 * g, 64), ry = (uint32_t)__shfl((int)res.y, 16 * g, 64), rz = (uint32_t)__shfl((int)res.z, 16 * g, 64);
-                    const bool found = (uint32_t)__shfl((int)(more && hits != 0u ? 1 : 0), 16 * g, 64) != 0u;
-                    const int who = __shfl(bl, 16 * g, 64);
-                    if (found && l == who) c0 = make_uint4(rx, ry, rz, 0u);
-                }
-                if (more && hits != 0u) pend &= pend - 1ull;     // found: on to the group's next bound, in this same step
-                else more = false;
-                more = more && pend != 0ull;
             }
-            docbase += (uint32_t)__shfl((int)incl, 15, 16);
+            // ---- every lane whose bound falls into one of the four blocks: its crossing, if it lies in this step
+            if (asking) {
+                const uint32_t done_bytes = 16u * pb;
+                const uint32_t valid = len - done_bytes < 256u ? len - done_bytes : 256u;       // (my block's bytes in this step; len > done_bytes while I ask)
+                const uint32_t *dv = sh_doc[wv][og];
+                uint32_t lo = 0, hi = valid;                     // first byte in [0, valid) whose sum is >= x
+#pragma unroll
+                for (int it = 0; it < 9; it++) {                 // (256 entries: nine halvings)
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const bool ge = lo < hi && dv[mid & 255u] >= x;
+                    hi = ge ? mid : hi;
+                    lo = (lo < hi && !ge) ? mid + 1u : lo;
+                }
+                if (lo < valid) {
+                    // the posting that holds byte lo is the first one >= x; it starts behind the last posting end before lo
+                    const uint32_t pi = lo >> 4, qi = lo & 15u;
+                    uint32_t m = sh_end[wv][og][pi] & ((1u << qi) - 1u);
+                    uint32_t tp = 16u * pi;
+                    if (m == 0u && pi != 0u) { m = sh_end[wv][og][pi - 1u]; tp -= 16u; }
+                    if (m != 0u) {
+                        tp += 31u - (uint32_t)__clz((int)m);
+                        c0 = make_uint4((a - 1u) | CUT_INSIDE, start + done_bytes + tp + 1u, dv[tp], 0u);
+                    } else {
+                        c0 = make_uint4((a - 1u) | CUT_INSIDE, prev_start, prev_doc, 0u);
+                    }
+                    asking = false;
+                } else if (done_bytes + 256u >= len) {
+                    asking = false;                              // the block lies wholly below my bound: the cut stays in front of the next block
+                } else {
+                    const uint2 lt = sh_last[wv][og];
+                    prev_start = lt.x; prev_doc = lt.y;
+                }
+            }
+            docbase += row_last(incl, grp);
         }
         // (bounds still pending: the block lies wholly below them - their cut stays in front of the next block)
     }
@@ -505,9 +537,11 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
                 }
                 if (rem < 16u) tmask &= (1u << rem) - 1u;
             }
-            uint32_t incl = val[15];
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 16); if (hl >= (uint32_t)d) incl += y; }
+            uint32_t incl = val[15];                              // prefix sum inside the group of 16 lanes = a DPP row
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
             const uint32_t base = docbase + incl - val[15];
             uint32_t cm = 0;
 #pragma unroll
@@ -537,12 +571,13 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__rest
                 res = make_uint4((uint32_t)__shfl((int)r.x, hsrc, 16), (uint32_t)__shfl((int)r.y, hsrc, 16), (uint32_t)__shfl((int)r.z, hsrc, 16), 0u);
                 open = false;
             }
-            docbase += (uint32_t)__shfl((int)incl, 15, 16);
+            docbase += row_last(incl, grp);
         }
         // the groups' results go to the lanes whose blocks they walked
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const uint32_t rx = (uint32_t)__shfl((int)res.x, 16 * g, 64), ry = (uint32_t)__shfl((int)res.y, 16 * g, 64), rz = (uint32_t)__shfl((int)res.z, 16 * g, 64);
+            const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)res.x, 16 * g), ry = (uint32_t)__builtin_amdgcn_readlane((int)res.y, 16 * g),
+                           rz = (uint32_t)__builtin_amdgcn_readlane((int)res.z, 16 * g);
             if ((uint32_t)g < ng && l == sl[g]) c0 = make_uint4(rx, ry, rz, 0u);
         }
     }
