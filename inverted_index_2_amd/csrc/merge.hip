@@ -268,7 +268,8 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
     const uint32_t hl = (uint32_t)l & 15u, grp = (uint32_t)l >> 4;
     const uint32_t n_tiles = *p.n_tiles_dev;
     const uint64_t n_pairs = (uint64_t)n_tiles * p.k;
-    const bool live = i < n_pairs;                              // (no early exit: the wave works together below)
+    const bool live = i < n_pairs;                              // (no early exit of single lanes: the wave works together below)
+    if (__ballot(live) == 0ull) return;                         // (the grid is sized by the tiles' upper bound: most waves have nothing)
     const uint32_t s = live ? (uint32_t)(i / n_tiles) : 0u, tile = live ? (uint32_t)(i % n_tiles) : 0u;
     const uint4 td = live ? p.desc[tile] : make_uint4(0u, 0u, 1u, 0u);
     const bool nonempty = live && td.z <= td.w;                 // (an empty range: the tile decodes nothing)
@@ -301,8 +302,9 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
     // or above its bound (that byte lies in the first posting >= the bound), the last mark before it is where that posting
     // starts and holds the doc id before it.  (The first version took the bounds one after the other, each with a 16-way
     // compare of every lane's sums and a dozen shuffles: ~900 instructions per block and step against ~300.)
-    __shared__ uint32_t sh_doc[4][4][256];       // [wave][group][byte]
+    __shared__ __align__(16) uint32_t sh_doc[4][4][256];     // [wave][group][byte]
     __shared__ uint32_t sh_end[4][4][16];        // [wave][group][piece] bit q: byte q of the piece ends a posting
+    __shared__ __align__(16) uint32_t sh_tot[4][4][16];      // [wave][group][piece] the sum at the piece's last byte
     __shared__ uint2 sh_last[4][4];              // [wave][group] {payload offset behind the step's last posting end, its doc id}
     const uint32_t wv = threadIdx.x >> 6;
     const unsigned long long blk_id = ((unsigned long long)s << 32) | a;
@@ -377,12 +379,17 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
             // ---- the step's 256 bytes in LDS (a piece past the block's end: all ones - never below a bound, and past `valid`)
             {
                 uint4 *d4 = reinterpret_cast<uint4 *>(&sh_doc[wv][grp][16u * hl]);
-                const uint32_t f = pv ? 0u : 0xFFFFFFFFu;
-                d4[0] = make_uint4((base + val[0]) | f, (base + val[1]) | f, (base + val[2]) | f, (base + val[3]) | f);
-                d4[1] = make_uint4((base + val[4]) | f, (base + val[5]) | f, (base + val[6]) | f, (base + val[7]) | f);
-                d4[2] = make_uint4((base + val[8]) | f, (base + val[9]) | f, (base + val[10]) | f, (base + val[11]) | f);
-                d4[3] = make_uint4((base + val[12]) | f, (base + val[13]) | f, (base + val[14]) | f, (base + val[15]) | f);
+                if (pv) {
+                    d4[0] = make_uint4(base + val[0], base + val[1], base + val[2], base + val[3]);
+                    d4[1] = make_uint4(base + val[4], base + val[5], base + val[6], base + val[7]);
+                    d4[2] = make_uint4(base + val[8], base + val[9], base + val[10], base + val[11]);
+                    d4[3] = make_uint4(base + val[12], base + val[13], base + val[14], base + val[15]);
+                } else {
+                    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                    d4[0] = ones; d4[1] = ones; d4[2] = ones; d4[3] = ones;
+                }
                 sh_end[wv][grp][hl] = tmask;
+                sh_tot[wv][grp][hl] = pv ? base + val[15] : 0xFFFFFFFFu;
                 // the step's last posting end, for the bounds that go on to the next step: the highest lane of the group with a mark
                 const uint32_t marks = (uint32_t)(__ballot(tmask != 0u) >> (16u * grp)) & 0xFFFFu;
                 if (marks != 0u && hl == 31u - (uint32_t)__clz((int)marks)) {
@@ -395,17 +402,22 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
                 const uint32_t done_bytes = 16u * pb;
                 const uint32_t valid = len - done_bytes < 256u ? len - done_bytes : 256u;       // (my block's bytes in this step; len > done_bytes while I ask)
                 const uint32_t *dv = sh_doc[wv][og];
-                uint32_t lo = 0, hi = valid;                     // first byte in [0, valid) whose sum is >= x
-#pragma unroll
-                for (int it = 0; it < 9; it++) {                 // (256 entries: nine halvings)
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const bool ge = lo < hi && dv[mid & 255u] >= x;
-                    hi = ge ? mid : hi;
-                    lo = (lo < hi && !ge) ? mid + 1u : lo;
+                // first byte in [0, valid) whose sum is >= x: the sums ascend, so it is the number of sums below x - counted over
+                // the 16 pieces' last sums, then over that piece's 16 bytes (two LDS round trips; a bisection is nine)
+                uint32_t pi = 0, qi = 0;
+                {
+                    const uint4 *t4 = reinterpret_cast<const uint4 *>(sh_tot[wv][og]);
+                    const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+                    pi = (t0.x < x) + (t0.y < x) + (t0.z < x) + (t0.w < x) + (t1.x < x) + (t1.y < x) + (t1.z < x) + (t1.w < x) +
+                         (t2.x < x) + (t2.y < x) + (t2.z < x) + (t2.w < x) + (t3.x < x) + (t3.y < x) + (t3.z < x) + (t3.w < x);
+                    const uint4 *d4 = reinterpret_cast<const uint4 *>(dv + 16u * (pi & 15u));
+                    const uint4 d0 = d4[0], d1 = d4[1], d2 = d4[2], d3 = d4[3];
+                    qi = (d0.x < x) + (d0.y < x) + (d0.z < x) + (d0.w < x) + (d1.x < x) + (d1.y < x) + (d1.z < x) + (d1.w < x) +
+                         (d2.x < x) + (d2.y < x) + (d2.z < x) + (d2.w < x) + (d3.x < x) + (d3.y < x) + (d3.z < x) + (d3.w < x);
                 }
+                const uint32_t lo = pi < 16u ? 16u * pi + qi : 256u;      // (pi < 16: the piece's last sum is >= x, so qi < 16)
                 if (lo < valid) {
                     // the posting that holds byte lo is the first one >= x; it starts behind the last posting end before lo
-                    const uint32_t pi = lo >> 4, qi = lo & 15u;
                     uint32_t m = sh_end[wv][og][pi] & ((1u << qi) - 1u);
                     uint32_t tp = 16u * pi;
                     if (m == 0u && pi != 0u) { m = sh_end[wv][og][pi - 1u]; tp -= 16u; }
@@ -445,6 +457,7 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
     if (last) p.cut1[(uint64_t)s * p.cut_ss + (uint64_t)tile * p.cut_st] = make_uint2(b_hi, 0u);
 }
 
+
 // Few lists (k < 32): a bound rarely shares its block with another one - a thread per (tile, list), neighbouring lanes hold the
 // lists of one tile (cut0[tile * k + s]), every bound walks its block.
 // cut0 / cut1: where list s's part of the tile begins and ends (tiles that take whole lists: the
@@ -453,12 +466,13 @@ __global__ __launch_bounds__(256) void k_merge_tile_runs_shared(const MergeSegs 
 // straddles the bound in the skip table; the walks through those blocks are then done by the wave together, four at a time:
 // 16 lanes per block, 16 payload bytes per lane, 256 bytes of a block in one round of loads (a thread walking its block
 // alone is a chain of dependent loads: ~1 ms on C3 against 0.1 ms for everything else the plan does).
-__global__ __launch_bounds__(256) void k_merge_tile_runs(const MergeSegs *__restrict__ ms, MergeParams p) {
+__global__ __launch_bounds__(256) void k_merge_tile_runs_few(const MergeSegs *__restrict__ ms, MergeParams p) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = lane_id();
     const uint32_t hl = (uint32_t)l & 15u, grp = (uint32_t)l >> 4;
     const uint64_t n_pairs = (uint64_t)*p.n_tiles_dev * p.k;
-    const bool live = i < n_pairs;                              // (no early exit: the wave works together below)
+    const bool live = i < n_pairs;                              // (no early exit of single lanes: the wave works together below)
+    if (__ballot(live) == 0ull) return;                         // (the grid is sized by the tiles' upper bound: most waves have nothing)
     const uint32_t tile = live ? (uint32_t)(i / p.k) : 0u, s = live ? (uint32_t)(i % p.k) : 0u;
     const uint4 td = live ? p.desc[tile] : make_uint4(0u, 0u, 1u, 0u);
     const bool nonempty = live && td.z <= td.w;                 // (an empty range: the tile decodes nothing)
@@ -1524,7 +1538,7 @@ hipError_t launch_merge_tile_desc(const MergeSegs *ms, const MergeParams &p, hip
 hipError_t launch_merge_tile_runs(const MergeSegs *ms, const MergeParams &p, hipStream_t s) {
     if (p.n_tiles_ub == 0) return hipSuccess;
     if (p.cut_st == 1u) hipLaunchKernelGGL(k_merge_tile_runs_shared, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
-    else hipLaunchKernelGGL(k_merge_tile_runs, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
+    else hipLaunchKernelGGL(k_merge_tile_runs_few, dim3(grid_for((uint64_t)p.n_tiles_ub * p.k)), dim3(256), 0, s, ms, p);
     return hipGetLastError();
 }
 hipError_t launch_merge_tiles(const MergeSegs *ms, const MergeParams &p, uint32_t grid, hipStream_t s) {
