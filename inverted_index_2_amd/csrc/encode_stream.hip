@@ -384,7 +384,14 @@ template <bool STAMPS> __global__ __launch_bounds__(256) void k_enc_stream(EncSt
     if (wv == 1u && lb_is_leader(g, gridDim.x)) {
         if (!lb_group_publish(p.lb, g, total) && l == 0) { wg_err = 1u; lb_fail(p.lb); }
     }
-    if (!big) es_tile_stage(A, st);
+    // Both tiles before the wait when they fit the stage together (the usual case: ~1900 bytes each) - twice the work between the
+    // publish and the question; otherwise the second tile takes the stage after the first has left.
+    const uint32_t off_b = (A.bytes + 15u) & ~15u;
+    const bool both = off_b + B.bytes <= ES_STAGE_BYTES;          // (wave-uniform)
+    if (!big) {
+        es_tile_stage(A, st);
+        if (both) es_tile_stage(B, st + off_b);
+    }
     II2_STAMP(4)              // publish, walk B of the first tile
     // ---- where the workgroup's bytes begin
     if (wv == 0u) {
@@ -419,8 +426,8 @@ template <bool STAMPS> __global__ __launch_bounds__(256) void k_enc_stream(EncSt
     if (A.nloc == 0u || err || !fits || big) return;
     es_tile_flush(p, A, st, base);
     II2_STAMP(6)              // first tile: flush, skip entries
-    es_tile_stage(B, st);
-    es_tile_flush(p, B, st, base + A.bytes);
+    if (!both) es_tile_stage(B, st);
+    es_tile_flush(p, B, both ? st + off_b : st, base + A.bytes);
     II2_STAMP(2)              // second tile: walk B, flush, skip entries
     if (stamps && l == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&p.debug[(uint64_t)(blockIdx.x % 2048u) * 8u + i], tacc[i]);
