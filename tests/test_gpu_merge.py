@@ -173,6 +173,43 @@ def test_merged_segment_bytes_equal_the_oracles_encoding(ctx, stream):
         ctx.set_option("encode.stream", 1)
 
 
+def _one_segment_case(ctx, lists):
+    off = np.concatenate([[0], np.cumsum([x.size for x in lists])]).astype(np.uint64)
+    vals = np.concatenate(list(lists) + [np.empty(0, np.uint32)]).astype(np.uint32)
+    before = ctx.counters()[1]
+    merged, st = ctx.merge_to_segment([ctx.encode(off, vals)], None)
+    assert st.n_out == vals.size
+    assert ctx.counters()[1] == before                          # (the one-pass encoder did it: no hand-over to the two-pass one)
+    _segment_equals_oracle_encoding(merged, off, vals)          # (one segment, nothing removed: the merge is the identity)
+    merged.free()
+
+
+def test_one_pass_encoder_on_list_structures_that_stress_its_bookkeeping(ctx):
+    """k_enc_stream derives block starts, block numbers and block owners from a bit mask of list starts per 1024-id tile
+    (encode_stream.hip); the shapes here aim at every branch of that: long runs of EMPTY lists in front of a list that is
+    longer than a block (the owner of a block that starts inside a list is then found by search, not by counting starts),
+    more than 64 list starts in one tile (several rounds of the marking loop), tiles filled with five-byte gaps to the
+    proven worst case of the LDS stage (lists of 16 ids 2^28 apart: 4800 bytes per 1024 ids), and totals right at the
+    tile / wave / workgroup sizes (1, 1023, 1024, 1025, 2048, 8192, 8193 ids)."""
+    rng = np.random.default_rng(77)
+    e = np.empty(0, np.uint32)
+    # (a) empty runs before long lists; the long lists start inside tiles
+    lists = [sorted_unique(rng, 300, 1 << 20)] + [e] * 5000 + [sorted_unique(rng, 700, 1 << 24)] + [e] * 3000 + \
+            [sorted_unique(rng, 2000, 1 << 22), sorted_unique(rng, 5, 100)] + [e] * 70000 + [sorted_unique(rng, 5000, 1 << 30), e, e, sorted_unique(rng, 257, 1 << 12)]
+    _one_segment_case(ctx, lists)
+    # (b) thousands of one- to three-posting lists, then a long one
+    tiny = [sorted_unique(rng, int(n), 1 << 31) for n in rng.integers(1, 4, 6000)]
+    _one_segment_case(ctx, tiny + [sorted_unique(rng, 9000, 1 << 26)] + tiny[:100])
+    # (c) five-byte gaps: 16 ids 2^28 apart per list, 300 lists (every tile at the stage's worst case), behind a 15-id tail
+    far = [(np.arange(16, dtype=np.uint64) * (1 << 28) + int(b)).astype(np.uint32) for b in rng.integers(0, 1 << 28, 300)]
+    _one_segment_case(ctx, [far[0][1:]] + far)
+    _one_segment_case(ctx, [sorted_unique(rng, 1009, 1 << 20)] + far)          # (the same lists at another phase of the tiles)
+    # (d) totals at the sizes the kernel is cut by
+    for n in (1, 1023, 1024, 1025, 2048, 4096, 8191, 8192, 8193, 16384):
+        _one_segment_case(ctx, [sorted_unique(rng, n, 1 << 28)])
+        _one_segment_case(ctx, [sorted_unique(rng, n - n // 2, 1 << 28), e, sorted_unique(rng, n // 2, 1 << 16)])
+
+
 def test_direct_placement_wait_runs_out_and_the_merge_is_repeated(ctx):
     """The merge's direct placement (tiles move their survivors to their final place once a scanner workgroup has turned the
     tiles' counts into offsets) rests on workgroups starting in index order.  Every wait is bounded: with a scanner that never
