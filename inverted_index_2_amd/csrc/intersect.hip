@@ -887,9 +887,16 @@ __global__ __launch_bounds__(256) void k_isect_sums(IntersectParams p) {
 // sums the tile kernel accumulated plus the counts inside the tile's own group of 64 — a few
 // 64-wide loads, once per expand workgroup (it then walks consecutive tiles), instead of a
 // separate scan launch.  (Sums per 64 tiles keep the atomics spread: 64 adds per address.)
+constexpr uint32_t SUMS_FROM_TILES = 4096;      // up to this many tiles the expand pass adds the counts up itself: no sums launch
+
 __device__ __forceinline__ unsigned long long tile_offset(const IntersectParams &p, uint32_t tile) {
     const uint32_t l = (uint32_t)lane_id();
     unsigned long long off = 0;
+    if (p.n_tiles <= SUMS_FROM_TILES) {           // (a query of a few thousand tiles is launch-bound: 64 loads per lane at most)
+        uint32_t acc = 0;
+        for (uint32_t i = l; i < tile; i += 64u) acc += p.tile_count[i] & ~LIST_FLAG;
+        return wave_sum(acc);                      // (<= 4096 tiles of <= 4096 ids)
+    }
     const uint32_t e1 = tile >> 6;
     for (uint32_t i = 0; i < e1; i += 64u) off += wave_sum(i + l < e1 ? p.sums[i + l] : 0u);
     const uint32_t a0 = e1 << 6;
@@ -984,7 +991,7 @@ hipError_t launch_intersect(const IntersectParams &p, uint64_t *d_tile_off, hipS
         else if (p.n_lists == 2u && !p.sparse_driver) hipLaunchKernelGGL((k_isect_tiles<false, 2u, false>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_isect_tiles<false, 0u, false>), dim3(grid), dim3(256), 0, s, p);
     }
-    hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);
+    if (p.n_tiles > SUMS_FROM_TILES) hipLaunchKernelGGL(k_isect_sums, dim3((p.n_sums + 3u) / 4u), dim3(256), 0, s, p);
     const uint32_t egrid = p.n_tiles < 4096u ? p.n_tiles : 4096u;
     hipLaunchKernelGGL(k_isect_expand, dim3(egrid), dim3(256), 0, s, p);
     if (ev1) (void)hipEventRecord(ev1, s);
