@@ -288,7 +288,16 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
         seg->h_spans.resize(3 * seg->n_lists);
         HIP_TRY(ctx, hipMemcpyAsync(seg->h_spans.data(), d_sp, 3 * seg->n_lists * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     }
+    // a view's postings: the sum of its lists' counts (the store's total would make every merge of a few of its lists plan,
+    // clear and launch for the whole store: milliseconds of fills and empty workgroups per call)
+    const bool count_view = seg->is_view && seg->n_lists && seg->d_cnt;
+    if (count_view) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail + 16, 0, sizeof(uint64_t), ctx->stream));
+        HIP_TRY(ctx, launch_sum_u32(seg->d_cnt, seg->n_lists, ctx->d_mail + 16, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 16, ctx->d_mail + 16, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (count_view) seg->n_postings = std::min<uint64_t>(seg->n_postings, ctx->h_mail[16]);
     seg->born = nullptr;                                    // finished: from here on the caller's contract governs its lifetime
     return II2_OK;
 }
@@ -605,7 +614,20 @@ int ii2_seg_select(ii2_ctx *ctx, const ii2_seg *src, uint64_t n_out, const int64
     seg->n_postings = src->n_postings;      // upper bound: postings of unselected window lists are still counted
     if (dm_alloc((void **)&seg->d_blk_off, (n_out + 1) * sizeof(uint32_t)) != hipSuccess) return fail(ctx, II2_ENOMEM, "segment allocation failed");
     HIP_TRY(ctx, hipMemcpyAsync(seg->d_blk_off, blk.data(), (n_out + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    // the view's window of the store: blocks [blk[0], blk[n_out]) and the payload bytes between their skip entries
+    ii2_skip w0, w1;
+    std::memset(&w0, 0, sizeof w0); std::memset(&w1, 0, sizeof w1);
+    if (n_out && blk[n_out] > blk[0]) {
+        HIP_TRY(ctx, hipMemcpyAsync(&w0, src->d_skip + blk[0], sizeof w0, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(&w1, src->d_skip + blk[n_out], sizeof w1, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (n_out && blk[n_out] > blk[0]) {
+        seg->win_blocks = (uint64_t)blk[n_out] - blk[0];
+        seg->win_bytes = std::max<uint64_t>((uint64_t)w1.byte_off - w0.byte_off, 1);
+    } else {
+        seg->win_blocks = 1; seg->win_bytes = 1;             // (nothing selected: a window of nothing; 0 would mean "the totals")
+    }
     int rc = seg_finish(ctx, seg.get());
     if (rc) return rc;
     seg->born = nullptr;

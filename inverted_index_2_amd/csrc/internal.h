@@ -111,6 +111,12 @@ struct ii2_seg {
                                              // still be written by enqueued kernels, so releasing one waits for that stream first
     std::shared_ptr<ii2_seg_store> store;   // owns d_skip / d_payload
     uint64_t n_lists = 0, n_postings = 0, n_blocks = 0, n_bytes = 0;
+    // what a merge of this segment can at most read: the segment's own totals, or - for a view of some lists of a store
+    // (ii2_seg_select) - the blocks and payload bytes of its window of the store; 0 = the totals above.  (A view's n_blocks and
+    // n_bytes stay its STORE's: its block numbers and byte offsets live there.)
+    uint64_t win_blocks = 0, win_bytes = 0;
+    uint64_t merge_blocks() const { return win_blocks ? win_blocks : n_blocks; }
+    uint64_t merge_bytes() const { return win_bytes ? win_bytes : n_bytes; }
     uint32_t *d_blk_off = nullptr;   // [n_lists+1]
     ii2_skip *d_skip = nullptr;      // [n_blocks+1]
     uint8_t *d_payload = nullptr;    // [n_bytes + 16]

@@ -241,8 +241,8 @@ static int merge_unlocked(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *segs, 
     uint64_t n_in = 0, n_blk = 0;
     for (uint32_t s = 0; s < k; s++) {
         views[s] = SegView{segs[s]->d_blk_off, segs[s]->d_skip, segs[s]->d_payload, segs[s]->d_cnt, segs[s]->d_blk_list, segs[s]->d_last_doc, 0u, 0u};
-        n_in += segs[s]->n_postings;       // (views made by ii2_seg_select carry their store's totals: upper bounds)
-        n_blk += segs[s]->n_blocks;
+        n_in += segs[s]->n_postings;       // (exact for whole segments and for views made by ii2_seg_select; views adopted from the device alignment carry their store's total)
+        n_blk += segs[s]->merge_blocks();
     }
     ii2_merge_stats local;
     std::memset(&local, 0, sizeof local);
@@ -272,7 +272,7 @@ int ii2_merge_segments_to_seg(ii2_ctx *ctx, uint32_t k, const ii2_seg *const *se
     int rc = check_segs(ctx, k, segs);
     if (rc) return rc;
     uint64_t n_in = 0, bytes_in = 0, blocks_in = 0;
-    for (uint32_t s = 0; s < k; s++) { n_in += segs[s]->n_postings; bytes_in += segs[s]->n_bytes; blocks_in += segs[s]->n_blocks; }
+    for (uint32_t s = 0; s < k; s++) { n_in += segs[s]->n_postings; bytes_in += segs[s]->merge_bytes(); blocks_in += segs[s]->merge_blocks(); }
     const uint64_t T = segs[0]->n_lists;
     // the merged CSR waits for the encoder in the context's grow-only staging buffers (no hipMalloc per Shard.Merge)
     uint64_t *off = (uint64_t *)ii2_pool_get(ctx, 2, (T + 1) * sizeof(uint64_t));
