@@ -2,6 +2,7 @@
 // intersect / union / merge entry points and the host-buffer convenience calls.
 // There is deliberately no CPU implementation behind any entry point.
 #include <algorithm>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -399,8 +400,10 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_debug, 0, (size_t)2048 * 8 * sizeof(unsigned long long), st));
         d_dbg = ctx->d_debug;
     }
-    HIP_TRY(ctx, launch_enc_stream(d_post_off, d_values, seg->d_blk_off, n_lists, n_postings, seg->d_skip, seg->d_payload, cap, seg->d_blk_list,
-                                   d_part, d_res, lb, d_dbg, st));
+    if (int rcq = ii2_lookback_launch(ctx, true, [&] {
+            return launch_enc_stream(d_post_off, d_values, seg->d_blk_off, n_lists, n_postings, seg->d_skip, seg->d_payload, cap, seg->d_blk_list,
+                                     d_part, d_res, lb, d_dbg, st);
+        })) return rcq;
     HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_res, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -870,6 +873,55 @@ static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, con
 
 // Look-back records for a launch of n_wg workgroups (lookback.h): a buffer of the context's own that only those kernels write,
 // every word tagged with its launch's number - nothing to clear between launches (cleared when it grows or the numbers wrap).
+// Kernels whose workgroups wait for lower-numbered workgroups of the SAME launch (lookback.h) must not share the GPU with
+// another such launch: workgroups go to the eight XCDs round robin and every XCD starts its share in order, but the XCDs do not
+// wait for each other - with two of these kernels from two contexts side by side, the workgroups of one can fill an XCD, spinning
+// for a predecessor that sits in another XCD's queue behind the spinning workgroups of the other: each waits for a slot the
+// other holds (seen: three contexts encoding merged segments at once under a tracer - every encoder ran out its seconds of
+// bounded waits and handed over to the two-pass encoder).  The merge's tile kernel with direct placement waits too, but only for
+// its scanner, workgroup 0 - the head of its XCD's queue: several of THEM side by side are safe (a freed slot goes to a
+// scanner before it goes to any other workgroup of that kernel), one of them beside a look-back kernel is not.
+// So, per device: a look-back kernel (exclusive = true) waits - on the GPU, not on the host - for every earlier kernel of
+// either kind and every later one waits for it; tile kernels (exclusive = false) only wait for the last look-back kernel.
+// Kernels without waits between workgroups run beside all of them as before.
+namespace {
+struct LbChain {
+    hipEvent_t ev_x = nullptr;              // the last exclusive kernel
+    bool has_x = false;
+    hipEvent_t ev_s[16] = {};               // the shared kernels since then (a ring: the 17th waits for the 1st)
+    bool has_s[16] = {};
+    unsigned next_s = 0;
+};
+std::mutex g_lb_mu;
+LbChain g_lb[64];
+}  // namespace
+int ii2_lookback_launch(ii2_ctx *ctx, bool exclusive, const std::function<hipError_t()> &launch) {
+    const int dev = ctx->device;
+    if (dev < 0 || dev >= 64) return fail(ctx, II2_EINVAL, "device number out of range");
+    if (ctx->opt_debug_no_chain) { HIP_TRY(ctx, launch()); return II2_OK; }      // (experiments: what happens without the order)
+    std::lock_guard<std::mutex> g(g_lb_mu);
+    LbChain &c = g_lb[dev];
+    if (!c.ev_x) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&c.ev_x, hipEventDisableTiming));
+        for (int i = 0; i < 16; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&c.ev_s[i], hipEventDisableTiming));
+    }
+    if (c.has_x) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c.ev_x, 0));
+    if (exclusive) {
+        for (int i = 0; i < 16; i++)
+            if (c.has_s[i]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c.ev_s[i], 0)); c.has_s[i] = false; }
+        HIP_TRY(ctx, launch());
+        HIP_TRY(ctx, hipEventRecord(c.ev_x, ctx->stream));
+        c.has_x = true;
+    } else {
+        const unsigned slot = c.next_s++ % 16u;
+        if (c.has_s[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c.ev_s[slot], 0));
+        HIP_TRY(ctx, launch());
+        HIP_TRY(ctx, hipEventRecord(c.ev_s[slot], ctx->stream));
+        c.has_s[slot] = true;
+    }
+    return II2_OK;
+}
+
 int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb) {
     hipStream_t st = ctx->stream;
     if (n_wg > ctx->lb_cap || ctx->lb_epoch >= (1u << 24) - 1u) {
@@ -1031,7 +1083,11 @@ static int intersect_unlocked(ii2_ctx *ctx, uint32_t n, const ii2_seg *const *se
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
         ii2_profile_pair(ctx, &e0, &e1);
-        HIP_TRY(ctx, and2 ? launch_intersect_and2(dp, st, e0, e1) : launch_intersect_dense(dp, st, e0, e1));
+        if (and2 && dp.lb.agg) {           // (the one-launch form waits between workgroups: one such kernel per device at a time)
+            if (int rcq = ii2_lookback_launch(ctx, true, [&] { return launch_intersect_and2(dp, st, e0, e1); })) return rcq;
+        } else {
+            HIP_TRY(ctx, and2 ? launch_intersect_and2(dp, st, e0, e1) : launch_intersect_dense(dp, st, e0, e1));
+        }
         return II2_OK;
     }
     // a tiny sparse driver (a rare term against long lists) would keep only a handful of workgroups busy, each decoding
@@ -1350,6 +1406,8 @@ int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value) {
     else if (k == "merge.direct") ctx->opt_merge_direct = value;
     else if (k == "merge.spin") ctx->opt_merge_spin = value;
     else if (k == "debug.stamps") ctx->opt_debug_stamps = value;
+    else if (k == "merge.alone") ctx->opt_merge_alone = value;
+    else if (k == "debug.no_chain") ctx->opt_debug_no_chain = value;
     else if (k == "profile.events") ctx->opt_profile_events = value;
     else if (k == "intersect.bitmap") ctx->opt_intersect_bitmap = value;
     else if (k == "union.dense") ctx->opt_union_dense = value;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <memory>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -45,6 +46,8 @@ struct ii2_ctx {
     // grow-only staging buffers of the encode / decode / merge-to-segment paths (no hipMalloc per call)
     uint8_t *pool[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t pool_cap[4] = {0, 0, 0, 0};
+    int64_t opt_merge_alone = 0;        // merge: Mi input postings above which the tile kernel does not share the GPU with another one (0: 64)
+    int64_t opt_debug_no_chain = 0;     // experiments: kernels that wait between workgroups are NOT ordered per device
     int64_t opt_debug_stamps = 0;       // intersect: collect per-phase cycle counters
     int64_t opt_intersect_map_docs = 0; // 0 = default (8192 docs per driver block)
     int64_t opt_union_rank = 1;         // unions of <= 8 lists / 2^20 postings by ranking (union_rank.hip)
@@ -294,6 +297,7 @@ hipError_t launch_intersect_and2(const DenseParams &p, hipStream_t s, hipEvent_t
 
 }  // namespace ii2
 int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb);      // api.cpp; ctx->mu held
+int ii2_lookback_launch(ii2_ctx *ctx, bool exclusive, const std::function<hipError_t()> &launch);      // api.cpp; ctx->mu held: kernels that wait between workgroups, ordered per device
 namespace ii2 {
 
 constexpr size_t SELFTEST_SCRATCH = 64 * 4 * 1408;

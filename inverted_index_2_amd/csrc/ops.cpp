@@ -182,7 +182,16 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     p.tile_off = d_tile_off;
     p.direct = (postings_ub <= out_cap && ctx->opt_merge_direct) ? 1u : 0u;
     if (p.direct) HIP_TRY(ctx, hipMemsetAsync(d_tile_off, 0xFF, nt1 * sizeof(uint64_t), st));      // all-ones: "offset not known yet"
-    HIP_TRY(ctx, launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * (1024u / MERGE_THREADS), st));
+    if (p.direct) {
+        // its workers wait for its scanner workgroup: never beside a look-back kernel (api.cpp).  Beside another tile kernel it is
+        // safe, and worth it for small merges (a few tiles per workgroup: one kernel's tail hides behind the other's body - the
+        // chunks of a rank's term range, 3 contexts: 2.5 - 3.2 ms a step against 2.8 - 3.7); big ones only get in each other's way
+        // (three chunks of C4 on one GPU: 18.1 ms side by side, 16.1 ms one after the other).
+        const bool alone = postings_ub > (uint64_t)(ctx->opt_merge_alone > 0 ? ctx->opt_merge_alone : 64) << 20;      // (option merge.alone: the threshold in Mi postings)
+        if (int rcq = ii2_lookback_launch(ctx, alone, [&] { return launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * (1024u / MERGE_THREADS), st); })) return rcq;
+    } else {
+        HIP_TRY(ctx, launch_merge_tiles(d_ms, p, (uint32_t)ctx->cu_count * (1024u / MERGE_THREADS), st));
+    }
     if (!p.direct) {
         HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
         HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));

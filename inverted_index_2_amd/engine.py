@@ -7,6 +7,7 @@ Nothing here computes postings on the CPU — every operator is a call into libi
 from __future__ import annotations
 
 import ctypes as C
+import os
 import sys
 from typing import List, Optional, Sequence
 
@@ -94,6 +95,10 @@ class Context:
             raise II2Error(rc, (self.lib.ii2_last_error(None) or b"").decode())
         self.h = h
         self.device = device
+        # experiments: II2_OPTIONS="name=value,name=value" sets options on every context of the process (scripts, bench runs)
+        for kv in filter(None, os.environ.get("II2_OPTIONS", "").split(",")):
+            name, _, value = kv.partition("=")
+            self.set_option(name.strip(), int(value))
 
     def _ck(self, rc: int) -> None:
         if rc:

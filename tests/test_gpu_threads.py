@@ -66,6 +66,54 @@ def test_eight_threads_eight_contexts_share_segments(ctx):
     assert np.array_equal(out.download(n), want_and)
 
 
+def test_kernels_that_wait_between_workgroups_do_not_starve_each_other_across_contexts(ctx):
+    """The one-pass encoder behind a merge, the one-launch two-list AND and the merge's direct placement let workgroups wait for
+    lower-numbered workgroups of their own launch.  Two such kernels from two contexts side by side can hold each other's slots
+    (seen: three contexts encoding at once - every encoder ran out its bounded waits, seconds each, and handed over to its
+    second path): the library orders them per device (api.cpp: ii2_lookback_launch).  Four contexts on four threads, launches big
+    enough to fill the chip several times over: right results, and NO launch repeated on its second path."""
+    D = 40_000_000
+    a, b = synth.zipf_list(2, D), synth.zipf_list(3, D)                 # dense: the one-launch AND (~4000 workgroups... of 256 docs x 16 blocks)
+    shared = ctx.encode_lists([a, b])
+    want_and = np.intersect1d(a, b, assume_unique=True)
+    offs, vals, rem = synth.merge_workload(150_000, 8, 120, 50_000_000, seed=77)       # ~18M postings: ~2000 encoder workgroups
+    segs = [ctx.encode(o, v) for o, v in zip(offs, vals)]
+    tomb = ctx.tombstones(rem)
+    ref_seg, _ = ctx.merge_to_segment(segs, tomb)
+    ref_off, ref_vals = ref_seg.decode()
+    ref_seg.free()
+    workers = [Context(0) for _ in range(4)]
+    errors, barrier = [], threading.Barrier(4)
+
+    def run(i):
+        try:
+            c = workers[i]
+            barrier.wait()
+            for rep in range(5):
+                m, st = c.merge_to_segment(segs, tomb)
+                assert st.n_out == ref_vals.size
+                out, n = c.intersect([(shared, 0), (shared, 1)])
+                assert n == want_and.size
+                if rep == 4:
+                    po, v = m.decode()
+                    assert np.array_equal(po, ref_off) and np.array_equal(v, ref_vals), ("merge_to_segment", i)
+                    assert np.array_equal(out.download(n), want_and), ("intersect", i)
+                m.free()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    repeats = [w.counters()[:2] for w in workers]
+    assert all(r == (0, 0) for r in repeats), repeats
+    for w in workers:
+        w.close()
+
+
 def test_host_mirror_merge_fans_out_over_workers(ctx):
     # InvertedIndex.Merge(reqCount, mCount, concurrency): same merged count and content with 1 and with 6 workers
     from inverted_index_2_amd.host import InvertedIndex
