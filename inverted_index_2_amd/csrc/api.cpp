@@ -160,6 +160,7 @@ void ii2_ctx_destroy(ii2_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ii2_lookback_forget(ctx);
     ii2_comm_destroy_internal(ctx);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->aux) (void)hipFree(ctx->aux);
@@ -884,13 +885,19 @@ static int ii2_setop_small_unlocked(ii2_ctx *ctx, bool is_union, uint32_t n, con
 // So, per device: a look-back kernel (exclusive = true) waits - on the GPU, not on the host - for every earlier kernel of
 // either kind and every later one waits for it; tile kernels (exclusive = false) only wait for the last look-back kernel.
 // Kernels without waits between workgroups run beside all of them as before.
+// The order costs nothing while one context works alone: stream order already is an order, so nothing is recorded or waited for
+// until a DIFFERENT stream comes along - which then records an event on the earlier stream itself (an event recorded late only
+// covers more) and waits for that.  (Recording after every launch put a marker between back-to-back queries of one context: 41 ->
+// 46 us per two-list AND.)
 namespace {
 struct LbChain {
-    hipEvent_t ev_x = nullptr;              // the last exclusive kernel
-    bool has_x = false;
-    hipEvent_t ev_s[16] = {};               // the shared kernels since then (a ring: the 17th waits for the 1st)
-    bool has_s[16] = {};
-    unsigned next_s = 0;
+    hipEvent_t ev_x = nullptr;              // the last exclusive kernel: recorded here (x_recorded), or still only in its stream's order (x_stream)
+    bool x_recorded = false;
+    hipStream_t x_stream = nullptr;         // stream of the last exclusive kernel while the event is not recorded yet
+    hipStream_t x_owner = nullptr;          // ... and once it is (that stream needs no wait)
+    hipEvent_t ev_s[16] = {};               // the shared kernels since then: one stream each
+    hipStream_t s_stream[16] = {};
+    unsigned n_s = 0;
 };
 std::mutex g_lb_mu;
 LbChain g_lb[64];
@@ -901,25 +908,52 @@ int ii2_lookback_launch(ii2_ctx *ctx, bool exclusive, const std::function<hipErr
     if (ctx->opt_debug_no_chain) { HIP_TRY(ctx, launch()); return II2_OK; }      // (experiments: what happens without the order)
     std::lock_guard<std::mutex> g(g_lb_mu);
     LbChain &c = g_lb[dev];
+    hipStream_t me = ctx->stream;
     if (!c.ev_x) {
         HIP_TRY(ctx, hipEventCreateWithFlags(&c.ev_x, hipEventDisableTiming));
         for (int i = 0; i < 16; i++) HIP_TRY(ctx, hipEventCreateWithFlags(&c.ev_s[i], hipEventDisableTiming));
     }
-    if (c.has_x) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c.ev_x, 0));
+    // behind the last exclusive kernel
+    if (c.x_stream && c.x_stream != me) {
+        HIP_TRY(ctx, hipEventRecord(c.ev_x, c.x_stream));
+        c.x_recorded = true; c.x_owner = c.x_stream; c.x_stream = nullptr;
+    }
+    if (c.x_recorded && c.x_owner != me) HIP_TRY(ctx, hipStreamWaitEvent(me, c.ev_x, 0));
     if (exclusive) {
-        for (int i = 0; i < 16; i++)
-            if (c.has_s[i]) { HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c.ev_s[i], 0)); c.has_s[i] = false; }
+        // ... and behind every shared kernel since then
+        for (unsigned i = 0; i < c.n_s; i++) {
+            if (c.s_stream[i] == me) continue;
+            HIP_TRY(ctx, hipEventRecord(c.ev_s[i], c.s_stream[i]));
+            HIP_TRY(ctx, hipStreamWaitEvent(me, c.ev_s[i], 0));
+        }
+        c.n_s = 0;
         HIP_TRY(ctx, launch());
-        HIP_TRY(ctx, hipEventRecord(c.ev_x, ctx->stream));
-        c.has_x = true;
+        c.x_stream = me; c.x_recorded = false; c.x_owner = nullptr;
     } else {
-        const unsigned slot = c.next_s++ % 16u;
-        if (c.has_s[slot]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, c.ev_s[slot], 0));
+        bool known = false;
+        for (unsigned i = 0; i < c.n_s; i++) known |= c.s_stream[i] == me;
+        if (!known && c.n_s == 16u) {          // (more than 16 streams with a shared kernel in flight: this one queues behind the first)
+            HIP_TRY(ctx, hipEventRecord(c.ev_s[0], c.s_stream[0]));
+            HIP_TRY(ctx, hipStreamWaitEvent(me, c.ev_s[0], 0));
+            c.s_stream[0] = me;
+            known = true;
+        }
         HIP_TRY(ctx, launch());
-        HIP_TRY(ctx, hipEventRecord(c.ev_s[slot], ctx->stream));
-        c.has_s[slot] = true;
+        if (!known) c.s_stream[c.n_s++] = me;
     }
     return II2_OK;
+}
+// a context goes away (its stream has been waited for): nothing of it is left to wait for
+void ii2_lookback_forget(ii2_ctx *ctx) {
+    if (ctx->device < 0 || ctx->device >= 64) return;
+    std::lock_guard<std::mutex> g(g_lb_mu);
+    LbChain &c = g_lb[ctx->device];
+    if (c.x_stream == ctx->stream) c.x_stream = nullptr;
+    if (c.x_owner == ctx->stream) c.x_owner = nullptr;          // (the recorded event stays valid: it is the chain's own)
+    unsigned k = 0;
+    for (unsigned i = 0; i < c.n_s; i++)
+        if (c.s_stream[i] != ctx->stream) c.s_stream[k++] = c.s_stream[i];
+    c.n_s = k;
 }
 
 int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb) {

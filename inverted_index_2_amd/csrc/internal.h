@@ -297,6 +297,7 @@ hipError_t launch_intersect_and2(const DenseParams &p, hipStream_t s, hipEvent_t
 
 }  // namespace ii2
 int ii2_lookback_prepare(ii2_ctx *ctx, size_t n_wg, ii2::LookBack *lb);      // api.cpp; ctx->mu held
+void ii2_lookback_forget(ii2_ctx *ctx);      // api.cpp: the context's stream is about to be destroyed
 int ii2_lookback_launch(ii2_ctx *ctx, bool exclusive, const std::function<hipError_t()> &launch);      // api.cpp; ctx->mu held: kernels that wait between workgroups, ordered per device
 namespace ii2 {
 
