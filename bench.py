@@ -639,11 +639,12 @@ def bench_merge(job):
         seg_s = (time.perf_counter() - t0s) / steps
         enc_in = sum(sg.info.n_bytes for sg in segs) + 8 * sum(sg.info.n_blocks for sg in segs) + 4 * k * (T + 1)
         alg_s = enc_in + args.docs // 8 + int(minfo.n_bytes) + 8 * int(minfo.n_blocks) + 4 * (T + 1)     # SURVEY §8 d, enc_bytes(out) form
+        traffic_s, traffic_s_src = pmc_traffic("merge_to_segment")
         res["to_segment"] = {
             "value": n_in / seg_s, "unit": "postings/s", "ms_per_step": seg_s * 1e3, "steps": steps,
             "ratio_to_raw_merge": seg_s / (dt / steps), "out_payload_bytes": int(minfo.n_bytes), "out_blocks": int(minfo.n_blocks),
             "roofline": {"bound": "hbm", "achieved": alg_s / seg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_s / seg_s / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": int(alg_s), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(alg_s), "traffic": traffic_s, "traffic_source": traffic_s_src,
                          "timing": "wall clock per ii2_merge_segments_to_seg call (two host waits inside: the merge's counts, the encoder's byte count)"},
             "what": "the drop-in Shard.Merge path: merge + one-pass DV1 encode of the merged terms into a ready segment",
             "check": "decodes to the oracle-checked raw merge" if ok_s else "MISMATCH"}

@@ -28,6 +28,8 @@ sq intersect k_and2 scripts/c2_loop.py steps=5
 sq merge k_merge_tiles scripts/merge_loop.py steps=3
 sq encode k_enc_stream scripts/m2s_loop.py steps=3
 sq c5 k_isect scripts/c5_loop.py steps=5
+# the PMC summaries go where bench.py looks for them (profiles/, this box's copy of the tree): the bench lines below then carry `traffic`
+python3 scripts/r04_collect.py $out > /dev/null
 mkdir -p $out/bench
 timeout -k 5 1000 rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench -o bench -- python3 bench.py --steps 20 --warmup 5 > $out/bench_under_profiler.json 2> $out/bench_under_profiler.err || echo "bench profile failed"
 find $out/bench -name "*kernel_stats.csv" -exec cp {} $out/bench_kernel_stats.csv \;
