@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--strong-last-share", type=float, default=0.5,
                     help="merge_strong: cost share of a rank's LAST chunk relative to the others (its exchange is the only one no later "
                          "merge hides)")
-    ap.add_argument("--strong-workers", type=int, default=3,
+    ap.add_argument("--strong-workers", type=int, default=2,
                     help="merge_strong: chunks merged side by side, one context (stream + scratch) each - the reference's "
                          "InvertedIndex.Merge(…, concurrency) fan-out (inverted_index.go:62-109) on one GPU")
     ap.add_argument("--c5-docs", type=int, default=1_000_000_000, help="c5: doc-id universe of the whole index (config 5: 1B)")
