@@ -54,14 +54,17 @@ def concat_in_rank_order(parts: Sequence[np.ndarray]) -> np.ndarray:
     return np.concatenate(list(parts)) if len(parts) else np.empty(0, np.uint32)
 
 
-# Merge cost per posting by term size, relative to a giant term (measured range by range on one MI355X, round 3,
-# scripts/strong_ranges.py 16, 64 segments, 0.2 ms of per-call fixed cost taken off): the densest terms go through bitmap tiles
-# (0.7 - 1.0), everything between ~1M and a few thousand postings through range tiles at about twice that whatever the size,
-# batches of small terms pay per list on top (block set-up, one 16-byte piece per tiny list).  Sizes are for the 100M-doc
-# universe of the configs.  (Round 2's table put the mid-size terms at 1.0 - 1.2: with it the two mid ranks of an 8-way
-# split took 2.8 ms against the head rank's 1.7.)
-_COST_LOG10_SIZE = np.array([1.95, 2.35, 2.75, 3.3, 4.4, 4.9, 5.9, 6.45, 7.1, 7.76])
-_COST_PER_POSTING = np.array([3.2, 2.6, 2.1, 2.0, 2.05, 1.93, 1.78, 1.09, 0.71, 1.0])
+# Merge cost per posting by term size, relative to a giant term (measured on one MI355X: every rank's share of the 8-way split of
+# C4 - 64 segments - timed through BENCH_PRETEND=r/8 python bench.py --workload strong, ~0.6 ms of per-step fixed cost taken off;
+# round 4's kernels): the densest terms go through bitmap tiles (0.7 - 1.0), terms of a few hundred thousand postings through range
+# tiles at about twice that, and terms of ~800 - 8,000 postings at more than three times (peak near 2,000: the boundary between
+# batches and range tiles): with 64 segments such a term is 12 - 120 postings per list, one mostly empty block each, and every
+# (range tile, list) pair needs its cut; batches of small
+# terms pay per list on top (block set-up, one 16-byte piece per tiny list).  Sizes are for the 100M-doc universe of the
+# configs.  (Round 3's table had everything between a few thousand and a million postings at ~2.0: the two mid ranks of the
+# 8-way split then took 3.65 ms against 2.6 - 2.9 for the others.)
+_COST_LOG10_SIZE = np.array([1.9, 2.1, 2.4, 2.7, 3.0, 3.3, 3.6, 3.9, 4.2, 4.5, 4.9, 5.4, 5.9, 6.45, 7.1, 7.76])
+_COST_PER_POSTING = np.array([4.2, 3.8, 3.1, 2.85, 3.4, 3.9, 3.5, 3.0, 2.3, 2.1, 2.05, 2.0, 1.7, 1.2, 0.75, 1.0])
 
 
 # DV1-encoding the merged postings (merge -> segment, what Shard.Merge does) costs the same per posting whatever the term:
