@@ -199,6 +199,33 @@ def test_segments_concatenate_like_the_exchange_would(ctx):
         ctx.seg_concat([view, segs[2]])
 
 
+def test_a_view_of_some_lists_knows_its_own_size(ctx):
+    """ii2_seg_select: a view shares its store's skip table and payload, but what a merge of it can read is its own lists -
+    its posting count is exact (a merge sizes its plan, its scratch and its launches by it: a view that reported its store's
+    total made every merge of a few lists of a big segment plan for the whole segment), and merging views gives what merging
+    the same lists as segments of their own gives."""
+    rng = np.random.default_rng(21)
+    lens = [0, 5, 300, 0, 7000, 1, 0, 64, 257, 0, 90_000, 3]
+    lists = [sorted_unique(rng, n, 1 << 26) for n in lens]
+    other = [x[::3].copy() for x in lists]
+    a, b = ctx.encode_lists(lists), ctx.encode_lists(other)
+    for lo, hi in ((0, len(lens)), (2, 6), (4, 5), (6, 7), (9, 12), (0, 1)):
+        idx = np.arange(lo, hi, dtype=np.int64)
+        va, vb = ctx.select(a, idx), ctx.select(b, idx)
+        assert va.info.n_lists == hi - lo and va.info.n_postings == sum(x.size for x in lists[lo:hi])
+        assert vb.info.n_postings == sum(x.size for x in other[lo:hi])
+        oo, ov, st = ctx.merge([va, vb])
+        sa, sb = ctx.encode_lists(lists[lo:hi]), ctx.encode_lists(other[lo:hi])
+        wo, wv, wst = ctx.merge([sa, sb])
+        assert st.n_out == wst.n_out and np.array_equal(oo.download(), wo.download()) and np.array_equal(ov.download(int(st.n_out)), wv.download(int(wst.n_out)))
+        m, _ = ctx.merge_to_segment([va, vb])
+        if st.n_out:
+            po, v = m.decode()
+            assert np.array_equal(po, wo.download()) and np.array_equal(v, wv.download(int(wst.n_out)))
+        else:
+            assert m is None
+
+
 def test_freed_segment_arrays_are_reused_not_returned_to_the_driver(ctx):
     """devmem.cpp: a freed segment's device arrays wait in a size-class cache; making the same segment again takes them out
     of it instead of allocating (ii2_devmem_stats: live bytes come back to the same value, idle bytes do not grow)."""
