@@ -318,6 +318,11 @@ int ii2_selftest(ii2_ctx *ctx);
  *   intersect.and2                          dense 2-list ANDs: 1 one launch (look-back for the output offsets), 2 two kernels, 0 the n-list kernel
  *   encode.stream                           merged segments encoded in one pass over the ids (1) or by the two-pass encoder (0)
  *   merge.spin, intersect.and2_spin         polls a bounded inter-workgroup wait may take (tests shorten them; see ii2_ctx_counters)
+ *   merge.alone                             Mi input postings above which a merge's tile kernel does not share the GPU with another
+ *                                           context's (default 64: big ones only get in each other's way, small ones hide each other's tails)
+ *   debug.no_chain                          experiments: the kernels that wait between workgroups (one-launch AND, one-pass encoder,
+ *                                           direct placement) are NOT ordered per device across contexts (they may
+ *                                           then hold each other's slots until their bounded waits run out)
  *   debug.stamps, profile.events            see ii2_debug_read / ii2_profile_read below
  * Every combination returns the same results; the tests run the kernels with the alternatives switched on and off. */
 int ii2_set_option(ii2_ctx *ctx, const char *name, int64_t value);
