@@ -265,7 +265,8 @@ static int seg_alloc_meta(ii2_ctx *ctx, ii2_seg *seg) {
 }
 
 // have_meta: the encoder filled d_cnt / d_last_doc / d_blk_list from the CSR it encoded (no list has to be decoded for them)
-static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
+// everything a finished segment still needs, enqueued (no wait): the caller waits for the stream and then calls seg_finish_done
+static int seg_finish_enqueue(ii2_ctx *ctx, ii2_seg *seg, bool have_meta, bool *count_view_out) {
     if (!seg->store) {
         seg->store = std::make_shared<ii2_seg_store>();
         seg->store->d_skip = seg->d_skip;
@@ -298,9 +299,18 @@ static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
         HIP_TRY(ctx, launch_sum_u32(seg->d_cnt, seg->n_lists, ctx->d_mail + 16, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 16, ctx->d_mail + 16, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count_view_out = count_view;
+    return II2_OK;
+}
+static void seg_finish_done(ii2_ctx *ctx, ii2_seg *seg, bool count_view) {
     if (count_view) seg->n_postings = std::min<uint64_t>(seg->n_postings, ctx->h_mail[16]);
     seg->born = nullptr;                                    // finished: from here on the caller's contract governs its lifetime
+}
+static int seg_finish(ii2_ctx *ctx, ii2_seg *seg, bool have_meta = false) {
+    bool count_view = false;
+    if (int rc = seg_finish_enqueue(ctx, seg, have_meta, &count_view)) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    seg_finish_done(ctx, seg, count_view);
     return II2_OK;
 }
 
@@ -407,6 +417,10 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
         })) return rcq;
     HIP_TRY(ctx, launch_enc_list_meta(d_post_off, d_values, n_lists, seg->d_cnt, seg->d_last_doc, st));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 8, d_res, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    // the mirrors a finished segment keeps (list spans of small segments) depend on nothing the host still has to learn: they are
+    // enqueued behind the encoder and ONE wait serves the byte count and them
+    bool count_view = false;
+    if (int rcf = seg_finish_enqueue(ctx, seg.get(), true, &count_view)) return rcf;
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint64_t nbytes = ctx->h_mail[8], nb = ctx->h_mail[9];
     if (nbytes == ~0ull || nb > nb_bound) {        // a bounded wait ran out, or the bound did not hold: the exact two-pass form
@@ -416,9 +430,7 @@ int ii2_seg_encode_stream_unlocked(ii2_ctx *ctx, uint64_t n_lists, const uint64_
     }
     seg->n_blocks = nb;
     seg->n_bytes = nbytes;
-    int rc = seg_finish(ctx, seg.get(), true);
-    if (rc) return rc;
-    seg->born = nullptr;
+    seg_finish_done(ctx, seg.get(), count_view);
     *out = seg.release();
     return II2_OK;
 }
