@@ -307,6 +307,8 @@ hipError_t launch_selftest(uint32_t *d_fail, uint8_t *d_scratch, hipStream_t s);
 // scans (scan.hip) — temp storage comes from the caller
 size_t scan_temp_bytes(size_t n);
 hipError_t scan_excl_u32(void *tmp, size_t tmp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
+hipError_t scan3_excl(void *tmp, size_t tmp_bytes, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
+                      uint32_t *out2, size_t n, hipStream_t s);      // three scans of one length in the launches of one; tmp: 3 x scan_temp_bytes(n)
 hipError_t scan_excl_u32_to_u64(void *tmp, size_t tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, hipStream_t s);
 hipError_t scan_excl_u32_to_u64_guarded(void *tmp, size_t tmp_bytes, const uint32_t *in, uint64_t *out, size_t n, const uint64_t *guard,
                                         uint64_t guard_max, hipStream_t s);
@@ -411,6 +413,8 @@ constexpr uint32_t MERGE_DESC_LARGE = 1u << 30;   // desc.y: the tile belongs to
 constexpr uint32_t MERGE_DESC_BITMAP = 1u << 31;  // desc.y: bitmap tile
 
 hipError_t launch_merge_plan_terms(const MergeSegs *ms, const MergeParams &p, hipStream_t s);
+hipError_t launch_merge_init(uint64_t *mail, uint32_t n_mail_words64, uint32_t *cnt, uint64_t n_cnt, void *aux, uint64_t aux_bytes, uint64_t *tile_off,
+                             uint64_t n_off, hipStream_t s);      // the call's clears in one launch (aux_bytes: a multiple of 4)
 hipError_t launch_merge_heads(const MergeParams &p, const uint64_t *wpre, uint32_t *head, hipStream_t s);
 hipError_t launch_merge_term_tile(const MergeParams &p, const uint32_t *head, const uint32_t *hpre, const uint32_t *lpre,
                                   uint32_t *term_tile, hipStream_t s);

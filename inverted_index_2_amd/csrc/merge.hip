@@ -1521,6 +1521,25 @@ hipError_t launch_merge_plan_terms(const MergeSegs *ms, const MergeParams &p, hi
     else hipLaunchKernelGGL(k_mp_terms, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, ms, p);
     return hipGetLastError();
 }
+// everything a call clears before its tile kernel, in one launch (four memsets were four dependent launches of ~5 us each): the
+// result words, the per-term output counts, the tickets / tile counts / bump allocators, and - direct placement - the tiles'
+// offsets, all ones = "not known yet"
+__global__ __launch_bounds__(256) void k_merge_init(uint32_t *__restrict__ mail, uint32_t n_mail, uint32_t *__restrict__ cnt, uint64_t n_cnt,
+                                                    uint32_t *__restrict__ aux, uint64_t n_aux, uint32_t *__restrict__ off, uint64_t n_off) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_mail) mail[t] = 0u;
+    for (uint64_t i = t; i < n_cnt; i += stride) cnt[i] = 0u;
+    for (uint64_t i = t; i < n_aux; i += stride) aux[i] = 0u;
+    for (uint64_t i = t; i < n_off; i += stride) off[i] = 0xFFFFFFFFu;
+}
+hipError_t launch_merge_init(uint64_t *mail, uint32_t n_mail_words64, uint32_t *cnt, uint64_t n_cnt, void *aux, uint64_t aux_bytes, uint64_t *tile_off,
+                             uint64_t n_off, hipStream_t s) {
+    const uint64_t most = std::max<uint64_t>(std::max<uint64_t>(n_cnt, aux_bytes / 4u), 2u * n_off);
+    const unsigned grid = (unsigned)std::min<uint64_t>((most + 1023u) / 1024u + 1u, 4096u);      // (four words per thread and round)
+    hipLaunchKernelGGL(k_merge_init, dim3(grid), dim3(256), 0, s, (uint32_t *)mail, 2u * n_mail_words64, cnt, n_cnt, (uint32_t *)aux, aux_bytes / 4u,
+                       (uint32_t *)tile_off, 2u * n_off);
+    return hipGetLastError();
+}
 hipError_t launch_merge_heads(const MergeParams &p, const uint64_t *wpre, uint32_t *head, hipStream_t s) {
     hipLaunchKernelGGL(k_merge_heads, dim3(grid_for(p.n_terms + 1)), dim3(256), 0, s, p, wpre, head);
     return hipGetLastError();

@@ -107,7 +107,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     const size_t n1 = (size_t)T + 1;
     const size_t scan_b = scan_temp_bytes(n1 + 1);
     // ws: per-term plan arrays
-    size_t need = 11 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) + scan_b + 4096;
+    size_t need = 11 * align_up(n1 * sizeof(uint32_t)) + 2 * align_up(n1 * sizeof(uint64_t)) + 3 * scan_b + 4096;
     int rc = ii2_ws_reserve(ctx, need);
     if (rc) return rc;
     uint8_t *cur = ctx->ws;
@@ -149,9 +149,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_segs, hs, sizeof(MergeSegs), hipMemcpyHostToDevice, st));
     // ---- plan (device): per-term counts and doc ranges, batches, tiles, the blocks every range tile has to decode ----
     HIP_TRY(ctx, launch_merge_plan_terms(d_ms, p, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, p.weight, d_wpre, n1, st));
-    HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan, scan_b, p.tn, d_npre, n1, st));
-    HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, p.ntl, d_lpre, n1, st));
+    HIP_TRY(ctx, scan3_excl(d_scan, 3 * scan_b, p.weight, d_wpre, p.tn, d_npre, p.ntl, d_lpre, n1, st));      // (three scans, the launches of one)
     HIP_TRY(ctx, launch_merge_heads(p, d_wpre, d_head, st));
     HIP_TRY(ctx, scan_excl_u32(d_scan, scan_b, d_head, d_hpre, n1, st));
     HIP_TRY(ctx, launch_merge_term_tile(p, d_head, d_hpre, d_lpre, d_tt, st));
@@ -172,16 +170,15 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
             return fail(ctx, II2_ENOMEM, "debug buffer allocation failed");
         p.debug = ctx->d_debug;
     }
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_mail, 0, 4 * sizeof(uint64_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(d_cnt, 0, n1 * sizeof(uint32_t), st));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->aux, 0, zero_bytes, st));         // tickets / frontier, tile counts (tiles past the real count contribute 0), bump allocators
     // 2 workgroups of ~75 KB LDS per CU.  When the caller's buffer is known to hold any result (out_cap >= all input postings)
     // the tiles put their survivors in place themselves (ticket order, one scanner workgroup: merge.hip) - every posting
     // crosses HBM once on its way in and once on its way out.  Otherwise (the fit is only known at the end, and the call is
     // all-or-nothing) the tiles park and a packing pass follows the scan of their counts.
     p.tile_off = d_tile_off;
     p.direct = (postings_ub <= out_cap && ctx->opt_merge_direct) ? 1u : 0u;
-    if (p.direct) HIP_TRY(ctx, hipMemsetAsync(d_tile_off, 0xFF, nt1 * sizeof(uint64_t), st));      // all-ones: "offset not known yet"
+    // one launch clears the result words, the per-term counts, the tickets / frontier / tile counts (tiles past the real count
+    // contribute 0) / bump allocators and - direct placement - sets the tiles' offsets to all ones: "not known yet"
+    HIP_TRY(ctx, launch_merge_init(ctx->d_mail, 4, d_cnt, n1, ctx->aux, zero_bytes, d_tile_off, p.direct ? nt1 : 0, st));
     if (p.direct) {
         // its workers wait for its scanner workgroup: never beside a look-back kernel (api.cpp).  Beside another tile kernel it is
         // safe, and worth it for small merges (a few tiles per workgroup: one kernel's tail hides behind the other's body - the

@@ -85,6 +85,61 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const TI *in, TO *o
     }
 }
 
+// ---- three scans of equal length in the launches of one (blockIdx.y = which array): the merge's plan scans its terms' weights
+// and posting counts (to u64) and their tile counts (to u32) one after the other - nine dependent launches of ~6 us each on a
+// merge of any size, a third of the whole call for the ones between a few thousand and a million postings
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan3_reduce(const uint32_t *__restrict__ in0, const uint32_t *__restrict__ in1,
+                                                               const uint32_t *__restrict__ in2, uint64_t n, uint64_t *__restrict__ part, uint64_t tiles) {
+    __shared__ uint64_t wsum[SCAN_THREADS / 64];
+    const uint32_t *in = blockIdx.y == 0 ? in0 : blockIdx.y == 1 ? in1 : in2;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_PER_THREAD; j++)
+        if (base + j < n) s += (uint64_t)in[base + j];
+    uint64_t tot;
+    (void)wg_excl_scan64(s, wsum, &tot);
+    if (threadIdx.x == 0) part[(uint64_t)blockIdx.y * tiles + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan3_tiles(uint64_t *__restrict__ part3, uint64_t n_tiles) {
+    __shared__ uint64_t wsum[SCAN_THREADS / 64];
+    uint64_t *part = part3 + (uint64_t)blockIdx.x * n_tiles;
+    uint64_t carry = 0;
+    for (uint64_t i0 = 0; i0 < n_tiles; i0 += SCAN_THREADS) {
+        const uint64_t i = i0 + threadIdx.x;
+        const uint64_t v = i < n_tiles ? part[i] : 0;
+        uint64_t tot;
+        const uint64_t ex = wg_excl_scan64(v, wsum, &tot);
+        if (i < n_tiles) part[i] = carry + ex;
+        carry += tot;
+    }
+}
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan3_apply(const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
+                                                              uint32_t *out2, uint64_t n, const uint64_t *__restrict__ part, uint64_t tiles) {
+    __shared__ uint64_t wsum[SCAN_THREADS / 64];
+    const uint32_t y = blockIdx.y;
+    const uint32_t *in = y == 0 ? in0 : y == 1 ? in1 : in2;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_PER_THREAD;
+    uint64_t v[SCAN_PER_THREAD];
+    uint64_t s = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_PER_THREAD; j++) {
+        v[j] = base + j < n ? (uint64_t)in[base + j] : 0;
+        s += v[j];
+    }
+    uint64_t tot;
+    uint64_t run = (part ? part[(uint64_t)y * tiles + blockIdx.x] : 0ull) + wg_excl_scan64(s, wsum, &tot);
+#pragma unroll
+    for (uint32_t j = 0; j < SCAN_PER_THREAD; j++) {
+        if (base + j < n) {
+            if (y == 0) out0[base + j] = run;
+            else if (y == 1) out1[base + j] = run;
+            else out2[base + j] = (uint32_t)run;
+        }
+        run += v[j];
+    }
+}
+
 size_t scan_temp_bytes(size_t n) {
     const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE + 1;
     return (tiles * sizeof(uint64_t) + 255) & ~(size_t)255;
@@ -120,6 +175,23 @@ hipError_t scan_excl_u32_to_u64_guarded(void *tmp, size_t tmp_bytes, const uint3
 }
 hipError_t scan_excl_u64(void *tmp, size_t tmp_bytes, const uint64_t *in, uint64_t *out, size_t n, hipStream_t s) {
     return scan_excl<uint64_t, uint64_t>(tmp, tmp_bytes, in, out, n, s);
+}
+
+// tmp: 3 x scan_temp_bytes(n).  The outputs may be their inputs' arrays only where the element types agree (out2 / in2).
+hipError_t scan3_excl(void *tmp, size_t tmp_bytes, const uint32_t *in0, uint64_t *out0, const uint32_t *in1, uint64_t *out1, const uint32_t *in2,
+                      uint32_t *out2, size_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    const size_t tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (tmp_bytes < 3 * tiles * sizeof(uint64_t)) return hipErrorInvalidValue;
+    uint64_t *part = (uint64_t *)tmp;
+    if (tiles == 1) {
+        hipLaunchKernelGGL(k_scan3_apply, dim3(1, 3), dim3(SCAN_THREADS), 0, s, in0, out0, in1, out1, in2, out2, (uint64_t)n, (const uint64_t *)nullptr, (uint64_t)1);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_scan3_reduce, dim3((unsigned)tiles, 3), dim3(SCAN_THREADS), 0, s, in0, in1, in2, (uint64_t)n, part, (uint64_t)tiles);
+    hipLaunchKernelGGL(k_scan3_tiles, dim3(3), dim3(SCAN_THREADS), 0, s, part, (uint64_t)tiles);
+    hipLaunchKernelGGL(k_scan3_apply, dim3((unsigned)tiles, 3), dim3(SCAN_THREADS), 0, s, in0, out0, in1, out1, in2, out2, (uint64_t)n, (const uint64_t *)part, (uint64_t)tiles);
+    return hipGetLastError();
 }
 
 }  // namespace ii2
