@@ -423,6 +423,7 @@ hipError_t launch_merge_tile_runs(const MergeSegs *ms, const MergeParams &p, hip
 hipError_t launch_merge_tiles(const MergeSegs *ms, const MergeParams &p, uint32_t grid, hipStream_t s);
 hipError_t launch_merge_large_counts(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
 hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hipStream_t s);
-hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s);
+hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s, const uint32_t *err = nullptr, const uint32_t *n_tiles = nullptr,
+                                uint64_t *mail = nullptr);      // mail: also mail[3] = *err (0 without), mail[4] = *n_tiles
 
 }  // namespace ii2

@@ -1501,8 +1501,15 @@ __global__ void k_merge_large_counts(MergeParams p, const uint64_t *__restrict__
 }
 
 // one atomic per workgroup, few workgroups: a single address sustains only ~90 device atomics per microsecond
-__global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out) {
+// (and what else the host reads at the end of a merge, so that ONE copy fetches it: mail[3] = the direct placement's error word,
+// mail[4] = the number of tiles)
+__global__ __launch_bounds__(256) void k_count_nonzero(const uint32_t *__restrict__ v, uint64_t n, uint64_t *__restrict__ out,
+                                                       const uint32_t *__restrict__ err, const uint32_t *__restrict__ n_tiles, uint64_t *__restrict__ mail) {
     __shared__ uint32_t wsum[4];
+    if (mail && blockIdx.x == 0 && threadIdx.x == 0) {
+        mail[3] = err ? (uint64_t)__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        mail[4] = n_tiles ? (uint64_t)*n_tiles : 0ull;
+    }
     uint32_t c = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) c += v[i] != 0;
     c = wave_sum(c);
@@ -1577,11 +1584,11 @@ hipError_t launch_merge_pack(const MergeParams &p, const uint64_t *tile_off, hip
                        (const uint32_t *)p.tile_count, tile_off, p.n_tiles_dev, p.out_values, p.out_cap, p.d_total);
     return hipGetLastError();
 }
-hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    unsigned g = grid_for(n);
+hipError_t launch_count_nonzero(const uint32_t *v, uint64_t n, uint64_t *out, hipStream_t s, const uint32_t *err, const uint32_t *n_tiles, uint64_t *mail) {
+    if (n == 0 && !mail) return hipSuccess;
+    unsigned g = grid_for(n ? n : 1);
     if (g > 128) g = 128;
-    hipLaunchKernelGGL(k_count_nonzero, dim3(g), dim3(256), 0, s, v, n, out);
+    hipLaunchKernelGGL(k_count_nonzero, dim3(g), dim3(256), 0, s, v, n, out, err, n_tiles, mail);
     return hipGetLastError();
 }
 

@@ -192,16 +192,14 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     if (!p.direct) {
         HIP_TRY(ctx, scan_excl_u32_to_u64(d_scan_t, scan_t, p.tile_count, d_tile_off, nt1, st));
         HIP_TRY(ctx, launch_merge_pack(p, d_tile_off, st));
-    } else {
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_mail + 3, &p.sync->error, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));      // -> h_mail[3]
     }
     HIP_TRY(ctx, launch_merge_large_counts(p, d_tile_off, st));
-    HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st));
+    // (the same launch leaves the direct placement's error word and the tile count in the mailbox: one copy fetches everything)
+    HIP_TRY(ctx, launch_count_nonzero(d_cnt, T, ctx->d_mail + 2, st, p.direct ? &p.sync->error : nullptr, p.n_tiles_dev, ctx->d_mail));
     // all-or-nothing: like the packing pass, the offsets are only written when the result fits the caller's buffer
     if (d_out_off) HIP_TRY(ctx, scan_excl_u32_to_u64_guarded(d_scan, scan_b, d_cnt, d_out_off, n1, ctx->d_mail, out_cap, st));
     if (e1) (void)hipEventRecord(e1, st);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail + 4, p.n_tiles_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_mail, ctx->d_mail, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     const uint32_t n_tiles = (uint32_t)(ctx->h_mail[4] & 0xFFFFFFFFull);
     if (n_tiles > p.n_tiles_ub) return fail(ctx, II2_EHIP, "merge: internal error (tile bound exceeded)");
