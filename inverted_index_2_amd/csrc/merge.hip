@@ -88,6 +88,18 @@ __global__ __launch_bounds__(256) void k_mp_terms(const MergeSegs *__restrict__ 
         } else {
             tiles = (uint32_t)(((uint64_t)n32 + p.range_target - 1) / p.range_target);
             if (best_nb < 2u * tiles) info |= 1u << 9;     // too few blocks to cut at: splitters uniform in doc space
+            else {
+                // cuts at block boundaries of the longest list give the fullest tile ceil(nb / tiles) of its nb blocks: with a
+                // handful of blocks per tile (few segments: a tile is several blocks of every list) that is well over the
+                // average - 7 blocks into 2 tiles are 3 + 4, the second tile overflows and is bisected, decoding its blocks
+                // again and again (one such tile was 185 of a 250 us merge).  Up to two tiles more bring the fullest one under
+                // the target (the plan's upper bound of the tile count has room for them).
+                for (uint32_t extra = 0; extra < 2u; extra++) {
+                    const uint32_t most = (best_nb + tiles - 1u) / tiles;
+                    if ((uint64_t)n32 * most <= (uint64_t)p.range_target * best_nb) break;
+                    tiles++;
+                }
+            }
         }
     } else {
         w = n32 > p.wmin ? n32 : p.wmin;
@@ -147,6 +159,18 @@ __global__ __launch_bounds__(256) void k_mp_terms_few(const MergeSegs *__restric
         } else {
             tiles = (uint32_t)(((uint64_t)n32 + p.range_target - 1) / p.range_target);
             if (best_nb < 2u * tiles) info |= 1u << 9;     // too few blocks to cut at: splitters uniform in doc space
+            else {
+                // cuts at block boundaries of the longest list give the fullest tile ceil(nb / tiles) of its nb blocks: with a
+                // handful of blocks per tile (few segments: a tile is several blocks of every list) that is well over the
+                // average - 7 blocks into 2 tiles are 3 + 4, the second tile overflows and is bisected, decoding its blocks
+                // again and again (one such tile was 185 of a 250 us merge).  Up to two tiles more bring the fullest one under
+                // the target (the plan's upper bound of the tile count has room for them).
+                for (uint32_t extra = 0; extra < 2u; extra++) {
+                    const uint32_t most = (best_nb + tiles - 1u) / tiles;
+                    if ((uint64_t)n32 * most <= (uint64_t)p.range_target * best_nb) break;
+                    tiles++;
+                }
+            }
         }
     } else {
         w = n32 > p.wmin ? n32 : p.wmin;

@@ -86,7 +86,7 @@ static int merge_core(ii2_ctx *ctx, uint32_t k, const SegView *views, uint64_t n
     // `sparsity` docs, ceil(span / MERGE_BM_DOCS) <= n * sparsity / MERGE_BM_DOCS + 1 bitmap tiles; a batch ends when its
     // weight passes batch_q or a large term interrupts the run of small ones
     const uint64_t n_large_ub = postings_ub / ((uint64_t)p.small_max + 1u);
-    const uint64_t tiles_ub64 = postings_ub / p.range_target + (postings_ub * p.bitmap_sparsity) / MERGE_BM_DOCS + 2 * n_large_ub +
+    const uint64_t tiles_ub64 = postings_ub / p.range_target + (postings_ub * p.bitmap_sparsity) / MERGE_BM_DOCS + 4 * n_large_ub +      // (+ 2 per large term: block-granular cuts, k_mp_terms)
                                 (postings_ub + T * p.wmin) / p.batch_q + n_large_ub + 4;
     if (tiles_ub64 >= (1ull << 31) || tiles_ub64 * k >= (1ull << 32)) return fail(ctx, II2_ERANGE, "merge: too many tiles");
     p.n_tiles_ub = (uint32_t)tiles_ub64;
