@@ -203,6 +203,23 @@ class Job:
         from inverted_index_2_amd import Context
         self.ctx = Context(device)
         self.ctx.selftest()
+        self.parts = {}            # the bench objects measured so far (what the watchdog prints if a later exchange gets stuck)
+        if self.world > 1 and self.rank == 0:
+            import signal
+
+            def on_term(signum, frame):      # the launcher ends the job because another rank failed: leave what has been measured
+                if self.parts:
+                    try:
+                        line = assemble(self, dict(self.parts))
+                        line["aborted"] = "terminated by the launcher (another rank failed); objects measured after that are missing"
+                        print(json.dumps(line), flush=True)
+                    except Exception:  # noqa: BLE001
+                        pass
+                os._exit(3)
+            try:
+                signal.signal(signal.SIGTERM, on_term)
+            except (ValueError, OSError):
+                pass
         self.comm = None           # "ii2" | "torch" once decided (identically on every rank)
         self.comm_main = False     # the job's own context has its communicator
         self.rc = 0
@@ -278,6 +295,15 @@ class Job:
             if not done.is_set():
                 print("rank %d: %s did not finish within %d s — aborting" % (self.rank, what, self.args.gather_timeout),
                       file=sys.stderr, flush=True)
+                # what has been measured so far is not lost with the stuck step: rank 0 still prints its line (marked), then
+                # the process leaves NON-zero - the first N > 1 run is the first time the RCCL exchanges execute at all
+                if self.rank == 0 and self.parts:
+                    try:
+                        line = assemble(self, dict(self.parts))
+                        line["aborted"] = "%s did not finish within %d s; objects measured after it are missing" % (what, self.args.gather_timeout)
+                        print(json.dumps(line), flush=True)
+                    except Exception as e:  # noqa: BLE001
+                        print("rank 0: could not assemble the partial line: %r" % (e,), file=sys.stderr, flush=True)
                 os._exit(3)
 
         timer = threading.Timer(self.args.gather_timeout, on_timeout)
@@ -464,6 +490,7 @@ def bench_intersect(job):
             res["union"] = {"error": repr(e)}
 
     # the exchange step, once, after the timed region: rank-order concatenation of the results
+    job.parts["intersect"] = res           # (measured: a stuck exchange below no longer takes the headline with it)
     if world > 1:
         def exchange():
             job.torch.cuda.synchronize()
@@ -788,6 +815,8 @@ def bench_merge_strong(job):
             seg_bytes = int(inf.n_bytes + 8 * inf.n_blocks + 4 * inf.n_lists)
         if world == 1 and seg is None:
             return 0, True
+        if os.environ.get("BENCH_STUCK"):          # (rehearsal of the watchdog: an exchange that never comes back)
+            time.sleep(3600)
         if world == 1 or job.comm == "ii2":
             if seg is None:          # a chunk in which nothing survived still takes part in the collective
                 seg = empty_seg
@@ -1080,27 +1109,9 @@ def bench_c5(job):
     return res
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(self_launch(args))
-    if args.dry_run:
-        sys.exit(dry_run(args))
-    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != max(args.gpus, 1):
-        print("bench.py: --gpus %d but the launcher started %s ranks; the line reports the ranks that run" % (args.gpus, os.environ["WORLD_SIZE"]),
-              file=sys.stderr, flush=True)
-    job = Job(args)
-    world, rank = job.world, job.rank
-    parts = {}
-    if args.workload in ("all", "intersect"):
-        parts["intersect"] = bench_intersect(job)
-    if args.workload in ("all", "merge") and world == 1:
-        parts["merge"] = bench_merge(job)
-    if args.workload in ("all", "strong") or (args.workload == "merge" and world > 1):
-        parts["merge_strong"] = bench_merge_strong(job)
-    if args.workload in ("all", "c5"):
-        parts["c5"] = bench_c5(job)
-
+def assemble(job, parts):
+    """The one JSON line from the bench objects measured so far (the headline is the first of intersect / merge / merge_strong / c5)."""
+    args, world = job.args, job.world
     head = parts.get("intersect") or parts.get("merge") or parts.get("merge_strong") or parts["c5"]
     result = {
         "metric": METRIC, "value": head["value"], "unit": "postings/s", "n_gpus": world, "steps": args.steps if "intersect" in parts else head.get("steps", args.steps),
@@ -1117,6 +1128,52 @@ def main():
     for name in ("merge", "merge_strong", "c5"):
         if name in parts and parts[name] is not head:
             result[name] = parts[name]
+    return result
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.dry_run:
+        sys.exit(dry_run(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != max(args.gpus, 1):
+        print("bench.py: --gpus %d but the launcher started %s ranks; the line reports the ranks that run" % (args.gpus, os.environ["WORLD_SIZE"]),
+              file=sys.stderr, flush=True)
+    job = Job(args)
+    world, rank = job.world, job.rank
+    parts = job.parts
+    if args.workload in ("all", "intersect"):
+        parts["intersect"] = bench_intersect(job)
+
+    def secondary(name, fn):
+        """A bench object besides the headline: what goes wrong in it is reported in its place (and in the exit code), the
+        line with everything else is still printed."""
+        try:
+            parts[name] = fn(job)
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            print("rank %d: %s failed: %r" % (rank, name, e), file=sys.stderr, flush=True)
+            if not parts:
+                raise
+            if world > 1:
+                # the other ranks are inside this object's collectives: this rank cannot go on to the next object without
+                # crossing them.  Rank 0 leaves what it has measured on stdout; the launcher ends the job.
+                if rank == 0:
+                    line = assemble(job, dict(parts))
+                    line["aborted"] = "%s failed on rank 0: %r; objects measured after it are missing" % (name, e)
+                    print(json.dumps(line), flush=True)
+                raise
+            parts[name] = {"error": repr(e)}
+            job.rc = max(job.rc, 6)
+    if args.workload in ("all", "merge") and world == 1:
+        secondary("merge", bench_merge)
+    if args.workload in ("all", "strong") or (args.workload == "merge" and world > 1):
+        secondary("merge_strong", bench_merge_strong)
+    if args.workload in ("all", "c5"):
+        secondary("c5", bench_c5)
+    result = assemble(job, parts)
     if job.rehearse:
         result["rehearsal"] = "all %d ranks shared cuda:0 (gloo control plane, torch exchange fallback): control-flow check only" % world
     if world > 1:
